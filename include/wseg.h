@@ -1,0 +1,155 @@
+/*
+ * wseg.h — C-ABI of libwseg.so, the MI355X (gfx950) hot path of whisperseg_amd.
+ *
+ * The reference (nianlonggu/WhisperSeg) has no FFI of its own: its boundary is Python duck-typing
+ * inside model.py.  Each entry point below therefore cites the reference call (file:line, relative to
+ * the reference repo root) whose device work it replaces; the Python host side in
+ * whisperseg_amd/{audio_utils,model,engine}.py binds these with ctypes and mirrors the reference's
+ * class/method surface.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  Every pointer documented "device" is a HIP device
+ *     pointer owned by the caller (PyTorch-ROCm allocates; the library never allocates or frees device
+ *     memory and never takes ownership).  `stream` is a hipStream_t passed as void* (NULL = default).
+ *   - Every function returns 0 on success, a negative wseg_status otherwise; wseg_last_error()
+ *     returns a thread-local message for the last failure.
+ *   - Functions are thread-compatible: distinct models / distinct streams may be used concurrently
+ *     from distinct host threads (the reference calls its backend from one Python thread per device,
+ *     model.py:173-184).
+ */
+#ifndef WSEG_H
+#define WSEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WSEG_ABI_VERSION 1
+
+typedef enum {
+  WSEG_OK = 0,
+  WSEG_ERR_INVALID = -1,    /* bad argument / unsupported geometry */
+  WSEG_ERR_HIP = -2,        /* a HIP runtime call or kernel launch failed */
+  WSEG_ERR_STATE = -3,      /* model not fully populated, workspace too small, ... */
+  WSEG_ERR_NO_DEVICE = -4   /* no gfx950 device visible */
+} wseg_status;
+
+typedef enum { WSEG_F32 = 0, WSEG_BF16 = 1 } wseg_dtype;
+
+int wseg_abi_version(void);
+const char* wseg_last_error(void);
+/* Name / gcnArch of the current device, or an error if none is visible. */
+int wseg_device_info(char* name_out, size_t name_cap, int* cu_count_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Log-mel front-end.
+ * Replaces, per window: reference audio_utils.py:45-76 (WhisperSegFeatureExtractor) ->
+ * HF feature_extraction_whisper.py:105-133 (_np_extract_fbank_features) -> HF audio_utils.py:809-1017
+ * (spectrogram), and the window slicing / zero padding / column truncation / min-fill of
+ * reference model.py:140-161 — all windows of a recording in one launch pair.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t n_fft;            /* 512 | 1024 | 2048 | 4096 | 8192  (reference audio_utils.py:32-43) */
+  int32_t hop;              /* int(spec_time_step * sr)          (reference audio_utils.py:48)    */
+  int32_t n_mels;           /* 80 */
+  int32_t n_cols;           /* total_spec_columns, 1000          (reference model.py:153)          */
+  const float* window;      /* device [n_fft]      periodic Hann                                   */
+  const float* twiddle;     /* device [n_fft/2][2] (cos, -sin)(2*pi*k/n_fft)                        */
+  const int32_t* mel_start; /* device [n_mels]     first non-zero FFT bin of each filter           */
+  const int32_t* mel_count; /* device [n_mels]     number of consecutive non-zero bins             */
+  const int32_t* mel_offset;/* device [n_mels]     offset of the filter's weights in mel_weight    */
+  const float* mel_weight;  /* device [sum(mel_count)] slaney triangle weights                     */
+} wseg_logmel_desc;
+
+/* Bytes of float scratch needed by wseg_logmel_f32 for n_windows windows of win_len samples. */
+size_t wseg_logmel_scratch_bytes(const wseg_logmel_desc* d, int32_t n_windows, int64_t win_len);
+
+/*
+ * audio      device float32 [n_audio]   the whole recording (mono), resident in HBM
+ * win_start  device int64   [n_windows] first sample of each window relative to audio[0]; may be
+ *                                        negative (multi-trial left padding, reference model.py:138-143)
+ *                                        or run past the end (zero-filled, reference model.py:150)
+ * win_len    samples per window = int(total_spec_columns * spec_time_step * sr)  (model.py:133)
+ * out        device float32 [n_windows][n_mels][n_cols]
+ */
+int wseg_logmel_f32(const wseg_logmel_desc* d, const float* audio, int64_t n_audio,
+                    const int64_t* win_start, int32_t n_windows, int64_t win_len,
+                    void* scratch, size_t scratch_bytes, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whisper encoder-decoder.
+ * Replaces HF WhisperForConditionalGeneration as the reference drives it:
+ *   construction  reference model.py:626-644 (WhisperSegmenter.__init__, from_pretrained)
+ *   generate      reference model.py:647-676 / 604-622 (model.generate(...) per batch)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t d_model, n_heads, enc_layers, dec_layers, ffn, vocab;
+  int32_t n_mels;           /* 80   */
+  int32_t spec_cols;        /* 1000 */
+  int32_t enc_positions;    /* 500 = spec_cols / 2 (reference model.py:79) */
+  int32_t dec_positions;    /* 448  */
+  int32_t dtype;            /* wseg_dtype: arithmetic/storage type of weights and activations */
+} wseg_model_config;
+
+typedef struct wseg_model wseg_model;
+
+int wseg_model_create(const wseg_model_config* cfg, wseg_model** out);
+void wseg_model_destroy(wseg_model* m);
+/*
+ * Attach one prepared weight tensor (device pointer, caller-owned, must outlive the model).
+ * Names and layouts are listed in whisperseg_amd/engine.py::prepare_weights (e.g. "enc.0.qkv.w"
+ * = [3*d_model, d_model] row-major in the model dtype).  bytes is checked against the expected size.
+ */
+int wseg_model_set_tensor(wseg_model* m, const char* name, const void* dev_ptr, size_t bytes);
+/* 0 when every tensor the geometry needs has been attached. */
+int wseg_model_ready(const wseg_model* m);
+
+/* Workspace (device bytes) needed for up to max_windows windows per call. */
+size_t wseg_workspace_bytes(const wseg_model* m, int32_t max_windows, int32_t num_beams, int32_t max_length);
+
+/*
+ * Encoder only: feats device float32 [n_windows][80][1000] -> enc_out device [n_windows][500][d_model]
+ * in the model dtype.  (HF modeling_whisper.py:592-646 as reached from reference model.py:655.)
+ */
+int wseg_encode(wseg_model* m, const float* feats, int32_t n_windows,
+                void* workspace, size_t workspace_bytes, void* enc_out, void* stream);
+
+typedef struct {
+  int32_t prompt[8];              /* decoder_input_ids, reference model.py:656 */
+  int32_t prompt_len;
+  int32_t eos_token_id, pad_token_id;   /* reference model.py:658-659 */
+  int32_t max_length;             /* total length incl. prompt (HF 4.38.2 semantics), model.py:660 */
+  int32_t num_beams;              /* 1 = greedy (do_sample with top_k=1, model.py:662-663), else beam search */
+  float length_penalty;           /* model.py:665 */
+  const int32_t* suppress_tokens; /* device [n_suppress]   generation_config.suppress_tokens        */
+  int32_t n_suppress;
+  const int32_t* begin_suppress_tokens; /* device [n_begin_suppress] applied at the first generated position */
+  int32_t n_begin_suppress;
+} wseg_generate_params;
+
+/*
+ * Full decode of n_windows windows: encoder, cross-K/V, then greedy / beam search with HF semantics
+ * (generation/utils.py:3208-3510), entirely on device.
+ *   out_tokens  device int32 [n_windows][max_length]  best sequence INCLUDING the prompt, pad-filled
+ *   out_lengths device int32 [n_windows]              number of valid tokens (prompt + generated)
+ * The call is asynchronous with respect to the host except for a small per-step "all finished" poll.
+ */
+int wseg_generate(wseg_model* m, const float* feats, int32_t n_windows, const wseg_generate_params* p,
+                  void* workspace, size_t workspace_bytes,
+                  int32_t* out_tokens, int32_t* out_lengths, void* stream);
+
+/* Debug/parity taps (used by tests): first-step logits fp32 [n_windows*num_beams][vocab] of the last
+ * wseg_generate call are kept in the workspace; this copies them out (device to device). */
+int wseg_debug_first_logits(wseg_model* m, void* workspace, float* out, int32_t n_rows, void* stream);
+
+/* Per-stage device time (ms) of the last wseg_generate call on this model, measured with HIP events
+ * on the call's stream: [0]=encoder, [1]=cross-K/V, [2]=decode loop, [3]=number of decode steps. */
+int wseg_last_timing(const wseg_model* m, float out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WSEG_H */

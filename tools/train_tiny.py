@@ -1,0 +1,75 @@
+"""Train the tiny fixture model on CPU (build container only) and write tests/golden/tiny_model/.
+
+Synthetic task in the reference's label grammar (reference datautils.py:329-390): tone bursts in
+noise -> "<|unknown|>" + "<|onset|>cluster<|offset|>"* + <|endoftext|>.  The point is not accuracy but
+a model whose next-token distributions are peaked and whose EOS fires at data-dependent lengths, so
+that beam-search parity (oracle vs HF, HIP engine vs oracle) is exercised on meaningful sequences.
+Weights are rounded to bf16 before saving so that the fp32 oracle and the bf16 engine share them exactly.
+
+    python tools/train_tiny.py [--steps 2500]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.frontend import logmel_window  # noqa: E402
+from tools import tiny_model as TM  # noqa: E402
+
+
+def make_batch(rng, bs, max_len=40):
+    feats, dec_in, labels = [], [], []
+    for _ in range(bs):
+        x, ev = TM.synth_clip(rng)
+        f = logmel_window(x, TM.SR, TM.STS)[:, :1000]
+        ids = TM.PROMPT + TM.label_tokens(ev)
+        d_in = ids[:-1]
+        lab = [-100, -100] + ids[3:]          # predict only after the prompt
+        lab = ids[1:]
+        lab = [-100 if i < 2 else t for i, t in enumerate(lab)]
+        d_in = d_in + [TM.EOT] * (max_len - len(d_in))
+        lab = lab + [-100] * (max_len - len(lab))
+        feats.append(f)
+        dec_in.append(d_in[:max_len])
+        labels.append(lab[:max_len])
+    return (torch.from_numpy(np.stack(feats)), torch.tensor(dec_in), torch.tensor(labels))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=2500)
+    ap.add_argument("--bs", type=int, default=16)
+    ap.add_argument("--out", default="tests/golden/tiny_model")
+    args = ap.parse_args()
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    cd = TM.hf_config_dict()
+    extra = {k: cd.pop(k) for k in ("total_spec_columns", "cluster_codebook", "default_segmentation_config", "model_type")}
+    cfg = WhisperConfig(**cd, suppress_tokens=None, begin_suppress_tokens=None)
+    model = WhisperForConditionalGeneration(cfg)
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-3, weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=2e-3, total_steps=args.steps, pct_start=0.1)
+    rng = np.random.default_rng(1234)
+    model.train()
+    t0 = time.time()
+    for step in range(args.steps):
+        f, d_in, lab = make_batch(rng, args.bs)
+        out = model(input_features=f, decoder_input_ids=d_in, labels=lab)
+        out.loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step(); sched.step(); opt.zero_grad()
+        if step % 50 == 0:
+            print(f"step {step} loss {out.loss.item():.4f}  {time.time()-t0:.0f}s", flush=True)
+    model.eval()
+    sd = {k: v.detach().to(torch.bfloat16) for k, v in model.state_dict().items() if k != "proj_out.weight"}
+    TM.write_model_dir(args.out, sd)
+    print("saved", args.out)
+
+
+if __name__ == "__main__":
+    main()
