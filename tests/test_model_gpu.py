@@ -1,0 +1,116 @@
+"""HIP encoder / decoder / beam search (through the C-ABI) vs the oracle on seeded random weights.
+
+f32 mode  : exact-parity mode of the same kernels; tolerance 5e-4 abs on O(1) activations / logits and
+            token-exact sequences.
+bf16 mode : production mode; weights are rounded to bf16 on BOTH sides, tolerance is relative to the
+            activation scale (bf16 has 8 mantissa bits; ~1e-2 after 2-4 layers is the expected class).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import whisper_ref as R
+
+pytestmark = pytest.mark.gpu
+
+PROMPT = [1100, 1102, 1103]
+EOS = 1101
+
+
+def hf_cfg(d=128, heads=2, layers=2, ffn=512, vocab=1280):
+    return dict(d_model=d, encoder_attention_heads=heads, decoder_attention_heads=heads, encoder_layers=layers,
+                decoder_layers=layers, encoder_ffn_dim=ffn, decoder_ffn_dim=ffn, vocab_size=vocab, num_mel_bins=80,
+                max_source_positions=500, max_target_positions=448)
+
+
+def make(cfg, dtype, seed=1):
+    from whisperseg_amd.engine import Engine
+    rc = R.RefConfig.from_hf_dict(cfg)
+    sd = R.random_state_dict(rc, seed=seed)
+    if dtype == "bf16":
+        sd = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+    eng = Engine.from_state_dict(sd, cfg, "cuda:0", dtype)
+    return rc, sd, eng
+
+
+def feats(n, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, 80, 1000, generator=g) * 0.5
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 5e-4), ("bf16", 6e-2)])
+@pytest.mark.parametrize("n", [1, 3])
+def test_encoder_matches_oracle(gpu_lib, dtype, tol, n):
+    cfg = hf_cfg()
+    rc, sd, eng = make(cfg, dtype)
+    x = feats(n)
+    want = R.encoder_forward(sd, rc, x)
+    got = eng.encode(x.cuda()).float().cpu()
+    assert got.shape == want.shape
+    err = (got - want).abs().max().item()
+    assert err <= tol * max(1.0, want.abs().max().item()), err
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 5e-4), ("bf16", 8e-2)])
+def test_encoder_wider_geometry(gpu_lib, dtype, tol):
+    """d=256 / 4 heads / ffn 1024: exercises multi-tile N and more than two heads."""
+    cfg = hf_cfg(d=256, heads=4, layers=2, ffn=1024)
+    rc, sd, eng = make(cfg, dtype, seed=3)
+    x = feats(2, seed=5)
+    want = R.encoder_forward(sd, rc, x)
+    got = eng.encode(x.cuda()).float().cpu()
+    err = (got - want).abs().max().item()
+    assert err <= tol * max(1.0, want.abs().max().item()), err
+
+
+def gen_params(nb, ml):
+    return R.GenParams(prompt=PROMPT, eos_token_id=EOS, pad_token_id=EOS, max_length=ml, num_beams=nb,
+                       suppress_tokens=[5, 6, 7, 200], begin_suppress_tokens=[220, EOS])
+
+
+@pytest.mark.parametrize("nb", [1, 4])
+def test_first_logits_f32(gpu_lib, nb):
+    cfg = hf_cfg()
+    rc, sd, eng = make(cfg, "f32")
+    x = feats(2)
+    gp = gen_params(nb, 8)
+    _, want = R.generate(sd, rc, x, gp, return_first_logits=True)
+    _, _, got = eng.generate(x.cuda(), PROMPT, EOS, EOS, max_length=8, num_beams=nb, suppress_tokens=gp.suppress_tokens,
+                             begin_suppress_tokens=gp.begin_suppress_tokens, return_first_logits=True)
+    err = (got.cpu() - want).abs().max().item()
+    assert err <= 1e-3, err
+
+
+@pytest.mark.parametrize("nb,ml", [(1, 12), (1, 40), (4, 12), (4, 40), (2, 20)])
+def test_generate_tokens_f32_random_weights(gpu_lib, nb, ml):
+    cfg = hf_cfg()
+    rc, sd, eng = make(cfg, "f32")
+    x = feats(3)
+    gp = gen_params(nb, ml)
+    want = R.generate(sd, rc, x, gp)
+    toks, lens = eng.generate(x.cuda(), PROMPT, EOS, EOS, max_length=ml, num_beams=nb, suppress_tokens=gp.suppress_tokens,
+                              begin_suppress_tokens=gp.begin_suppress_tokens)
+    toks, lens = toks.cpu().numpy(), lens.cpu().numpy()
+    for i in range(3):
+        a = R.canonical(want[i].tolist(), 3, EOS, PROMPT)
+        b = R.canonical(toks[i, :lens[i]].tolist(), 3, EOS, PROMPT)
+        assert a == b, (i, a, b)
+
+
+def test_real_vocab_logits_bf16(gpu_lib):
+    """Whisper's real vocabulary size (51865, not a tile multiple) through the tied LM head."""
+    cfg = hf_cfg(vocab=51865)
+    rc, sd, eng = make(cfg, "bf16", seed=7)
+    x = feats(2, seed=9)
+    prompt, eos = [50258, 50259, 50363], 50257
+    gp = R.GenParams(prompt=prompt, eos_token_id=eos, pad_token_id=eos, max_length=6, num_beams=4,
+                     suppress_tokens=[1, 2, 7, 50258], begin_suppress_tokens=[220, eos])
+    _, want = R.generate(sd, rc, x, gp, return_first_logits=True)
+    _, _, got = eng.generate(x.cuda(), prompt, eos, eos, max_length=6, num_beams=4, suppress_tokens=gp.suppress_tokens,
+                             begin_suppress_tokens=gp.begin_suppress_tokens, return_first_logits=True)
+    got = got.cpu()
+    assert got.shape == want.shape == (8, 51865)
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 8e-2 * max(scale, 1.0)
+    # beams of one window are identical at the first step
+    assert torch.equal(got[0], got[1])

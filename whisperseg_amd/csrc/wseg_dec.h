@@ -1,0 +1,53 @@
+// Decoder-side kernels and the device-resident decoding state (internal to libwseg).
+#pragma once
+#include "wseg_kernels.h"
+
+namespace wseg {
+
+constexpr int MAX_BEAMS = 8;
+constexpr int MAX_CAND = 2 * MAX_BEAMS;
+
+// Everything the decode loop needs lives on the device; the host only enqueues kernels and polls
+// `active[step]`.  W windows, nb beams, R = W * nb rows, L = max_length (cache capacity).
+struct DecodeState {
+  int W, nb, L, V, ldv;            // ldv: leading dimension of the logits buffer (vocab padded)
+  int P;                           // prompt length
+  int eos, pad, max_length;
+  float length_penalty;
+  int prompt[8];
+  int* pos;                        // [1]   position of the token being fed this step
+  int* tokens_in;                  // [R]   token fed at this step
+  int* run_seq;                    // [W][nb][L]
+  int* fin_seq;                    // [W][nb][L]
+  float* run_score;                // [W][nb]
+  float* fin_score;                // [W][nb]
+  int* fin_flag;                   // [W][nb]
+  int* fin_len;                    // [W][nb]  generated length of each finished slot
+  int* unsat;                      // [W]      is_early_stop_heuristic_unsatisfied (beam) / unfinished (greedy)
+  unsigned char* anc;              // [W][nb][L] cache slot (beam index) that holds position p of this row's history
+  float* cand_val;                 // [R][Kc]
+  int* cand_tok;                   // [R][Kc]
+  int* active;                     // [L]      number of windows still improvable after each step
+  const unsigned char* sup_mask;   // [V] bit0: always suppressed, bit1: suppressed at the first generated position
+};
+
+int launch_decode_init(const DecodeState& st, hipStream_t s);
+int launch_build_suppress_mask(unsigned char* mask, int V, const int* sup, int n_sup, const int* bsup, int n_bsup, hipStream_t s);
+// x[r][:] = tok_emb[tokens_in[r]][:] + pos_emb[*pos][:]
+int launch_embed(int dtype, const DecodeState& st, const void* tok_emb, const void* pos_emb, void* x, int d, hipStream_t s);
+// prompt phase: tokens_in <- prompt[*pos + 1], anc[..][*pos] = own slot
+int launch_prompt_feed(const DecodeState& st, hipStream_t s);
+int launch_advance(const DecodeState& st, hipStream_t s);
+// decoder self-attention over the KV cache [R][H][L][64] with per-position ancestry
+int launch_dec_self_attn(int dtype, const DecodeState& st, const void* q, const void* kc, const void* vc, void* out,
+                         int H, int d, hipStream_t s);
+// cross-attention: the nb beams of a window share K/V [W][H][Tk][64]
+int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const void* ck, const void* cv, void* out,
+                          int H, int Tk, int d, hipStream_t s);
+// log-softmax + suppress + running score -> top-2nb per row (beam) / argmax of the processed logits (greedy)
+int launch_row_topk(const DecodeState& st, const float* logits, hipStream_t s);
+int launch_beam_step(const DecodeState& st, hipStream_t s);
+int launch_greedy_step(const DecodeState& st, hipStream_t s);
+int launch_finalize(const DecodeState& st, int* out_tokens, int* out_lengths, hipStream_t s);
+
+}  // namespace wseg

@@ -1,0 +1,472 @@
+// Decoder-step kernels for gfx950: token embedding, KV-cache attention (self: per-row gather through
+// the beam ancestry table, so a beam reorder never copies the cache; cross: the beams of a window share
+// one pass over its 500 encoder keys), and HF-exact greedy / beam-search bookkeeping on the device.
+//
+// Beam semantics follow HF generation/utils.py:3208-3510 (_beam_search) and helpers :3008-3206 literally,
+// including the float32 "+ -1e9" masking arithmetic; see oracle/whisper_ref.py for the CPU restatement.
+// These kernels are HBM/latency-bound integer + VALU work (no MFMA): reads are 128-byte rows.
+#include "wseg_dec.h"
+
+namespace wseg {
+
+// ------------------------------------------------------------------------------------------------
+__global__ void decode_init_kernel(DecodeState st) {
+  const int W = st.W, nb = st.nb, L = st.L;
+  const int total = W * nb * L;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int p = i % L, j = (i / L) % nb;
+    const int v = p < st.P ? st.prompt[p] : st.pad;
+    st.run_seq[i] = v;
+    st.fin_seq[i] = v;
+    st.anc[i] = (unsigned char)j;
+  }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < W * nb; i += gridDim.x * 256) {
+    const int j = i % nb;
+    st.run_score[i] = j == 0 ? 0.0f : -1.0e9f;
+    st.fin_score[i] = -1.0e9f;
+    st.fin_flag[i] = 0;
+    st.fin_len[i] = 0;
+    st.tokens_in[i] = st.prompt[0];
+  }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < W; i += gridDim.x * 256) st.unsat[i] = 1;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < L; i += gridDim.x * 256) st.active[i] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *st.pos = 0;
+}
+
+__global__ void suppress_mask_kernel(unsigned char* mask, int V, const int* sup, int n_sup, const int* bsup, int n_bsup) {
+  // single block: clear, then set bits
+  for (int i = threadIdx.x; i < V; i += blockDim.x) mask[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_sup; i += blockDim.x) { const int t = sup[i]; if (t >= 0 && t < V) atomicOr((unsigned int*)(mask + (t & ~3)), 1u << (8 * (t & 3))); }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_bsup; i += blockDim.x) { const int t = bsup[i]; if (t >= 0 && t < V) atomicOr((unsigned int*)(mask + (t & ~3)), 2u << (8 * (t & 3))); }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_kernel(DecodeState st, const T* __restrict__ tok_emb, const T* __restrict__ pos_emb,
+                                                    T* __restrict__ x, int d) {
+  const int r = blockIdx.x;
+  const int tok = st.tokens_in[r], pos = *st.pos;
+  for (int c = threadIdx.x; c < d; c += 256)
+    El<T>::st(x + (size_t)r * d + c, El<T>::ld(tok_emb + (size_t)tok * d + c) + El<T>::ld(pos_emb + (size_t)pos * d + c));
+}
+
+__global__ void prompt_feed_kernel(DecodeState st) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= st.W * st.nb) return;
+  const int pos = *st.pos;
+  st.tokens_in[i] = st.prompt[pos + 1 < st.P ? pos + 1 : st.P - 1];
+}
+
+__global__ void advance_kernel(DecodeState st) { *st.pos += 1; }
+
+// ------------------------------------------------------------------------------------------------
+// Self-attention, one wave per (row, head).
+// ------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void load_row64(const T* p, float v[64]);
+template <> __device__ __forceinline__ void load_row64<float>(const float* p, float v[64]) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { const float4 t = ((const float4*)p)[i]; v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w; }
+}
+template <> __device__ __forceinline__ void load_row64<bf16_t>(const bf16_t* p, float v[64]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint4 t = ((const uint4*)p)[i];
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[8 * i + 2 * j] = __uint_as_float(w[j] << 16); v[8 * i + 2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const T* __restrict__ q, const T* __restrict__ kc,
+                                                           const T* __restrict__ vc, T* __restrict__ out, int H, int d) {
+  __shared__ float sq[64];
+  __shared__ float sp[512];
+  __shared__ int srow[512];
+  const int lane = threadIdx.x;
+  const int r = blockIdx.x / H, h = blockIdx.x - r * H;
+  const int w = r / st.nb;
+  const int L = st.L;
+  const int n = *st.pos + 1;                      // keys 0 .. pos (the current token's K/V were just appended)
+  sq[lane] = El<T>::ld(q + (size_t)r * d + h * 64 + lane);
+  const unsigned char* anc = st.anc + (size_t)r * L;
+  for (int t = lane; t < n; t += 64) srow[t] = w * st.nb + (t == n - 1 ? (r - w * st.nb) : (int)anc[t]);
+  __syncthreads();
+  float mx = -3.0e38f;
+  for (int t = lane; t < n; t += 64) {
+    float kv[64];
+    load_row64<T>(kc + (((size_t)srow[t] * H + h) * L + t) * 64, kv);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 64; ++e) s = fmaf(sq[e], kv[e], s);
+    sp[t] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int t = lane; t < n; t += 64) { const float p = expf(sp[t] - mx); sp[t] = p; sum += p; }
+  sum = wave_sum(sum);
+  __syncthreads();
+  float acc = 0.f;
+  for (int t = 0; t < n; ++t) acc = fmaf(sp[t], El<T>::ld(vc + (((size_t)srow[t] * H + h) * L + t) * 64 + lane), acc);
+  El<T>::st(out + (size_t)r * d + h * 64 + lane, acc / sum);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cross-attention, one workgroup per (window, head); all beams of the window in one pass over K and V.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dec_cross_attn_kernel(DecodeState st, const T* __restrict__ q, const T* __restrict__ ck,
+                                                             const T* __restrict__ cv, T* __restrict__ out, int H, int Tk, int d) {
+  __shared__ float sq[MAX_BEAMS][64];
+  __shared__ float sc[MAX_BEAMS][512];
+  __shared__ float red[4][MAX_BEAMS][64];
+  __shared__ float sinv[MAX_BEAMS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int w = blockIdx.x / H, h = blockIdx.x - w * H;
+  const int nb = st.nb;
+  for (int i = tid; i < nb * 64; i += 256) {
+    const int j = i >> 6, e = i & 63;
+    sq[j][e] = El<T>::ld(q + (size_t)(w * nb + j) * d + h * 64 + e);
+  }
+  __syncthreads();
+  const T* Kb = ck + ((size_t)w * H + h) * Tk * 64;
+  const T* Vb = cv + ((size_t)w * H + h) * Tk * 64;
+  for (int t = tid; t < Tk; t += 256) {
+    float kv[64];
+    load_row64<T>(Kb + (size_t)t * 64, kv);
+#pragma unroll
+    for (int j = 0; j < MAX_BEAMS; ++j) {
+      if (j < nb) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 64; ++e) s = fmaf(sq[j][e], kv[e], s);
+        sc[j][t] = s;
+      }
+    }
+  }
+  __syncthreads();
+  for (int j = wave; j < nb; j += 4) {
+    float mx = -3.0e38f;
+    for (int t = lane; t < Tk; t += 64) mx = fmaxf(mx, sc[j][t]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int t = lane; t < Tk; t += 64) { const float p = expf(sc[j][t] - mx); sc[j][t] = p; sum += p; }
+    sum = wave_sum(sum);
+    if (lane == 0) sinv[j] = 1.0f / sum;
+  }
+  __syncthreads();
+  float acc[MAX_BEAMS];
+#pragma unroll
+  for (int j = 0; j < MAX_BEAMS; ++j) acc[j] = 0.f;
+  const int per = (Tk + 3) / 4, t0 = wave * per, t1 = min(Tk, t0 + per);
+  for (int t = t0; t < t1; ++t) {
+    const float v = El<T>::ld(Vb + (size_t)t * 64 + lane);
+#pragma unroll
+    for (int j = 0; j < MAX_BEAMS; ++j)
+      if (j < nb) acc[j] = fmaf(sc[j][t], v, acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < MAX_BEAMS; ++j)
+    if (j < nb) red[wave][j][lane] = acc[j];
+  __syncthreads();
+  for (int i = tid; i < nb * 64; i += 256) {
+    const int j = i >> 6, e = i & 63;
+    const float o = ((red[0][j][e] + red[1][j][e]) + red[2][j][e]) + red[3][j][e];
+    El<T>::st(out + (size_t)(w * nb + j) * d + h * 64 + e, o * sinv[j]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-row candidates: log_softmax (fp32) -> suppress -> + running beam score -> top-Kc.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool better(float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); }
+
+template <int KC>
+__global__ __launch_bounds__(256) void row_topk_kernel(DecodeState st, const float* __restrict__ logits) {
+  __shared__ float s_red[4];
+  __shared__ float s_bv[4];
+  __shared__ int s_bi[4];
+  __shared__ int s_bt[4];
+  __shared__ float s_bcast[2];
+  __shared__ int s_winner;
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int V = st.V;
+  const float* x = logits + (size_t)r * st.ldv;
+  const bool greedy = st.nb == 1;
+  const int Kc = greedy ? 1 : 2 * st.nb;
+  const int cur_len = *st.pos + 1;
+  const unsigned char begin_bit = (cur_len == st.P) ? 2 : 0;
+
+  float shift = 0.f, lse = 0.f, base = 0.f;
+  if (!greedy) {
+    float mx = -3.0e38f;
+    for (int i = tid; i < V; i += 256) mx = fmaxf(mx, x[i]);
+    mx = wave_max(mx);
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = tid; i < V; i += 256) sum += expf(x[i] - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) s_red[wave] = sum;
+    __syncthreads();
+    sum = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    shift = mx;
+    lse = logf(sum);
+    base = st.run_score[r];
+  }
+  float tv[KC];
+  int ti[KC];
+#pragma unroll
+  for (int j = 0; j < KC; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
+  for (int i = tid; i < V; i += 256) {
+    float v = x[i];
+    if (!greedy) v = ((v - shift) - lse);
+    if (st.sup_mask[i] & (1 | begin_bit)) v = -INFINITY;
+    if (!greedy) v = v + base;
+    if (better(v, i, tv[KC - 1], ti[KC - 1])) {
+#pragma unroll
+      for (int j = KC - 1; j >= 0; --j) {
+        const bool gt_prev = (j > 0) ? better(v, i, tv[j > 0 ? j - 1 : 0], ti[j > 0 ? j - 1 : 0]) : false;
+        const bool gt_cur = better(v, i, tv[j], ti[j]);
+        if (gt_prev) { tv[j] = tv[j - 1 >= 0 ? j - 1 : 0]; ti[j] = ti[j - 1 >= 0 ? j - 1 : 0]; }
+        else if (gt_cur) { tv[j] = v; ti[j] = i; }
+      }
+    }
+  }
+  // block merge: Kc rounds of arg-best over the per-thread heads
+  for (int k = 0; k < Kc; ++k) {
+    float bv = tv[0];
+    int bi = ti[0], bt = tid;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64), ot = __shfl_xor(bt, o, 64);
+      if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; bt = ot; }
+    }
+    if (lane == 0) { s_bv[wave] = bv; s_bi[wave] = bi; s_bt[wave] = bt; }
+    __syncthreads();
+    if (tid == 0) {
+      float fv = s_bv[0]; int fi = s_bi[0], ft = s_bt[0];
+      for (int q = 1; q < 4; ++q) if (better(s_bv[q], s_bi[q], fv, fi)) { fv = s_bv[q]; fi = s_bi[q]; ft = s_bt[q]; }
+      st.cand_val[(size_t)r * Kc + k] = fv;
+      st.cand_tok[(size_t)r * Kc + k] = fi;
+      s_winner = ft;
+    }
+    __syncthreads();
+    if (tid == s_winner) {
+#pragma unroll
+      for (int j = 0; j < KC - 1; ++j) { tv[j] = tv[j + 1]; ti[j] = ti[j + 1]; }
+      tv[KC - 1] = -INFINITY; ti[KC - 1] = 0x7fffffff;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Beam bookkeeping: one 64-lane workgroup per window (lane 0 decides, all lanes move sequences).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void beam_step_kernel(DecodeState st) {
+  __shared__ float c_val[MAX_CAND];
+  __shared__ int c_beam[MAX_CAND], c_tok[MAX_CAND], c_hit[MAX_CAND];
+  __shared__ float run_val[MAX_CAND], fin_cand[MAX_CAND];
+  __shared__ int run_src[MAX_BEAMS], run_tok[MAX_BEAMS], fin_src[MAX_BEAMS];
+  __shared__ float n_run_score[MAX_BEAMS], n_fin_score[MAX_BEAMS];
+  __shared__ int n_fin_flag[MAX_BEAMS], n_fin_len[MAX_BEAMS];
+  __shared__ int head[MAX_BEAMS];
+  const int w = blockIdx.x, lane = threadIdx.x;
+  const int nb = st.nb, Kc = 2 * nb, L = st.L, P = st.P;
+  const int cur_len = *st.pos + 1;      // tokens present before this step's choice
+  if (lane == 0) {
+    // c. top-Kc continuations over nb*V accumulated log-probs (each row's list is already sorted)
+    for (int j = 0; j < nb; ++j) head[j] = 0;
+    for (int k = 0; k < Kc; ++k) {
+      int bj = -1; float bv = 0.f; int bt = 0;
+      for (int j = 0; j < nb; ++j) {
+        if (head[j] >= Kc) continue;
+        const size_t o = (size_t)(w * nb + j) * Kc + head[j];
+        const float v = st.cand_val[o];
+        const int t = st.cand_tok[o];
+        if (bj < 0 || v > bv) { bj = j; bv = v; bt = t; }   // ties keep the lower flat index (lower beam)
+      }
+      head[bj]++;
+      c_val[k] = bv; c_beam[k] = bj; c_tok[k] = bt;
+      // d. stopping criteria: EOS or max_length reached
+      c_hit[k] = (bt == st.eos) || (cur_len + 1 >= st.max_length);
+    }
+    // e. running beams for the next iteration
+    for (int k = 0; k < Kc; ++k) run_val[k] = c_val[k] + (c_hit[k] ? 1.0f : 0.0f) * -1.0e9f;
+    unsigned used = 0;
+    for (int i = 0; i < nb; ++i) {
+      int bk = -1;
+      for (int k = 0; k < Kc; ++k) if (!((used >> k) & 1u) && (bk < 0 || run_val[k] > run_val[bk])) bk = k;
+      used |= 1u << bk;
+      run_src[i] = c_beam[bk]; run_tok[i] = c_tok[bk]; n_run_score[i] = run_val[bk];
+    }
+    // f. finished beams
+    const int un = st.unsat[w];
+    const float denom = (float)pow((double)(cur_len + 1 - P), (double)st.length_penalty);
+    for (int k = 0; k < Kc; ++k) {
+      const int did = c_hit[k] && k < nb;
+      float v = c_val[k] / denom;
+      v = v + 0.0f * -1.0e9f;                       // beams_in_batch_are_full & early_stopping(False)
+      v = v + (un ? 0.0f : 1.0f) * -1.0e9f;
+      v = v + (did ? 0.0f : 1.0f) * -1.0e9f;
+      fin_cand[k] = v;
+    }
+    unsigned usedm = 0;
+    for (int i = 0; i < nb; ++i) {
+      int bi = -1; float bv = 0.f;
+      for (int m = 0; m < nb + Kc; ++m) {
+        if ((usedm >> m) & 1u) continue;
+        const float v = m < nb ? st.fin_score[w * nb + m] : fin_cand[m - nb];
+        if (bi < 0 || v > bv) { bi = m; bv = v; }
+      }
+      usedm |= 1u << bi;
+      fin_src[i] = bi;
+      n_fin_score[i] = bv;
+      n_fin_flag[i] = bi < nb ? st.fin_flag[w * nb + bi] : (c_hit[bi - nb] && (bi - nb) < nb);
+      n_fin_len[i] = bi < nb ? st.fin_len[w * nb + bi] : cur_len + 1 - P;
+    }
+    // g. early-stop heuristic (early_stopping=False): can the best running beam still beat the worst finished one?
+    const float best_running = n_run_score[0] / (float)pow((double)(cur_len + 1 - P), (double)st.length_penalty);
+    float mn = n_fin_score[0];
+    for (int i = 1; i < nb; ++i) mn = fminf(mn, n_fin_score[i]);
+    int improve = 0;
+    for (int i = 0; i < nb; ++i) { const float worst = n_fin_flag[i] ? mn : -1.0e9f; if (best_running > worst) improve = 1; }
+    const int un_new = un && improve;
+    st.unsat[w] = un_new;
+    if (un_new) atomicAdd(&st.active[cur_len - 1], 1);
+    for (int i = 0; i < nb; ++i) {
+      st.run_score[w * nb + i] = n_run_score[i];
+      st.fin_score[w * nb + i] = n_fin_score[i];
+      st.fin_flag[w * nb + i] = n_fin_flag[i];
+      st.fin_len[w * nb + i] = n_fin_len[i];
+      st.tokens_in[w * nb + i] = run_tok[i];
+    }
+  }
+  __syncthreads();
+  int* run = st.run_seq + (size_t)w * nb * L;
+  int* fin = st.fin_seq + (size_t)w * nb * L;
+  unsigned char* anc = st.anc + (size_t)w * nb * L;
+  for (int p = lane; p < L; p += 64) {          // every position column is independent: read all, then write
+    int rv[MAX_BEAMS], fv[MAX_BEAMS];
+    unsigned char av[MAX_BEAMS];
+#pragma unroll
+    for (int i = 0; i < MAX_BEAMS; ++i) {
+      if (i < nb) {
+        const int src = run_src[i];
+        rv[i] = p < cur_len ? run[src * L + p] : (p == cur_len ? run_tok[i] : st.pad);
+        av[i] = p < cur_len ? anc[src * L + p] : (unsigned char)i;
+        const int fs = fin_src[i];
+        if (fs < nb) fv[i] = fin[fs * L + p];
+        else { const int k = fs - nb; fv[i] = p < cur_len ? run[c_beam[k] * L + p] : (p == cur_len ? c_tok[k] : st.pad); }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAX_BEAMS; ++i) {
+      if (i < nb) { run[i * L + p] = rv[i]; anc[i * L + p] = av[i]; fin[i * L + p] = fv[i]; }
+    }
+  }
+}
+
+__global__ void greedy_step_kernel(DecodeState st) {
+  const int w = blockIdx.x * 64 + threadIdx.x;
+  if (w >= st.W) return;
+  const int L = st.L;
+  const int cur_len = *st.pos + 1;
+  int unfinished = st.unsat[w];
+  int tok = st.cand_tok[w];
+  if (!unfinished) tok = st.pad;
+  st.run_seq[(size_t)w * L + cur_len] = tok;
+  st.anc[(size_t)w * L + cur_len] = 0;
+  st.tokens_in[w] = tok;
+  if (unfinished && (tok == st.eos || cur_len + 1 >= st.max_length)) {
+    unfinished = 0;
+    st.fin_len[w] = cur_len + 1 - st.P;
+  }
+  st.unsat[w] = unfinished;
+  if (unfinished) atomicAdd(&st.active[cur_len - 1], 1);
+}
+
+__global__ void finalize_kernel(DecodeState st, int* out_tokens, int* out_lengths) {
+  const int w = blockIdx.x, L = st.L;
+  const int* src = (st.nb == 1 ? st.run_seq : st.fin_seq) + (size_t)w * st.nb * L;
+  const int len = st.P + st.fin_len[w * st.nb];
+  for (int p = threadIdx.x; p < L; p += blockDim.x) out_tokens[(size_t)w * L + p] = p < len ? src[p] : st.pad;
+  if (threadIdx.x == 0) out_lengths[w] = len;
+}
+
+// ------------------------------------------------------------------------------------------------
+int launch_decode_init(const DecodeState& st, hipStream_t s) {
+  hipLaunchKernelGGL(decode_init_kernel, dim3(64), dim3(256), 0, s, st);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+int launch_build_suppress_mask(unsigned char* mask, int V, const int* sup, int n_sup, const int* bsup, int n_bsup, hipStream_t s) {
+  hipLaunchKernelGGL(suppress_mask_kernel, dim3(1), dim3(1024), 0, s, mask, V, sup, n_sup, bsup, n_bsup);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+int launch_embed(int dtype, const DecodeState& st, const void* tok_emb, const void* pos_emb, void* x, int d, hipStream_t s) {
+  const int R = st.W * st.nb;
+  if (dtype == WSEG_BF16) hipLaunchKernelGGL((embed_kernel<bf16_t>), dim3(R), dim3(256), 0, s, st, (const bf16_t*)tok_emb, (const bf16_t*)pos_emb, (bf16_t*)x, d);
+  else hipLaunchKernelGGL((embed_kernel<float>), dim3(R), dim3(256), 0, s, st, (const float*)tok_emb, (const float*)pos_emb, (float*)x, d);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+int launch_prompt_feed(const DecodeState& st, hipStream_t s) {
+  hipLaunchKernelGGL(prompt_feed_kernel, dim3(cdiv(st.W * st.nb, 256)), dim3(256), 0, s, st);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+int launch_advance(const DecodeState& st, hipStream_t s) {
+  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, st);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+int launch_dec_self_attn(int dtype, const DecodeState& st, const void* q, const void* kc, const void* vc, void* out, int H, int d, hipStream_t s) {
+  if (st.L > 512) { set_error("self-attention: max_length %d > 512", st.L); return WSEG_ERR_INVALID; }
+  const int R = st.W * st.nb;
+  if (dtype == WSEG_BF16) hipLaunchKernelGGL((dec_self_attn_kernel<bf16_t>), dim3(R * H), dim3(64), 0, s, st, (const bf16_t*)q, (const bf16_t*)kc, (const bf16_t*)vc, (bf16_t*)out, H, d);
+  else hipLaunchKernelGGL((dec_self_attn_kernel<float>), dim3(R * H), dim3(64), 0, s, st, (const float*)q, (const float*)kc, (const float*)vc, (float*)out, H, d);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const void* ck, const void* cv, void* out, int H, int Tk, int d, hipStream_t s) {
+  if (Tk > 512) { set_error("cross-attention: %d encoder positions > 512", Tk); return WSEG_ERR_INVALID; }
+  if (dtype == WSEG_BF16) hipLaunchKernelGGL((dec_cross_attn_kernel<bf16_t>), dim3(st.W * H), dim3(256), 0, s, st, (const bf16_t*)q, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)out, H, Tk, d);
+  else hipLaunchKernelGGL((dec_cross_attn_kernel<float>), dim3(st.W * H), dim3(256), 0, s, st, (const float*)q, (const float*)ck, (const float*)cv, (float*)out, H, Tk, d);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+int launch_row_topk(const DecodeState& st, const float* logits, hipStream_t s) {
+  const int R = st.W * st.nb;
+  const int Kc = st.nb == 1 ? 1 : 2 * st.nb;
+  if (Kc == 1) hipLaunchKernelGGL((row_topk_kernel<1>), dim3(R), dim3(256), 0, s, st, logits);
+  else if (Kc <= 4) hipLaunchKernelGGL((row_topk_kernel<4>), dim3(R), dim3(256), 0, s, st, logits);
+  else if (Kc <= 8) hipLaunchKernelGGL((row_topk_kernel<8>), dim3(R), dim3(256), 0, s, st, logits);
+  else hipLaunchKernelGGL((row_topk_kernel<16>), dim3(R), dim3(256), 0, s, st, logits);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+int launch_beam_step(const DecodeState& st, hipStream_t s) {
+  hipLaunchKernelGGL(beam_step_kernel, dim3(st.W), dim3(64), 0, s, st);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+int launch_greedy_step(const DecodeState& st, hipStream_t s) {
+  hipLaunchKernelGGL(greedy_step_kernel, dim3(cdiv(st.W, 64)), dim3(64), 0, s, st);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+int launch_finalize(const DecodeState& st, int* out_tokens, int* out_lengths, hipStream_t s) {
+  hipLaunchKernelGGL(finalize_kernel, dim3(st.W), dim3(256), 0, s, st, out_tokens, out_lengths);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+
+}  // namespace wseg

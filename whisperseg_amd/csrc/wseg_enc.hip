@@ -1,0 +1,340 @@
+// Encoder-side kernels for gfx950: conv-as-GEMM operand builders (im2col), LayerNorm, and the
+// encoder self-attention (T = 500 keys, head_dim 64, no mask).
+//
+// Attention (bf16): flash-style, one workgroup = 128 query rows of one (window, head), 4 waves x 32 rows.
+// Scores are computed TRANSPOSED (S^T = K Q^T with v_mfma_f32_32x32x16_bf16) so that a lane owns one
+// query column: the softmax row reductions are 16 in-register values + one cross-half shuffle, and the
+// exponentiated probabilities are already in the B-operand layout of the second MFMA
+// (O^T = V^T P^T), so P never goes through LDS.  V^T is produced directly by the QKV GEMM epilogue
+// (EPI_QKV_ENC), K and V^T tiles (64 keys) are staged in LDS with XOR swizzles that keep the
+// ds_read_b128 / ds_read_b64 fragment reads conflict-free.
+#include "wseg_kernels.h"
+
+namespace wseg {
+
+// ------------------------------------------------------------------------------------------------
+// im2col for conv1 (k=3, pad 1): A1[b*cols + t][tap*C + c] = x[b][c][t + tap - 1]
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_conv1_kernel(const float* __restrict__ x, T* __restrict__ a1,
+                                                           int C, int cols, int kp) {
+  constexpr int TT = 32;  // time steps per block
+  __shared__ float tile[96][TT + 2 + 1];
+  const int b = blockIdx.y, t0 = blockIdx.x * TT;
+  for (int i = threadIdx.x; i < C * (TT + 2); i += 256) {
+    const int c = i / (TT + 2), j = i - c * (TT + 2);
+    const int t = t0 + j - 1;
+    tile[c][j] = (t >= 0 && t < cols) ? x[((size_t)b * C + c) * cols + t] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < TT * kp; i += 256) {
+    const int tt = i / kp, k = i - tt * kp;
+    if (t0 + tt >= cols) continue;
+    float v = 0.f;
+    if (k < 3 * C) {
+      const int tap = k / C, c = k - tap * C;
+      v = tile[c][tt + tap];
+    }
+    El<T>::st(a1 + ((size_t)b * cols + t0 + tt) * kp + k, v);
+  }
+}
+
+// im2col for conv2 (k=3, stride 2, pad 1): A2[b*(cols/2) + t][tap*d + c] = h1[b*cols + 2t + tap - 1][c]
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_conv2_kernel(const T* __restrict__ h1, T* __restrict__ a2,
+                                                           int B, int cols, int d) {
+  constexpr int V = 16 / sizeof(T);
+  const int dv = d / V, half = cols / 2;
+  const size_t total = (size_t)B * half * 3 * dv;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cv = (int)(i % dv);
+    const size_t r = i / dv;
+    const int tap = (int)(r % 3);
+    const size_t bt = r / 3;
+    const int t = (int)(bt % half), b = (int)(bt / half);
+    const int src = 2 * t + tap - 1;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (src >= 0 && src < cols) v = *(const uint4*)(h1 + ((size_t)b * cols + src) * d + (size_t)cv * V);
+    *(uint4*)(a2 + (bt * 3 + tap) * d + (size_t)cv * V) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, 16-byte vector loads, two-pass statistics in registers.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct VecIO;
+template <> struct VecIO<float> {
+  static constexpr int V = 4;
+  static __device__ __forceinline__ void ld(const float* p, float v[4]) { const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  static __device__ __forceinline__ void st(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct VecIO<bf16_t> {
+  static constexpr int V = 8;
+  static __device__ __forceinline__ void ld(const bf16_t* p, float v[8]) {
+    const uint4 t = *(const uint4*)p;
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float v[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
+    *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ bta,
+                                                        T* __restrict__ y, int M, int d) {
+  constexpr int V = VecIO<T>::V;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const T* xr = x + (size_t)row * d;
+  float v[NIT][V];
+  float sum = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = (it * 64 + lane) * V;
+    if (c < d) {
+      VecIO<T>::ld(xr + c, v[it]);
+#pragma unroll
+      for (int j = 0; j < V; ++j) sum += v[it][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[it][j] = 0.f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)d;
+  float sq = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = (it * 64 + lane) * V;
+    if (c < d) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) { const float t = v[it][j] - mean; sq += t * t; }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)d + 1e-5f);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = (it * 64 + lane) * V;
+    if (c < d) {
+      float gg[V], bb[V], o[V];
+      VecIO<T>::ld(g + c, gg);
+      VecIO<T>::ld(bta + c, bb);
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = (v[it][j] - mean) * rstd * gg[j] + bb[j];
+      VecIO<T>::st(y + (size_t)row * d + c, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Encoder attention, bf16 MFMA.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+
+__global__ __launch_bounds__(256) void enc_attention_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                 const bf16_t* __restrict__ Vt, bf16_t* __restrict__ out,
+                                                                 int H, int T, int Tp, int d) {
+  __shared__ __attribute__((aligned(16))) bf16_t sK[64 * 64];   // [key][64 hd], 16-B slots XOR (key & 7)
+  __shared__ __attribute__((aligned(16))) bf16_t sV[64 * 64];   // [hd][64 keys], 8-B granules XOR ((hd >> 1) & 15)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int qi = lane & 31, g2 = lane >> 5;
+  const bf16_t* Qb = Q + (size_t)bh * Tp * 64;
+  const bf16_t* Kb = K + (size_t)bh * Tp * 64;
+  const bf16_t* Vb = Vt + (size_t)bh * 64 * Tp;
+
+  bf16x8 qf[4];
+#pragma unroll
+  for (int hs = 0; hs < 4; ++hs) qf[hs] = *(const bf16x8*)(Qb + (size_t)(q0 + qi) * 64 + hs * 16 + g2 * 8);
+
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -1.0e30f, l_run = 0.f;
+
+  const int n_tiles = (T + 63) / 64;
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    __syncthreads();
+    // stage K tile and V^T tile (each 8 KiB): 512 16-byte chunks per tile, 2 per thread.
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 256, row = c >> 3, sl = c & 7;
+      const uint4 kv = *(const uint4*)(Kb + (size_t)(kt * 64 + row) * 64 + sl * 8);
+      *(uint4*)(sK + row * 64 + ((sl ^ (row & 7)) << 3)) = kv;
+      const uint4 vv = *(const uint4*)(Vb + (size_t)row * Tp + kt * 64 + sl * 8);
+      const int sw = (row >> 1) & 15;
+      *(uint2*)(sV + row * 64 + (((2 * sl) ^ sw) << 2)) = make_uint2(vv.x, vv.y);
+      *(uint2*)(sV + row * 64 + (((2 * sl + 1) ^ sw) << 2)) = make_uint2(vv.z, vv.w);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int key_base = kt * 64 + sub * 32;
+      if (key_base >= T) break;
+      // S^T[key][q] = sum_hd K[key][hd] Q[q][hd]
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      const int krow = sub * 32 + qi;
+#pragma unroll
+      for (int hs = 0; hs < 4; ++hs) {
+        const bf16x8 kf = *(const bf16x8*)(sK + krow * 64 + (((hs * 2 + g2) ^ (krow & 7)) << 3));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[hs], s, 0, 0, 0);
+      }
+      if (key_base + 32 > T) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key_base + (r & 3) + 8 * (r >> 2) + 4 * g2;
+          if (key >= T) s[r] = -1.0e30f;
+        }
+      }
+      float mx = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __expf(m_run - m_new);
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - m_new); ps += s[r]; }
+      ps += __shfl_xor(ps, 32, 64);
+      l_run = l_run * alpha + ps;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      // O^T[hd][q] += V^T[hd][key] P^T[key][q]; contraction slots of lane-half g2, MFMA mm:
+      // keys 16*mm + 4*g2 + {0,1,2,3, 8,9,10,11}  == registers 8*mm .. 8*mm+7 of s.
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm) {
+        union { bf16x8 v; uint32_t u[4]; } pf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pf.u[j] = pack_bf16(s[8 * mm + 2 * j], s[8 * mm + 2 * j + 1]);
+        const int gran = sub * 8 + 4 * mm + g2;
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+          const int hd = ht * 32 + qi, sw = (hd >> 1) & 15;
+          union { bf16x8 v; uint2 u[2]; } vf;
+          vf.u[0] = *(const uint2*)(sV + hd * 64 + ((gran ^ sw) << 2));
+          vf.u[1] = *(const uint2*)(sV + hd * 64 + (((gran + 2) ^ sw) << 2));
+          if (ht == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o0, 0, 0, 0);
+          else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o1, 0, 0, 0);
+        }
+      }
+    }
+  }
+  const int q = q0 + qi;
+  if (q < T) {
+    const float inv = 1.0f / l_run;
+    bf16_t* orow = out + ((size_t)b * T + q) * d + h * 64;
+#pragma unroll
+    for (int ht = 0; ht < 2; ++ht) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int hd = ht * 32 + 8 * rg + 4 * g2;
+        const f32x16& o = ht == 0 ? o0 : o1;
+        uint2 pk;
+        pk.x = pack_bf16(o[4 * rg + 0] * inv, o[4 * rg + 1] * inv);
+        pk.y = pack_bf16(o[4 * rg + 2] * inv, o[4 * rg + 3] * inv);
+        *(uint2*)(orow + hd) = pk;
+      }
+    }
+  }
+}
+
+// f32 exact-mode attention: one thread per query row (tests / tiny models only).
+__global__ __launch_bounds__(64) void enc_attention_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                               const float* __restrict__ Vt, float* __restrict__ out,
+                                                               int H, int T, int Tp, int d) {
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= T) return;
+  const float* qp = Q + ((size_t)bh * Tp + q) * 64;
+  float qv[64], o[64];
+#pragma unroll
+  for (int e = 0; e < 64; ++e) { qv[e] = qp[e]; o[e] = 0.f; }
+  // pass 1: row max; pass 2: exp / sum / PV  (same order of operations as softmax(QK^T) V)
+  float mx = -3.0e38f;
+  for (int t = 0; t < T; ++t) {
+    const float* kp = K + ((size_t)bh * Tp + t) * 64;
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 64; ++e) s = fmaf(qv[e], kp[e], s);
+    mx = fmaxf(mx, s);
+  }
+  float l = 0.f;
+  for (int t = 0; t < T; ++t) {
+    const float* kp = K + ((size_t)bh * Tp + t) * 64;
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 64; ++e) s = fmaf(qv[e], kp[e], s);
+    const float p = expf(s - mx);
+    l += p;
+    const float* vp = Vt + (size_t)bh * 64 * Tp + t;
+#pragma unroll
+    for (int e = 0; e < 64; ++e) o[e] = fmaf(p, vp[(size_t)e * Tp], o[e]);
+  }
+  float* orow = out + ((size_t)b * T + q) * d + h * 64;
+  const float inv = 1.0f / l;
+#pragma unroll
+  for (int e = 0; e < 64; ++e) orow[e] = o[e] * inv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Launchers
+// ------------------------------------------------------------------------------------------------
+int launch_im2col_conv1(int dtype, const float* feats, void* a1, int B, int n_mels, int cols, int kp, hipStream_t s) {
+  if (n_mels > 96 || 3 * n_mels > kp) { set_error("im2col_conv1: n_mels %d unsupported", n_mels); return WSEG_ERR_INVALID; }
+  dim3 grid(cdiv(cols, 32), B);
+  if (dtype == WSEG_BF16) hipLaunchKernelGGL((im2col_conv1_kernel<bf16_t>), grid, dim3(256), 0, s, feats, (bf16_t*)a1, n_mels, cols, kp);
+  else hipLaunchKernelGGL((im2col_conv1_kernel<float>), grid, dim3(256), 0, s, feats, (float*)a1, n_mels, cols, kp);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+
+int launch_im2col_conv2(int dtype, const void* h1, void* a2, int B, int cols, int d, hipStream_t s) {
+  const size_t vec = dtype == WSEG_BF16 ? 8 : 4;
+  const size_t total = (size_t)B * (cols / 2) * 3 * (d / vec);
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (dtype == WSEG_BF16) hipLaunchKernelGGL((im2col_conv2_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)h1, (bf16_t*)a2, B, cols, d);
+  else hipLaunchKernelGGL((im2col_conv2_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)h1, (float*)a2, B, cols, d);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+
+int launch_layernorm(int dtype, const void* x, const void* g, const void* b, void* y, int M, int d, hipStream_t s) {
+  if (M <= 0) return WSEG_OK;
+  dim3 grid(cdiv(M, 4));
+  if (dtype == WSEG_BF16) {
+    if (d % 8 || d > 64 * 8 * 4) { set_error("layernorm: d %d unsupported", d); return WSEG_ERR_INVALID; }
+    if (d <= 512) hipLaunchKernelGGL((layernorm_kernel<bf16_t, 1>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)g, (const bf16_t*)b, (bf16_t*)y, M, d);
+    else if (d <= 1024) hipLaunchKernelGGL((layernorm_kernel<bf16_t, 2>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)g, (const bf16_t*)b, (bf16_t*)y, M, d);
+    else hipLaunchKernelGGL((layernorm_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)g, (const bf16_t*)b, (bf16_t*)y, M, d);
+  } else {
+    if (d % 4 || d > 64 * 4 * 8) { set_error("layernorm: d %d unsupported", d); return WSEG_ERR_INVALID; }
+    if (d <= 512) hipLaunchKernelGGL((layernorm_kernel<float, 2>), grid, dim3(256), 0, s, (const float*)x, (const float*)g, (const float*)b, (float*)y, M, d);
+    else hipLaunchKernelGGL((layernorm_kernel<float, 8>), grid, dim3(256), 0, s, (const float*)x, (const float*)g, (const float*)b, (float*)y, M, d);
+  }
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+
+int launch_enc_attention(int dtype, const void* q, const void* k, const void* vt, void* out,
+                         int B, int H, int T, int Tp, int d, hipStream_t s) {
+  if (dtype == WSEG_BF16) {
+    if (Tp % 128) { set_error("enc_attention: Tp %d %% 128", Tp); return WSEG_ERR_INVALID; }
+    dim3 grid(cdiv(T, 128), B * H);
+    hipLaunchKernelGGL(enc_attention_bf16_kernel, grid, dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, T, Tp, d);
+  } else {
+    dim3 grid(cdiv(T, 64), B * H);
+    hipLaunchKernelGGL(enc_attention_f32_kernel, grid, dim3(64), 0, s, (const float*)q, (const float*)k, (const float*)vt, (float*)out, H, T, Tp, d);
+  }
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+
+}  // namespace wseg

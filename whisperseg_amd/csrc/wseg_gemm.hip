@@ -1,0 +1,348 @@
+// GEMM kernels for gfx950:  C[m][n] = sum_k A[m][k] * W[n][k]  with fused epilogues.
+//
+// bf16 path (production): MFMA v_mfma_f32_16x16x32_bf16, LDS-staged through global_load_lds (16 B per
+// lane, XOR-swizzled on the SOURCE address so the lane-linear LDS image is bank-conflict free for
+// ds_read_b128), double-buffered with a counted vmcnt so the next K-tile streams in under the MFMAs.
+// Operands are swapped (MFMA "A" = weight rows, "B" = activation rows) so that each lane ends up with
+// 4 CONSECUTIVE output columns of one output row: bias / residual / stores are 8-byte vectors.
+// Tile shapes: 128x128 (encoder, M = windows*500) and 64x64 / 32x64 with split-K (decoder steps, where
+// M = windows*beams is small and the kernel is a weight stream bounded by HBM, not MFMA).
+//
+// f32 path (exact-parity mode): plain VALU 64x64 tile, fmaf chain in k order.
+//
+// Both paths share one epilogue (epi_apply), also used by the split-K reduction kernel.
+#include "wseg_kernels.h"
+
+namespace wseg {
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue: 4 consecutive columns n0..n0+3 of row m.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+  static __device__ __forceinline__ void ld(const float* p, float v[4]) {
+    const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  static __device__ __forceinline__ void st(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Vec4<bf16_t> {
+  static __device__ __forceinline__ void ld(const bf16_t* p, float v[4]) {
+    const uint2 t = *(const uint2*)p;
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float v[4]) {
+    uint2 t;
+    t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *(uint2*)p = t;
+  }
+};
+
+template <int EPI, typename T>
+__device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, float v[4]) {
+  if (ep.bias) {
+    float b[4];
+    Vec4<T>::ld((const T*)ep.bias + n0, b);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += b[i];
+  }
+  if constexpr (EPI == EPI_STORE) {
+    Vec4<T>::st((T*)ep.out + (size_t)m * ep.ldc + n0, v);
+  } else if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+    Vec4<T>::st((T*)ep.out + (size_t)m * ep.ldc + n0, v);
+  } else if constexpr (EPI == EPI_RESID) {
+    float r[4];
+    Vec4<T>::ld((const T*)ep.resid + (size_t)m * ep.ldc + n0, r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = r[i] + v[i];
+    Vec4<T>::st((T*)ep.out + (size_t)m * ep.ldc + n0, v);
+  } else if constexpr (EPI == EPI_GELU_POS) {
+    float p[4];
+    Vec4<T>::ld((const T*)ep.pos + (size_t)(m % ep.pos_rows) * ep.ldc + n0, p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]) + p[i];
+    Vec4<T>::st((T*)ep.out + (size_t)m * ep.ldc + n0, v);
+  } else if constexpr (EPI == EPI_QKV_ENC) {
+    const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
+    const int b = m / ep.t_len, t = m - b * ep.t_len;
+    const size_t bh = (size_t)b * ep.n_heads + h;
+    if (sec == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] *= ep.scale;
+      Vec4<T>::st((T*)ep.q + (bh * ep.t_pad + t) * 64 + e, v);
+    } else if (sec == 1) {
+      Vec4<T>::st((T*)ep.k + (bh * ep.t_pad + t) * 64 + e, v);
+    } else {
+      T* vt = (T*)ep.v + (bh * 64 + e) * ep.t_pad + t;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) El<T>::st(vt + (size_t)i * ep.t_pad, v[i]);
+    }
+  } else if constexpr (EPI == EPI_KV_CROSS) {
+    const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
+    const int b = m / ep.t_len, t = m - b * ep.t_len;
+    T* dst = (T*)(sec == 0 ? ep.k : ep.v) + (((size_t)b * ep.n_heads + h) * ep.t_len + t) * 64 + e;
+    Vec4<T>::st(dst, v);
+  } else if constexpr (EPI == EPI_F32) {
+    *(float4*)(ep.out_f32 + (size_t)m * ep.ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
+  } else if constexpr (EPI == EPI_QKV_DEC) {
+    const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
+    if (sec == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] *= ep.scale;
+      Vec4<T>::st((T*)ep.q + (size_t)m * d + nn, v);
+    } else {
+      const int pos = *ep.pos_ptr;
+      T* dst = (T*)(sec == 1 ? ep.k : ep.v) + (((size_t)m * ep.n_heads + h) * ep.t_pad + pos) * 64 + e;
+      Vec4<T>::st(dst, v);
+    }
+  } else if constexpr (EPI == EPI_SCALE) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] *= ep.scale;
+    Vec4<T>::st((T*)ep.out + (size_t)m * ep.ldc + n0, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 MFMA kernel
+// ------------------------------------------------------------------------------------------------
+#define WSEG_GLDS16(gptr, ldsptr)                                                              \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),      \
+                                   (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// SPLIT: write fp32 partials [z][m_pad][n] (epilogue applied later by splitk_reduce_kernel).
+template <int BM, int BN, int WM, int WN, int EPI, bool SPLIT>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, int lda,
+                                                        const bf16_t* __restrict__ W, int ldw,
+                                                        int M, int N, int k_len, EpiParams ep,
+                                                        float* __restrict__ part, int m_pad) {
+  constexpr int BK = 64;
+  constexpr int TM = BM / WM, TN = BN / WN;      // wave tile
+  constexpr int MI = TM / 16, NI = TN / 16;      // 16x16 MFMA tiles per wave
+  constexpr int A_IT = BM * 8 / 256, W_IT = BN * 8 / 256;
+  constexpr int NLD = A_IT + W_IT;
+  static_assert(WM * WN == 4 && A_IT >= 1 && W_IT >= 1, "tile config");
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * BK];
+  bf16_t* sA = smem;                   // [2][BM*64]
+  bf16_t* sW = smem + 2 * BM * BK;     // [2][BN*64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * k_len;
+  const int nk = k_len / BK;
+
+  // per-thread source pointers (swizzle on the source: LDS slot p holds logical 16-B slot (p&7)^(row&7))
+  const bf16_t* a_src[A_IT];
+  const bf16_t* w_src[W_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int p = it * 256 + tid, row = p >> 3, sl = (p & 7) ^ (row & 7);
+    a_src[it] = A + (size_t)(m0 + row) * lda + kbeg + sl * 8;
+  }
+#pragma unroll
+  for (int it = 0; it < W_IT; ++it) {
+    const int p = it * 256 + tid, row = p >> 3, sl = (p & 7) ^ (row & 7);
+    w_src[it] = W + (size_t)(n0 + row) * ldw + kbeg + sl * 8;
+  }
+  auto issue = [&](int kt, int buf) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it)
+      WSEG_GLDS16(a_src[it] + kt * BK, sA + buf * BM * BK + (it * 256 + wave * 64) * 8);
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it)
+      WSEG_GLDS16(w_src[it] + kt * BK, sW + buf * BN * BK + (it * 256 + wave * 64) * 8);
+  };
+
+  f32x4 acc[NI][MI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = lane >> 4;
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) {
+      issue(kt + 1, buf ^ 1);
+      wait_vmcnt<NLD>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    const bf16_t* cA = sA + buf * BM * BK + (wm * TM) * BK;
+    const bf16_t* cW = sW + buf * BN * BK + (wn * TN) * BK;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[MI], wf[NI];
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+        const int r = j * 16 + fr;
+        af[j] = *(const bf16x8*)(cA + r * BK + (((kk * 4 + fg) ^ (r & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int r = i * 16 + fr;
+        wf[i] = *(const bf16x8*)(cW + r * BK + (((kk * 4 + fg) ^ (r & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // epilogue: lane holds n = nb + i*16 + fg*4 + {0..3}, m = mb + j*16 + fr
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const int m = m0 + wm * TM + j * 16 + fr;
+      const int n = n0 + wn * TN + i * 16 + fg * 4;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if constexpr (SPLIT) {
+        *(float4*)(part + ((size_t)blockIdx.z * m_pad + m) * N + n) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        if (m < M) epi_apply<EPI, bf16_t>(ep, m, n, v);
+      }
+    }
+  }
+}
+
+template <int EPI, typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, int m_pad,
+                                                            int M, int N, EpiParams ep) {
+  const int nq = N >> 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * nq) return;
+  const int m = idx / nq, n0 = (idx - m * nq) << 2;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < splits; ++z) {
+    const float4 t = *(const float4*)(part + ((size_t)z * m_pad + m) * N + n0);
+    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+  }
+  epi_apply<EPI, T>(ep, m, n0, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// f32 exact kernel: 64x64 tile, 4x4 micro-tile per thread, sequential-k fmaf chain.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                       int M, int N, int K, EpiParams ep) {
+  __shared__ float sA[16][68];
+  __shared__ float sW[16][68];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int lr = tid >> 2, lq = (tid & 3) * 4;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    const float4 av = *(const float4*)(A + (size_t)(m0 + lr) * lda + k0 + lq);
+    const float4 wv = *(const float4*)(W + (size_t)(n0 + lr) * ldw + k0 + lq);
+    sA[lq + 0][lr] = av.x; sA[lq + 1][lr] = av.y; sA[lq + 2][lr] = av.z; sA[lq + 3][lr] = av.w;
+    sW[lq + 0][lr] = wv.x; sW[lq + 1][lr] = wv.y; sW[lq + 2][lr] = wv.z; sW[lq + 3][lr] = wv.w;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      float a[4], w[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = sA[k][ty * 4 + i]; w[i] = sW[k][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], w[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m < M) epi_apply<EPI, float>(ep, m, n0 + tx * 4, acc[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Launchers
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+static int launch_bf16(const GemmArgs& g, hipStream_t s) {
+  const bf16_t* A = (const bf16_t*)g.A;
+  const bf16_t* W = (const bf16_t*)g.W;
+  if (g.K % 64 || g.N % 64) { set_error("gemm bf16: K %d / N %d not tile multiples", g.K, g.N); return WSEG_ERR_INVALID; }
+  if (g.M > 64) {
+    if (g.N % 128) { set_error("gemm bf16: N %d %% 128 != 0", g.N); return WSEG_ERR_INVALID; }
+    dim3 grid(g.N / 128, cdiv(g.M, 128), 1);
+    hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 2, 2, EPI, false>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
+                       g.K, g.ep, (float*)nullptr, 0);
+    WSEG_LAUNCH_CHECK();
+    return WSEG_OK;
+  }
+  // skinny: decoder step.  Choose split-K so that ~256+ workgroups stream the weight matrix.
+  const int bm = g.M <= 32 ? 32 : 64;
+  const int blocks = g.N / 64;
+  int splits = 1;
+  if (g.splitk_ws) {
+    while (blocks * splits < 256 && (g.K / (splits * 2)) % 64 == 0 && g.K / (splits * 2) >= 128 && splits < 16) splits *= 2;
+    const size_t need = (size_t)splits * bm * g.N * sizeof(float);
+    if (splits > 1 && need > g.splitk_ws_bytes) splits = 1;
+  }
+  dim3 grid(blocks, 1, splits);
+  const int k_len = g.K / splits;
+  if (splits == 1) {
+    if (bm == 32)
+      hipLaunchKernelGGL((gemm_bf16_kernel<32, 64, 1, 4, EPI, false>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, k_len, g.ep, (float*)nullptr, 0);
+    else
+      hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 1, 4, EPI, false>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, k_len, g.ep, (float*)nullptr, 0);
+    WSEG_LAUNCH_CHECK();
+    return WSEG_OK;
+  }
+  if (bm == 32)
+    hipLaunchKernelGGL((gemm_bf16_kernel<32, 64, 1, 4, EPI, true>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, k_len, g.ep, g.splitk_ws, bm);
+  else
+    hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 1, 4, EPI, true>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, k_len, g.ep, g.splitk_ws, bm);
+  WSEG_LAUNCH_CHECK();
+  const int work = g.M * (g.N / 4);
+  hipLaunchKernelGGL((splitk_reduce_kernel<EPI, bf16_t>), dim3(cdiv(work, 256)), dim3(256), 0, s, g.splitk_ws, splits, bm, g.M, g.N, g.ep);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+
+template <int EPI>
+static int launch_f32(const GemmArgs& g, hipStream_t s) {
+  if (g.K % 16 || g.N % 64) { set_error("gemm f32: K %d / N %d not tile multiples", g.K, g.N); return WSEG_ERR_INVALID; }
+  dim3 grid(g.N / 64, cdiv(g.M, 64));
+  hipLaunchKernelGGL((gemm_f32_kernel<EPI>), grid, dim3(256), 0, s, (const float*)g.A, g.lda, (const float*)g.W, g.ldw, g.M, g.N, g.K, g.ep);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+
+template <int EPI>
+static int launch_any(int dtype, const GemmArgs& g, hipStream_t s) {
+  return dtype == WSEG_BF16 ? launch_bf16<EPI>(g, s) : launch_f32<EPI>(g, s);
+}
+
+int launch_gemm(int dtype, EpiKind epi, const GemmArgs& g, hipStream_t s) {
+  switch (epi) {
+    case EPI_STORE: return launch_any<EPI_STORE>(dtype, g, s);
+    case EPI_GELU: return launch_any<EPI_GELU>(dtype, g, s);
+    case EPI_RESID: return launch_any<EPI_RESID>(dtype, g, s);
+    case EPI_GELU_POS: return launch_any<EPI_GELU_POS>(dtype, g, s);
+    case EPI_QKV_ENC: return launch_any<EPI_QKV_ENC>(dtype, g, s);
+    case EPI_KV_CROSS: return launch_any<EPI_KV_CROSS>(dtype, g, s);
+    case EPI_F32: return launch_any<EPI_F32>(dtype, g, s);
+    case EPI_QKV_DEC: return launch_any<EPI_QKV_DEC>(dtype, g, s);
+    case EPI_SCALE: return launch_any<EPI_SCALE>(dtype, g, s);
+    default: break;
+  }
+  set_error("unknown epilogue %d", (int)epi);
+  return WSEG_ERR_INVALID;
+}
+
+}  // namespace wseg

@@ -1,0 +1,74 @@
+// Host-side launchers of the gfx950 kernels (internal to libwseg).
+#pragma once
+#include "wseg_common.h"
+
+namespace wseg {
+
+// ---------------------------------------------------------------------------------------------
+// GEMM:  C[m][n] = sum_k A[m][k] * W[n][k]   (A [M][lda], W [N][ldw]; both K-contiguous, i.e. W is a
+// torch.nn.Linear weight as stored).  Epilogues fuse bias / GELU / residual / layout scatter.
+// ---------------------------------------------------------------------------------------------
+enum EpiKind {
+  EPI_STORE = 0,     // out[m][n] = acc + bias
+  EPI_GELU,          // out = gelu(acc + bias)
+  EPI_RESID,         // out = resid + acc + bias
+  EPI_GELU_POS,      // out = gelu(acc + bias) + pos[m % pos_rows][n]          (conv2 + positional emb.)
+  EPI_QKV_ENC,       // fused q|k|v: q*scale -> Q[b][h][t][64], k -> K[b][h][t][64], v -> Vt[b][h][64][Tp]
+  EPI_KV_CROSS,      // fused k|v of one decoder layer: K[b][h][t][64], V[b][h][t][64]
+  EPI_F32,           // out_f32[m][n] = acc (+ bias)
+  EPI_QKV_DEC,       // decoder step: q*scale -> q[m][n]; k,v -> self cache [m][h][pos][64]
+  EPI_SCALE,         // out = (acc + bias) * scale                                (cross-attention q)
+  EPI_COUNT
+};
+
+struct EpiParams {
+  const void* bias = nullptr;  // model dtype [N] (nullptr = none)
+  void* out = nullptr;         // model dtype
+  int ldc = 0;
+  const void* resid = nullptr;
+  const void* pos = nullptr;
+  int pos_rows = 1;
+  float scale = 1.f;
+  void* q = nullptr;
+  void* k = nullptr;
+  void* v = nullptr;
+  int d_model = 0;
+  int t_len = 1;               // rows per window (500)
+  int t_pad = 1;               // padded rows per (b,h) slab (512) / cache capacity for EPI_QKV_DEC
+  int n_heads = 1;
+  const int* pos_ptr = nullptr;  // device scalar: current decode position (EPI_QKV_DEC)
+  float* out_f32 = nullptr;
+};
+
+struct GemmArgs {
+  const void* A; int lda;
+  const void* W; int ldw;
+  int M, N, K;
+  EpiParams ep;
+  float* splitk_ws = nullptr;     // fp32 [splits][M_pad][N] when the launcher decides to split K
+  size_t splitk_ws_bytes = 0;
+};
+
+// dtype: WSEG_F32 (exact VALU kernel) or WSEG_BF16 (MFMA).  M may be any value as long as A has
+// round_up(M,128) readable rows; N % 128 == 0 rows of W readable; K % 64 == 0.
+int launch_gemm(int dtype, EpiKind epi, const GemmArgs& g, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Encoder-side kernels (wseg_enc.hip)
+// ---------------------------------------------------------------------------------------------
+// feats f32 [B][80][1000] -> A1 [B*1000][Kp] with k = tap*80 + c (zero padded to Kp).
+int launch_im2col_conv1(int dtype, const float* feats, void* a1, int B, int n_mels, int cols, int kp, hipStream_t s);
+// h1 [B*1000][d] -> A2 [B*500][3d] with k = tap*d + c, stride 2, pad 1.
+int launch_im2col_conv2(int dtype, const void* h1, void* a2, int B, int cols, int d, hipStream_t s);
+// y[m][:] = LayerNorm(x[m][:]) * g + b, eps 1e-5.
+int launch_layernorm(int dtype, const void* x, const void* g, const void* b, void* y, int M, int d, hipStream_t s);
+// Encoder self-attention over Q,K [B][H][Tp][64], Vt [B][H][64][Tp] (q pre-scaled) -> out [B*T][d].
+int launch_enc_attention(int dtype, const void* q, const void* k, const void* vt, void* out,
+                         int B, int H, int T, int Tp, int d, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Decoder-side kernels (wseg_dec.hip)
+// ---------------------------------------------------------------------------------------------
+struct DecodeState;   // device-resident bookkeeping, defined in wseg_dec.h
+
+}  // namespace wseg

@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void logmel_stft_kernel(LogmelArgs a) {
     const float* p = pw + fr * (nc + 1) + k0;
     float acc = 0.f;
     for (int k = 0; k < cnt; ++k) acc = fmaf(wt[k], p[k], acc);
-    const float v = log10f(fmaxf(acc, 1e-10f));
+    // mel floor: max(1e-10, x) then log10; log10(1e-10) is exactly -10 in the reference (float64 -> float32)
+    const float v = acc > 1e-10f ? log10f(acc) : -10.0f;
     a.raw[((size_t)w * n_mels + m) * a.n_frames + f] = v;
     lmax = fmaxf(lmax, v);
     if (f < a.d.n_cols) lmin = fminf(lmin, v);

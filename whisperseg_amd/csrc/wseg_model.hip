@@ -1,0 +1,431 @@
+// Model object, workspace planning and the encode / generate drivers of libwseg.
+//
+// Replaces HF WhisperForConditionalGeneration as the reference drives it (reference model.py:626-676):
+// encoder (HF modeling_whisper.py:592-646), decoder with KV cache (:690-796), tied LM head (:1080) and
+// greedy / beam-search decoding (HF generation/utils.py:3208-3510).  The host code below only enqueues
+// kernels on the caller's stream; all decoding state lives in the caller-provided workspace.
+#include <map>
+#include <string>
+#include <vector>
+#include "wseg_dec.h"
+
+using namespace wseg;
+
+namespace {
+
+struct Slot { const void** field; size_t bytes; bool set; };
+
+struct EncLayer { const void *ln1_g, *ln1_b, *qkv_w, *qkv_b, *o_w, *o_b, *ln2_g, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b; };
+struct DecLayer {
+  const void *ln1_g, *ln1_b, *qkv_w, *qkv_b, *o_w, *o_b, *ln2_g, *ln2_b, *cq_w, *cq_b, *ckv_w, *ckv_b, *co_w, *co_b,
+      *ln3_g, *ln3_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+};
+
+struct Plan {   // workspace carve-up (all offsets 256-byte aligned)
+  size_t total = 0;
+  char *a1, *h1, *a2, *x, *y, *q, *k, *vt, *hbuf, *enc_out;
+  char *ck, *cv, *sk, *sv, *dx, *dy, *dq, *dattn, *dh, *logits, *first_logits, *splitk, *mask;
+  size_t splitk_bytes;
+  DecodeState st;
+};
+
+}  // namespace
+
+struct wseg_model {
+  wseg_model_config cfg;
+  size_t es;                 // element size of the model dtype
+  int kp1, vp, tp;           // conv1 K padded, vocab padded, encoder positions padded
+  std::map<std::string, Slot> slots;
+  const void *conv1_w, *conv1_b, *conv2_w, *conv2_b, *enc_pos, *enc_ln_g, *enc_ln_b;
+  const void *dec_tok, *dec_pos, *dec_ln_g, *dec_ln_b;
+  std::vector<EncLayer> enc;
+  std::vector<DecLayer> dec;
+  hipEvent_t ev[4];
+  bool ev_ok = false;
+  int last_steps = 0;
+  int last_W = 0, last_nb = 0, last_L = 0;
+  bool timing_valid = false;
+  int* poll = nullptr;       // pinned host ints, one per decode step
+  std::vector<hipEvent_t> step_ev;
+};
+
+namespace {
+
+void add_slot(wseg_model* m, const std::string& name, const void** field, size_t elems) {
+  *field = nullptr;
+  m->slots[name] = Slot{field, elems * m->es, false};
+}
+
+// Lay out the workspace for W windows, nb beams, capacity L positions.  base may be null (size query).
+void make_plan(const wseg_model* m, int W, int nb, int L, char* base, Plan& p) {
+  const wseg_model_config& c = m->cfg;
+  const size_t es = m->es;
+  const size_t d = c.d_model, H = c.n_heads, ffn = c.ffn;
+  const size_t M1p = align_up((size_t)W * c.spec_cols, 128), Mp = align_up((size_t)W * c.enc_positions, 128);
+  const size_t R = (size_t)W * nb, Rp = align_up(R, 128);
+  char* cur = base;
+  auto take = [&](size_t bytes) { char* q = cur; cur += align_up(bytes, 256); return q; };
+  // encoder: a1 | h1 | a2 are dead once conv2 has run; hbuf reuses their space.
+  const size_t conv_bytes = align_up(M1p * m->kp1 * es, 256) + align_up(M1p * d * es, 256) + align_up(Mp * 3 * d * es, 256);
+  const size_t hbuf_bytes = align_up(Mp * ffn * es, 256);
+  char* u = take(conv_bytes > hbuf_bytes ? conv_bytes : hbuf_bytes);
+  p.a1 = u;
+  p.h1 = p.a1 + align_up(M1p * m->kp1 * es, 256);
+  p.a2 = p.h1 + align_up(M1p * d * es, 256);
+  p.hbuf = u;
+  p.x = take(Mp * d * es);
+  p.y = take(Mp * d * es);
+  p.q = take((size_t)W * H * m->tp * 64 * es);
+  p.k = take((size_t)W * H * m->tp * 64 * es);
+  p.vt = take((size_t)W * H * m->tp * 64 * es);
+  p.enc_out = take(Mp * d * es);
+  // decoder
+  const size_t Ld = c.dec_layers, Tk = c.enc_positions;
+  p.ck = take(Ld * W * H * Tk * 64 * es);
+  p.cv = take(Ld * W * H * Tk * 64 * es);
+  p.sk = take(Ld * R * H * (size_t)L * 64 * es);
+  p.sv = take(Ld * R * H * (size_t)L * 64 * es);
+  p.dx = take(Rp * d * es);
+  p.dy = take(Rp * d * es);
+  p.dq = take(Rp * d * es);
+  p.dattn = take(Rp * d * es);
+  p.dh = take(Rp * ffn * es);
+  p.logits = take(Rp * (size_t)m->vp * 4);
+  p.first_logits = take(R * (size_t)m->vp * 4);
+  const size_t maxn = 3 * d > ffn ? 3 * d : ffn;
+  p.splitk_bytes = (size_t)16 * 64 * maxn * 4;
+  p.splitk = take(p.splitk_bytes);
+  p.mask = take(align_up((size_t)c.vocab, 4));
+  DecodeState& st = p.st;
+  st.W = W; st.nb = nb; st.L = L; st.V = c.vocab; st.ldv = m->vp;
+  st.pos = (int*)take(256);
+  st.tokens_in = (int*)take(R * 4);
+  st.run_seq = (int*)take(R * L * 4);
+  st.fin_seq = (int*)take(R * L * 4);
+  st.run_score = (float*)take(R * 4);
+  st.fin_score = (float*)take(R * 4);
+  st.fin_flag = (int*)take(R * 4);
+  st.fin_len = (int*)take(R * 4);
+  st.unsat = (int*)take((size_t)W * 4);
+  st.anc = (unsigned char*)take(R * L);
+  st.cand_val = (float*)take(R * MAX_CAND * 4);
+  st.cand_tok = (int*)take(R * MAX_CAND * 4);
+  st.active = (int*)take((size_t)L * 4);
+  st.sup_mask = (const unsigned char*)p.mask;
+  p.total = (size_t)(cur - base);
+}
+
+int check_geometry(const wseg_model_config& c) {
+  if (c.d_model <= 0 || c.n_heads <= 0 || c.d_model != c.n_heads * 64) { set_error("d_model %d must be n_heads %d * 64", c.d_model, c.n_heads); return WSEG_ERR_INVALID; }
+  if (c.d_model % 128 || c.ffn % 128) { set_error("d_model/ffn must be multiples of 128"); return WSEG_ERR_INVALID; }
+  if (c.spec_cols != 2 * c.enc_positions || c.enc_positions > 512) { set_error("spec_cols %d / enc_positions %d unsupported", c.spec_cols, c.enc_positions); return WSEG_ERR_INVALID; }
+  if (c.n_mels <= 0 || c.n_mels > 96) { set_error("n_mels %d unsupported", c.n_mels); return WSEG_ERR_INVALID; }
+  if (c.dec_positions <= 0 || c.dec_positions > 512) { set_error("dec_positions %d unsupported", c.dec_positions); return WSEG_ERR_INVALID; }
+  if (c.dtype != WSEG_F32 && c.dtype != WSEG_BF16) { set_error("dtype %d unsupported", c.dtype); return WSEG_ERR_INVALID; }
+  if (c.enc_layers <= 0 || c.dec_layers <= 0 || c.vocab <= 0) { set_error("bad layer/vocab counts"); return WSEG_ERR_INVALID; }
+  return WSEG_OK;
+}
+
+#define WSEG_TRY(expr) do { int _s = (expr); if (_s != WSEG_OK) return _s; } while (0)
+
+int gemm(const wseg_model* m, EpiKind epi, const void* A, int lda, const void* Wt, int ldw, int M, int N, int K,
+         const EpiParams& ep, const Plan* p, hipStream_t s) {
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.W = Wt; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.ep = ep;
+  if (p) { g.splitk_ws = (float*)p->splitk; g.splitk_ws_bytes = p->splitk_bytes; }
+  return launch_gemm(m->cfg.dtype, epi, g, s);
+}
+
+int run_encoder(wseg_model* m, const float* feats, int W, Plan& p, void* enc_out, hipStream_t s) {
+  const wseg_model_config& c = m->cfg;
+  const int dt = c.dtype, d = c.d_model, H = c.n_heads, ffn = c.ffn, T = c.enc_positions, Tp = m->tp;
+  const int M1 = W * c.spec_cols, M = W * T;
+  const size_t qkv_bytes = (size_t)W * H * Tp * 64 * m->es;
+  // pad rows of Q/K and pad columns of V^T must be finite (they are multiplied by exact zeros)
+  WSEG_HIP_CHECK(hipMemsetAsync(p.q, 0, qkv_bytes, s));
+  WSEG_HIP_CHECK(hipMemsetAsync(p.k, 0, qkv_bytes, s));
+  WSEG_HIP_CHECK(hipMemsetAsync(p.vt, 0, qkv_bytes, s));
+  WSEG_TRY(launch_im2col_conv1(dt, feats, p.a1, W, c.n_mels, c.spec_cols, m->kp1, s));
+  EpiParams e;
+  e.bias = m->conv1_b; e.out = p.h1; e.ldc = d;
+  WSEG_TRY(gemm(m, EPI_GELU, p.a1, m->kp1, m->conv1_w, m->kp1, M1, d, m->kp1, e, nullptr, s));
+  WSEG_TRY(launch_im2col_conv2(dt, p.h1, p.a2, W, c.spec_cols, d, s));
+  e = EpiParams();
+  e.bias = m->conv2_b; e.out = p.x; e.ldc = d; e.pos = m->enc_pos; e.pos_rows = T;
+  WSEG_TRY(gemm(m, EPI_GELU_POS, p.a2, 3 * d, m->conv2_w, 3 * d, M, d, 3 * d, e, nullptr, s));
+  for (int l = 0; l < c.enc_layers; ++l) {
+    const EncLayer& L = m->enc[l];
+    WSEG_TRY(launch_layernorm(dt, p.x, L.ln1_g, L.ln1_b, p.y, M, d, s));
+    e = EpiParams();
+    e.bias = L.qkv_b; e.q = p.q; e.k = p.k; e.v = p.vt; e.d_model = d; e.t_len = T; e.t_pad = Tp; e.n_heads = H; e.scale = 0.125f;
+    WSEG_TRY(gemm(m, EPI_QKV_ENC, p.y, d, L.qkv_w, d, M, 3 * d, d, e, nullptr, s));
+    WSEG_TRY(launch_enc_attention(dt, p.q, p.k, p.vt, p.y, W, H, T, Tp, d, s));
+    e = EpiParams();
+    e.bias = L.o_b; e.out = p.x; e.resid = p.x; e.ldc = d;
+    WSEG_TRY(gemm(m, EPI_RESID, p.y, d, L.o_w, d, M, d, d, e, nullptr, s));
+    WSEG_TRY(launch_layernorm(dt, p.x, L.ln2_g, L.ln2_b, p.y, M, d, s));
+    e = EpiParams();
+    e.bias = L.fc1_b; e.out = p.hbuf; e.ldc = ffn;
+    WSEG_TRY(gemm(m, EPI_GELU, p.y, d, L.fc1_w, d, M, ffn, d, e, nullptr, s));
+    e = EpiParams();
+    e.bias = L.fc2_b; e.out = p.x; e.resid = p.x; e.ldc = d;
+    WSEG_TRY(gemm(m, EPI_RESID, p.hbuf, ffn, L.fc2_w, ffn, M, d, ffn, e, nullptr, s));
+  }
+  WSEG_TRY(launch_layernorm(dt, p.x, m->enc_ln_g, m->enc_ln_b, enc_out, M, d, s));
+  return WSEG_OK;
+}
+
+// One decoder step for all R rows at position *st.pos.  want_logits: run final LN + LM head.
+int run_decoder_step(wseg_model* m, Plan& p, bool want_logits, hipStream_t s) {
+  const wseg_model_config& c = m->cfg;
+  const int dt = c.dtype, d = c.d_model, H = c.n_heads, ffn = c.ffn, Tk = c.enc_positions;
+  const DecodeState& st = p.st;
+  const int R = st.W * st.nb;
+  const size_t es = m->es;
+  const size_t self_stride = (size_t)R * H * st.L * 64 * es;
+  const size_t cross_stride = (size_t)st.W * H * Tk * 64 * es;
+  WSEG_TRY(launch_embed(dt, st, m->dec_tok, m->dec_pos, p.dx, d, s));
+  EpiParams e;
+  for (int l = 0; l < c.dec_layers; ++l) {
+    const DecLayer& L = m->dec[l];
+    WSEG_TRY(launch_layernorm(dt, p.dx, L.ln1_g, L.ln1_b, p.dy, R, d, s));
+    e = EpiParams();
+    e.bias = L.qkv_b; e.q = p.dq; e.k = p.sk + l * self_stride; e.v = p.sv + l * self_stride;
+    e.d_model = d; e.n_heads = H; e.t_pad = st.L; e.pos_ptr = st.pos; e.scale = 0.125f;
+    WSEG_TRY(gemm(m, EPI_QKV_DEC, p.dy, d, L.qkv_w, d, R, 3 * d, d, e, &p, s));
+    WSEG_TRY(launch_dec_self_attn(dt, st, p.dq, p.sk + l * self_stride, p.sv + l * self_stride, p.dattn, H, d, s));
+    e = EpiParams();
+    e.bias = L.o_b; e.out = p.dx; e.resid = p.dx; e.ldc = d;
+    WSEG_TRY(gemm(m, EPI_RESID, p.dattn, d, L.o_w, d, R, d, d, e, &p, s));
+    WSEG_TRY(launch_layernorm(dt, p.dx, L.ln2_g, L.ln2_b, p.dy, R, d, s));
+    e = EpiParams();
+    e.bias = L.cq_b; e.out = p.dq; e.ldc = d; e.scale = 0.125f;
+    WSEG_TRY(gemm(m, EPI_SCALE, p.dy, d, L.cq_w, d, R, d, d, e, &p, s));
+    WSEG_TRY(launch_dec_cross_attn(dt, st, p.dq, p.ck + l * cross_stride, p.cv + l * cross_stride, p.dattn, H, Tk, d, s));
+    e = EpiParams();
+    e.bias = L.co_b; e.out = p.dx; e.resid = p.dx; e.ldc = d;
+    WSEG_TRY(gemm(m, EPI_RESID, p.dattn, d, L.co_w, d, R, d, d, e, &p, s));
+    WSEG_TRY(launch_layernorm(dt, p.dx, L.ln3_g, L.ln3_b, p.dy, R, d, s));
+    e = EpiParams();
+    e.bias = L.fc1_b; e.out = p.dh; e.ldc = ffn;
+    WSEG_TRY(gemm(m, EPI_GELU, p.dy, d, L.fc1_w, d, R, ffn, d, e, &p, s));
+    e = EpiParams();
+    e.bias = L.fc2_b; e.out = p.dx; e.resid = p.dx; e.ldc = d;
+    WSEG_TRY(gemm(m, EPI_RESID, p.dh, ffn, L.fc2_w, ffn, R, d, ffn, e, &p, s));
+  }
+  if (want_logits) {
+    WSEG_TRY(launch_layernorm(dt, p.dx, m->dec_ln_g, m->dec_ln_b, p.dy, R, d, s));
+    e = EpiParams();
+    e.out_f32 = (float*)p.logits; e.ldc = m->vp;
+    WSEG_TRY(gemm(m, EPI_F32, p.dy, d, m->dec_tok, d, R, m->vp, d, e, nullptr, s));
+  }
+  return WSEG_OK;
+}
+
+}  // namespace
+
+extern "C" int wseg_model_create(const wseg_model_config* cfg, wseg_model** out) {
+  if (!cfg || !out) { set_error("wseg_model_create: null argument"); return WSEG_ERR_INVALID; }
+  WSEG_TRY(check_geometry(*cfg));
+  wseg_model* m = new wseg_model();
+  m->cfg = *cfg;
+  m->es = cfg->dtype == WSEG_BF16 ? 2 : 4;
+  m->kp1 = (int)align_up((size_t)3 * cfg->n_mels, 64);
+  m->vp = (int)align_up((size_t)cfg->vocab, 128);
+  m->tp = (int)align_up((size_t)cfg->enc_positions, 128);
+  const size_t d = cfg->d_model, ffn = cfg->ffn;
+  add_slot(m, "enc.conv1.w", &m->conv1_w, d * m->kp1);
+  add_slot(m, "enc.conv1.b", &m->conv1_b, d);
+  add_slot(m, "enc.conv2.w", &m->conv2_w, d * 3 * d);
+  add_slot(m, "enc.conv2.b", &m->conv2_b, d);
+  add_slot(m, "enc.pos", &m->enc_pos, (size_t)cfg->enc_positions * d);
+  add_slot(m, "enc.ln.g", &m->enc_ln_g, d);
+  add_slot(m, "enc.ln.b", &m->enc_ln_b, d);
+  add_slot(m, "dec.tok", &m->dec_tok, (size_t)m->vp * d);
+  add_slot(m, "dec.pos", &m->dec_pos, (size_t)cfg->dec_positions * d);
+  add_slot(m, "dec.ln.g", &m->dec_ln_g, d);
+  add_slot(m, "dec.ln.b", &m->dec_ln_b, d);
+  m->enc.resize(cfg->enc_layers);
+  m->dec.resize(cfg->dec_layers);
+  for (int i = 0; i < cfg->enc_layers; ++i) {
+    EncLayer& L = m->enc[i];
+    const std::string p = "enc." + std::to_string(i) + ".";
+    add_slot(m, p + "ln1.g", &L.ln1_g, d); add_slot(m, p + "ln1.b", &L.ln1_b, d);
+    add_slot(m, p + "qkv.w", &L.qkv_w, 3 * d * d); add_slot(m, p + "qkv.b", &L.qkv_b, 3 * d);
+    add_slot(m, p + "o.w", &L.o_w, d * d); add_slot(m, p + "o.b", &L.o_b, d);
+    add_slot(m, p + "ln2.g", &L.ln2_g, d); add_slot(m, p + "ln2.b", &L.ln2_b, d);
+    add_slot(m, p + "fc1.w", &L.fc1_w, ffn * d); add_slot(m, p + "fc1.b", &L.fc1_b, ffn);
+    add_slot(m, p + "fc2.w", &L.fc2_w, d * ffn); add_slot(m, p + "fc2.b", &L.fc2_b, d);
+  }
+  for (int i = 0; i < cfg->dec_layers; ++i) {
+    DecLayer& L = m->dec[i];
+    const std::string p = "dec." + std::to_string(i) + ".";
+    add_slot(m, p + "ln1.g", &L.ln1_g, d); add_slot(m, p + "ln1.b", &L.ln1_b, d);
+    add_slot(m, p + "qkv.w", &L.qkv_w, 3 * d * d); add_slot(m, p + "qkv.b", &L.qkv_b, 3 * d);
+    add_slot(m, p + "o.w", &L.o_w, d * d); add_slot(m, p + "o.b", &L.o_b, d);
+    add_slot(m, p + "ln2.g", &L.ln2_g, d); add_slot(m, p + "ln2.b", &L.ln2_b, d);
+    add_slot(m, p + "cq.w", &L.cq_w, d * d); add_slot(m, p + "cq.b", &L.cq_b, d);
+    add_slot(m, p + "ckv.w", &L.ckv_w, 2 * d * d); add_slot(m, p + "ckv.b", &L.ckv_b, 2 * d);
+    add_slot(m, p + "co.w", &L.co_w, d * d); add_slot(m, p + "co.b", &L.co_b, d);
+    add_slot(m, p + "ln3.g", &L.ln3_g, d); add_slot(m, p + "ln3.b", &L.ln3_b, d);
+    add_slot(m, p + "fc1.w", &L.fc1_w, ffn * d); add_slot(m, p + "fc1.b", &L.fc1_b, ffn);
+    add_slot(m, p + "fc2.w", &L.fc2_w, d * ffn); add_slot(m, p + "fc2.b", &L.fc2_b, d);
+  }
+  *out = m;
+  return WSEG_OK;
+}
+
+extern "C" void wseg_model_destroy(wseg_model* m) {
+  if (!m) return;
+  if (m->ev_ok) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(m->ev[i]);
+  for (hipEvent_t e : m->step_ev) (void)hipEventDestroy(e);
+  if (m->poll) (void)hipHostFree(m->poll);
+  delete m;
+}
+
+extern "C" int wseg_model_set_tensor(wseg_model* m, const char* name, const void* dev_ptr, size_t bytes) {
+  if (!m || !name || !dev_ptr) { set_error("wseg_model_set_tensor: null argument"); return WSEG_ERR_INVALID; }
+  auto it = m->slots.find(name);
+  if (it == m->slots.end()) { set_error("unknown tensor '%s'", name); return WSEG_ERR_INVALID; }
+  if (it->second.bytes != bytes) { set_error("tensor '%s': expected %zu bytes, got %zu", name, it->second.bytes, bytes); return WSEG_ERR_INVALID; }
+  if (((uintptr_t)dev_ptr) & 15) { set_error("tensor '%s' is not 16-byte aligned", name); return WSEG_ERR_INVALID; }
+  *it->second.field = dev_ptr;
+  it->second.set = true;
+  return WSEG_OK;
+}
+
+extern "C" int wseg_model_ready(const wseg_model* m) {
+  if (!m) { set_error("wseg_model_ready: null model"); return WSEG_ERR_INVALID; }
+  for (const auto& kv : m->slots)
+    if (!kv.second.set) { set_error("tensor '%s' has not been attached", kv.first.c_str()); return WSEG_ERR_STATE; }
+  return WSEG_OK;
+}
+
+extern "C" size_t wseg_workspace_bytes(const wseg_model* m, int32_t max_windows, int32_t num_beams, int32_t max_length) {
+  if (!m || max_windows <= 0 || num_beams <= 0 || num_beams > MAX_BEAMS || max_length <= 0) return 0;
+  Plan p;
+  make_plan(m, max_windows, num_beams, max_length, nullptr, p);
+  return p.total + 256;
+}
+
+static char* aligned_base(void* ws) { return (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255); }
+
+extern "C" int wseg_encode(wseg_model* m, const float* feats, int32_t n_windows, void* workspace, size_t workspace_bytes,
+                           void* enc_out, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (!m || !feats || !workspace || !enc_out) { set_error("wseg_encode: null argument"); return WSEG_ERR_INVALID; }
+  WSEG_TRY(wseg_model_ready(m));
+  if (n_windows <= 0) return WSEG_OK;
+  Plan p;
+  make_plan(m, n_windows, 1, 8, aligned_base(workspace), p);
+  if (p.total + 256 > workspace_bytes) { set_error("workspace too small: need %zu, have %zu", p.total + 256, workspace_bytes); return WSEG_ERR_STATE; }
+  WSEG_TRY(run_encoder(m, feats, n_windows, p, p.enc_out, s));
+  const size_t bytes = (size_t)n_windows * m->cfg.enc_positions * m->cfg.d_model * m->es;
+  WSEG_HIP_CHECK(hipMemcpyAsync(enc_out, p.enc_out, bytes, hipMemcpyDeviceToDevice, s));
+  return WSEG_OK;
+}
+
+extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_windows, const wseg_generate_params* gp,
+                             void* workspace, size_t workspace_bytes, int32_t* out_tokens, int32_t* out_lengths,
+                             void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (!m || !feats || !gp || !workspace || !out_tokens || !out_lengths) { set_error("wseg_generate: null argument"); return WSEG_ERR_INVALID; }
+  WSEG_TRY(wseg_model_ready(m));
+  if (n_windows <= 0) return WSEG_OK;
+  const wseg_model_config& c = m->cfg;
+  const int nb = gp->num_beams, P = gp->prompt_len, L = gp->max_length;
+  if (nb < 1 || nb > MAX_BEAMS) { set_error("num_beams %d unsupported (1..%d)", nb, MAX_BEAMS); return WSEG_ERR_INVALID; }
+  if (P < 1 || P > 8 || L <= P || L > c.dec_positions) { set_error("prompt_len %d / max_length %d unsupported", P, L); return WSEG_ERR_INVALID; }
+  if (gp->n_suppress < 0 || gp->n_begin_suppress < 0 || (gp->n_suppress && !gp->suppress_tokens) || (gp->n_begin_suppress && !gp->begin_suppress_tokens)) {
+    set_error("bad suppress-token lists"); return WSEG_ERR_INVALID;
+  }
+  Plan p;
+  make_plan(m, n_windows, nb, L, aligned_base(workspace), p);
+  if (p.total + 256 > workspace_bytes) { set_error("workspace too small: need %zu, have %zu", p.total + 256, workspace_bytes); return WSEG_ERR_STATE; }
+  if (!m->ev_ok) {
+    for (int i = 0; i < 4; ++i) WSEG_HIP_CHECK(hipEventCreate(&m->ev[i]));
+    m->ev_ok = true;
+  }
+  if (!m->poll) WSEG_HIP_CHECK(hipHostMalloc((void**)&m->poll, 512 * sizeof(int), hipHostMallocDefault));
+  while ((int)m->step_ev.size() < L) {
+    hipEvent_t e;
+    WSEG_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    m->step_ev.push_back(e);
+  }
+  DecodeState& st = p.st;
+  st.P = P; st.eos = gp->eos_token_id; st.pad = gp->pad_token_id; st.max_length = L; st.length_penalty = gp->length_penalty;
+  for (int i = 0; i < 8; ++i) st.prompt[i] = i < P ? gp->prompt[i] : 0;
+
+  m->timing_valid = false;
+  WSEG_HIP_CHECK(hipEventRecord(m->ev[0], s));
+  WSEG_TRY(run_encoder(m, feats, n_windows, p, p.enc_out, s));
+  WSEG_HIP_CHECK(hipEventRecord(m->ev[1], s));
+  // cross-attention K/V of every decoder layer, once per window (shared by its beams)
+  {
+    const int d = c.d_model, H = c.n_heads, Tk = c.enc_positions, M = n_windows * Tk;
+    const size_t cross_stride = (size_t)n_windows * H * Tk * 64 * m->es;
+    for (int l = 0; l < c.dec_layers; ++l) {
+      EpiParams e;
+      e.bias = m->dec[l].ckv_b; e.k = p.ck + l * cross_stride; e.v = p.cv + l * cross_stride;
+      e.d_model = d; e.t_len = Tk; e.n_heads = H;
+      WSEG_TRY(gemm(m, EPI_KV_CROSS, p.enc_out, d, m->dec[l].ckv_w, d, M, 2 * d, d, e, nullptr, s));
+    }
+  }
+  WSEG_HIP_CHECK(hipEventRecord(m->ev[2], s));
+  WSEG_TRY(launch_build_suppress_mask((unsigned char*)p.mask, c.vocab, gp->suppress_tokens, gp->n_suppress,
+                                      gp->begin_suppress_tokens, gp->n_begin_suppress, s));
+  WSEG_TRY(launch_decode_init(st, s));
+  int steps = 0, checked = P - 1;
+  bool stop = false;
+  for (int t = 0; t < L - 1 && !stop; ++t) {
+    const bool gen = t >= P - 1;
+    WSEG_TRY(run_decoder_step(m, p, gen, s));
+    ++steps;
+    if (!gen) {
+      WSEG_TRY(launch_prompt_feed(st, s));
+    } else {
+      if (t == P - 1)
+        WSEG_HIP_CHECK(hipMemcpyAsync(p.first_logits, p.logits, (size_t)n_windows * nb * m->vp * 4, hipMemcpyDeviceToDevice, s));
+      WSEG_TRY(launch_row_topk(st, (const float*)p.logits, s));
+      if (nb == 1) WSEG_TRY(launch_greedy_step(st, s));
+      else WSEG_TRY(launch_beam_step(st, s));
+      m->poll[t] = -1;
+      WSEG_HIP_CHECK(hipMemcpyAsync(&m->poll[t], st.active + t, sizeof(int), hipMemcpyDeviceToHost, s));
+      WSEG_HIP_CHECK(hipEventRecord(m->step_ev[t], s));
+    }
+    WSEG_TRY(launch_advance(st, s));
+    // lagged, non-blocking poll: stop enqueueing once an already-finished step reported no improvable window
+    while (checked < t && hipEventQuery(m->step_ev[checked]) == hipSuccess) {
+      if (m->poll[checked] == 0) { stop = true; break; }
+      ++checked;
+    }
+  }
+  WSEG_TRY(launch_finalize(st, out_tokens, out_lengths, s));
+  WSEG_HIP_CHECK(hipEventRecord(m->ev[3], s));
+  m->last_steps = steps;
+  m->last_W = n_windows; m->last_nb = nb; m->last_L = L;
+  m->timing_valid = true;
+  return WSEG_OK;
+}
+
+extern "C" int wseg_debug_first_logits(wseg_model* m, void* workspace, float* out, int32_t n_rows, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (!m || !workspace || !out || n_rows <= 0) { set_error("wseg_debug_first_logits: bad argument"); return WSEG_ERR_INVALID; }
+  if (m->last_W <= 0 || n_rows > m->last_W * m->last_nb) { set_error("no matching wseg_generate call"); return WSEG_ERR_STATE; }
+  Plan p;
+  make_plan(m, m->last_W, m->last_nb, m->last_L, aligned_base(workspace), p);
+  WSEG_HIP_CHECK(hipMemcpy2DAsync(out, (size_t)m->cfg.vocab * 4, p.first_logits, (size_t)m->vp * 4, (size_t)m->cfg.vocab * 4,
+                                  (size_t)n_rows, hipMemcpyDeviceToDevice, s));
+  return WSEG_OK;
+}
+
+extern "C" int wseg_last_timing(const wseg_model* m, float out[4]) {
+  if (!m || !out) { set_error("wseg_last_timing: null argument"); return WSEG_ERR_INVALID; }
+  if (!m->timing_valid) { set_error("no completed wseg_generate call to time"); return WSEG_ERR_STATE; }
+  for (int i = 0; i < 3; ++i) {
+    WSEG_HIP_CHECK(hipEventSynchronize(m->ev[i + 1]));
+    WSEG_HIP_CHECK(hipEventElapsedTime(&out[i], m->ev[i], m->ev[i + 1]));
+  }
+  out[3] = (float)m->last_steps;
+  return WSEG_OK;
+}

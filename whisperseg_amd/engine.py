@@ -1,0 +1,257 @@
+"""Host-side driver of the libwseg model: weight preparation, workspace management, generate().
+
+PyTorch-ROCm is plumbing here (device memory, streams); every FLOP of the model runs in libwseg's
+hand-written HIP kernels through the C-ABI of include/wseg.h.  There is no CPU fallback.
+
+Replaces what the reference obtains from `WhisperForConditionalGeneration.from_pretrained(...)` and
+`model.generate(...)` (reference model.py:633-636, 655-666).
+"""
+import ctypes as C
+import json
+import os
+
+import torch
+
+from . import _lib
+
+DTYPES = {"f32": (0, torch.float32), "bf16": (1, torch.bfloat16)}
+
+# generation_config.suppress_tokens of the multilingual Whisper checkpoints WhisperSeg fine-tunes
+# (saved with the trained models: reference docs/WhisperSeg_Training_Pipeline.ipynb, generation params).
+DEFAULT_SUPPRESS_TOKENS = [
+    1, 2, 7, 8, 9, 10, 14, 25, 26, 27, 28, 29, 31, 58, 59, 60, 61, 62, 63, 90, 91, 92, 93, 359, 503, 522, 542, 873,
+    893, 902, 918, 922, 931, 1350, 1853, 1982, 2460, 2627, 3246, 3253, 3268, 3536, 3846, 3961, 4183, 4667, 6585, 6647,
+    7273, 9061, 9383, 10428, 10929, 11938, 12033, 12331, 12562, 13793, 14157, 14635, 15265, 15618, 16553, 16604, 18362,
+    18956, 20075, 21675, 22520, 26130, 26161, 26435, 28279, 29464, 31650, 32302, 32470, 36865, 42863, 47425, 49870,
+    50254, 50258, 50358, 50359, 50360, 50361, 50362]
+DEFAULT_BEGIN_SUPPRESS_TOKENS = [220, 50257]
+
+
+def _round_up(v, a):
+    return (v + a - 1) // a * a
+
+
+def geometry_from_config(cfg):
+    """cfg: dict in HF config.json vocabulary -> libwseg geometry dict."""
+    d = cfg["d_model"]
+    heads = cfg["encoder_attention_heads"]
+    if cfg.get("decoder_attention_heads", heads) != heads or cfg.get("decoder_ffn_dim", cfg["encoder_ffn_dim"]) != cfg["encoder_ffn_dim"]:
+        raise ValueError("encoder/decoder head count and ffn width must match")
+    spec_cols = cfg.get("total_spec_columns", 2 * cfg.get("max_source_positions", 500))
+    return dict(d_model=d, n_heads=heads, enc_layers=cfg["encoder_layers"], dec_layers=cfg["decoder_layers"],
+                ffn=cfg["encoder_ffn_dim"], vocab=cfg["vocab_size"], n_mels=cfg.get("num_mel_bins", 80),
+                spec_cols=spec_cols, enc_positions=cfg.get("max_source_positions", spec_cols // 2),
+                dec_positions=cfg.get("max_target_positions", 448))
+
+
+def prepare_weights(sd, geo, torch_dtype, device):
+    """HF-named state dict -> {libwseg tensor name: contiguous device tensor} (layouts of include/wseg.h).
+
+    qkv.w  [3d, d]   rows = q | k | v projections;   qkv.b has zeros for k (k_proj has no bias)
+    ckv.w  [2d, d]   rows = cross-attention k | v
+    conv1.w [d, Kp]  k = tap * n_mels + channel, zero padded to a multiple of 64
+    conv2.w [d, 3d]  k = tap * d + channel
+    dec.tok [Vp, d]  token embedding == tied LM head, rows padded to a multiple of 128
+    """
+    d, n_mels = geo["d_model"], geo["n_mels"]
+    dev = torch.device(device)
+
+    def g(name):
+        return sd[name].to(device=dev, dtype=torch.float32)
+
+    out = {}
+    kp1 = _round_up(3 * n_mels, 64)
+    w1 = g("model.encoder.conv1.weight").permute(0, 2, 1).reshape(d, 3 * n_mels)
+    out["enc.conv1.w"] = torch.nn.functional.pad(w1, (0, kp1 - 3 * n_mels))
+    out["enc.conv1.b"] = g("model.encoder.conv1.bias")
+    out["enc.conv2.w"] = g("model.encoder.conv2.weight").permute(0, 2, 1).reshape(d, 3 * d)
+    out["enc.conv2.b"] = g("model.encoder.conv2.bias")
+    out["enc.pos"] = g("model.encoder.embed_positions.weight")[: geo["enc_positions"]]
+    out["enc.ln.g"] = g("model.encoder.layer_norm.weight")
+    out["enc.ln.b"] = g("model.encoder.layer_norm.bias")
+    zeros = torch.zeros(d, device=dev)
+
+    def attn(dst, src, fused_kv_only=False):
+        q_w, k_w, v_w = g(src + "q_proj.weight"), g(src + "k_proj.weight"), g(src + "v_proj.weight")
+        q_b, v_b = g(src + "q_proj.bias"), g(src + "v_proj.bias")
+        if fused_kv_only:
+            out[dst + "cq.w"], out[dst + "cq.b"] = q_w, q_b
+            out[dst + "ckv.w"] = torch.cat([k_w, v_w], 0)
+            out[dst + "ckv.b"] = torch.cat([zeros, v_b], 0)
+            out[dst + "co.w"], out[dst + "co.b"] = g(src + "out_proj.weight"), g(src + "out_proj.bias")
+        else:
+            out[dst + "qkv.w"] = torch.cat([q_w, k_w, v_w], 0)
+            out[dst + "qkv.b"] = torch.cat([q_b, zeros, v_b], 0)
+            out[dst + "o.w"], out[dst + "o.b"] = g(src + "out_proj.weight"), g(src + "out_proj.bias")
+
+    def ln(dst, src):
+        out[dst + ".g"], out[dst + ".b"] = g(src + ".weight"), g(src + ".bias")
+
+    def mlp(dst, src):
+        for n in ("fc1", "fc2"):
+            out[f"{dst}{n}.w"], out[f"{dst}{n}.b"] = g(f"{src}{n}.weight"), g(f"{src}{n}.bias")
+
+    for i in range(geo["enc_layers"]):
+        s, t = f"model.encoder.layers.{i}.", f"enc.{i}."
+        ln(t + "ln1", s + "self_attn_layer_norm")
+        attn(t, s + "self_attn.")
+        ln(t + "ln2", s + "final_layer_norm")
+        mlp(t, s)
+    vp = _round_up(geo["vocab"], 128)
+    tok = g("model.decoder.embed_tokens.weight")
+    out["dec.tok"] = torch.nn.functional.pad(tok, (0, 0, 0, vp - tok.shape[0]))
+    out["dec.pos"] = g("model.decoder.embed_positions.weight")[: geo["dec_positions"]]
+    ln("dec.ln", "model.decoder.layer_norm")
+    for i in range(geo["dec_layers"]):
+        s, t = f"model.decoder.layers.{i}.", f"dec.{i}."
+        ln(t + "ln1", s + "self_attn_layer_norm")
+        attn(t, s + "self_attn.")
+        ln(t + "ln2", s + "encoder_attn_layer_norm")
+        attn(t, s + "encoder_attn.", fused_kv_only=True)
+        ln(t + "ln3", s + "final_layer_norm")
+        mlp(t, s)
+    return {k: v.to(torch_dtype).contiguous() for k, v in out.items()}
+
+
+def random_weights(geo, torch_dtype, device, seed=0):
+    """Seeded random weights generated directly on the device in libwseg layout (benchmarks:
+    no checkpoint exists offline).  Same distributions as oracle.whisper_ref.random_state_dict."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    d, f, nm = geo["d_model"], geo["ffn"], geo["n_mels"]
+    vp, kp1 = _round_up(geo["vocab"], 128), _round_up(3 * nm, 64)
+
+    def rn(*shape, s=0.02):
+        return (torch.randn(*shape, generator=gen, device=device, dtype=torch.float32) * s).to(torch_dtype)
+
+    out = {"enc.conv1.w": rn(d, kp1, s=0.05), "enc.conv1.b": rn(d), "enc.conv2.w": rn(d, 3 * d), "enc.conv2.b": rn(d),
+           "enc.pos": rn(geo["enc_positions"], d), "dec.tok": rn(vp, d, s=0.05), "dec.pos": rn(geo["dec_positions"], d)}
+    out["enc.conv1.w"][:, 3 * nm:] = 0
+
+    def ln(p):
+        out[p + ".g"] = (1.0 + torch.randn(d, generator=gen, device=device) * 0.1).to(torch_dtype)
+        out[p + ".b"] = rn(d, s=0.1)
+
+    def lin(p, n, k):
+        out[p + ".w"] = rn(n, k, s=k ** -0.5)
+        out[p + ".b"] = rn(n)
+
+    ln("enc.ln"); ln("dec.ln")
+    for side, n in (("enc", geo["enc_layers"]), ("dec", geo["dec_layers"])):
+        for i in range(n):
+            p = f"{side}.{i}."
+            ln(p + "ln1"); lin(p + "qkv", 3 * d, d); lin(p + "o", d, d); ln(p + "ln2")
+            out[p + "qkv.b"][d:2 * d] = 0
+            if side == "dec":
+                lin(p + "cq", d, d); lin(p + "ckv", 2 * d, d); lin(p + "co", d, d); ln(p + "ln3")
+                out[p + "ckv.b"][:d] = 0
+            lin(p + "fc1", f, d); lin(p + "fc2", d, f)
+    return out
+
+
+class Engine:
+    """One model replica on one GPU."""
+
+    def __init__(self, geo, weights, device="cuda:0", dtype="bf16"):
+        self.lib = _lib.load(require_device=True)
+        self.device = torch.device(device)
+        self.geo = dict(geo)
+        self.dtype_name = dtype
+        self.dtype_id, self.torch_dtype = DTYPES[dtype]
+        cfg = _lib.ModelConfig(**self.geo, dtype=self.dtype_id)
+        handle = C.c_void_p()
+        _lib.check(self.lib.wseg_model_create(C.byref(cfg), C.byref(handle)))
+        self.handle = handle
+        self.weights = weights          # keep the device tensors alive
+        for name, t in weights.items():
+            if t.device != self.device or t.dtype != self.torch_dtype or not t.is_contiguous():
+                raise ValueError(f"weight {name}: wrong device/dtype/layout")
+            _lib.check(self.lib.wseg_model_set_tensor(handle, name.encode(), t.data_ptr(), t.numel() * t.element_size()))
+        _lib.check(self.lib.wseg_model_ready(handle))
+        self._ws = None
+        self._ws_key = None
+
+    @classmethod
+    def from_state_dict(cls, sd, hf_config, device="cuda:0", dtype="bf16"):
+        geo = geometry_from_config(hf_config)
+        return cls(geo, prepare_weights(sd, geo, DTYPES[dtype][1], device), device, dtype)
+
+    @classmethod
+    def from_pretrained(cls, model_dir, device="cuda:0", dtype="bf16"):
+        """Read an HF-style checkpoint directory (config.json + model.safetensors | pytorch_model.bin)."""
+        with open(os.path.join(model_dir, "config.json")) as f:
+            hf_config = json.load(f)
+        st = os.path.join(model_dir, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(model_dir, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+        return cls.from_state_dict(sd, hf_config, device, dtype)
+
+    @classmethod
+    def random(cls, hf_config, device="cuda:0", dtype="bf16", seed=0):
+        geo = geometry_from_config(hf_config)
+        return cls(geo, random_weights(geo, DTYPES[dtype][1], device, seed), device, dtype)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.wseg_model_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def _workspace(self, n_windows, num_beams, max_length):
+        need = self.lib.wseg_workspace_bytes(self.handle, n_windows, num_beams, max_length)
+        if need == 0:
+            raise _lib.WsegError("wseg_workspace_bytes rejected the request")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def encode(self, feats):
+        """feats float32 device tensor [W, 80, 1000] -> [W, 500, d] in the model dtype."""
+        feats = feats.to(device=self.device, dtype=torch.float32).contiguous()
+        W = feats.shape[0]
+        ws = self._workspace(W, 1, 8)
+        out = torch.empty((W, self.geo["enc_positions"], self.geo["d_model"]), dtype=self.torch_dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.wseg_encode(self.handle, feats.data_ptr(), W, ws.data_ptr(), ws.numel(), out.data_ptr(),
+                                            _lib.stream_ptr()))
+        return out
+
+    def generate(self, feats, prompt, eos_token_id, pad_token_id, max_length=448, num_beams=4, length_penalty=1.0,
+                 suppress_tokens=(), begin_suppress_tokens=(), return_first_logits=False):
+        """Greedy / beam-search decode.  Returns (tokens int32 [W, max_length] on device, lengths int32 [W])."""
+        feats = feats.to(device=self.device, dtype=torch.float32).contiguous()
+        W = feats.shape[0]
+        max_length = int(min(max_length, self.geo["dec_positions"]))
+        ws = self._workspace(W, num_beams, max_length)
+        sup = torch.tensor(list(suppress_tokens) or [0], dtype=torch.int32, device=self.device)
+        bsup = torch.tensor(list(begin_suppress_tokens) or [0], dtype=torch.int32, device=self.device)
+        gp = _lib.GenerateParams()
+        for i, t in enumerate(prompt):
+            gp.prompt[i] = int(t)
+        gp.prompt_len = len(prompt)
+        gp.eos_token_id, gp.pad_token_id = int(eos_token_id), int(pad_token_id)
+        gp.max_length, gp.num_beams, gp.length_penalty = max_length, int(num_beams), float(length_penalty)
+        gp.suppress_tokens, gp.n_suppress = sup.data_ptr(), len(suppress_tokens)
+        gp.begin_suppress_tokens, gp.n_begin_suppress = bsup.data_ptr(), len(begin_suppress_tokens)
+        tokens = torch.empty((W, max_length), dtype=torch.int32, device=self.device)
+        lengths = torch.empty((W,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.wseg_generate(self.handle, feats.data_ptr(), W, C.byref(gp), ws.data_ptr(), ws.numel(),
+                                              tokens.data_ptr(), lengths.data_ptr(), _lib.stream_ptr()))
+            if return_first_logits:
+                fl = torch.empty((W * num_beams, self.geo["vocab"]), dtype=torch.float32, device=self.device)
+                _lib.check(self.lib.wseg_debug_first_logits(self.handle, ws.data_ptr(), fl.data_ptr(), W * num_beams,
+                                                            _lib.stream_ptr()))
+                return tokens, lengths, fl
+        return tokens, lengths
+
+    def last_timing(self):
+        """(encoder_ms, cross_kv_ms, decode_ms, n_steps) of the last generate call (synchronises)."""
+        arr = (C.c_float * 4)()
+        _lib.check(self.lib.wseg_last_timing(self.handle, C.byref(arr)))
+        return tuple(arr)
