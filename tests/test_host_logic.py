@@ -1,0 +1,105 @@
+"""Product host logic (whisperseg_amd.windows / postprocess / model.SegmenterBase.segment) against golden
+outputs of the reference's own segment() driven with the same generated texts.  No GPU: the device
+stages are stubbed, everything else is the shipped code.  Comparison is EXACT float equality."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_inputs as GI
+from whisperseg_amd import postprocess
+from whisperseg_amd.model import SegmenterBase
+from whisperseg_amd.windows import shard_bounds, window_table
+
+
+def test_window_table_exact(golden_dir):
+    with open(os.path.join(golden_dir, "windows.json")) as f:
+        cases = json.load(f)
+    for c in cases:
+        rows = window_table(c["n"], c["sr"], c["sts"], c["trials"], 1000)
+        assert [[w.trial_id, w.offset_time, w.clip_seconds] for w in rows] == c["table"], c
+
+
+class StubSegmenter(SegmenterBase):
+    """Device stages replaced: windows carry no features, texts come from the fixture."""
+
+    def __init__(self, codebook, texts):
+        super().__init__()
+        self.total_spec_columns = 1000
+        self.cluster_codebook = codebook
+        self.texts = texts
+        self.device_list = ["stub"]
+
+    def get_sliced_audios_features(self, audio, sr, min_frequency, spec_time_step, num_trials):
+        return [(w.trial_id, w.offset_time, None, w.clip_seconds)
+                for w in window_table(len(audio), sr, spec_time_step, num_trials, self.total_spec_columns)]
+
+    def generate_segment_text(self, sliced, *a, **k):
+        assert len(sliced) == len(self.texts)
+        return list(self.texts)
+
+
+def load_cases(golden_dir):
+    with open(os.path.join(golden_dir, "parse_cases.json")) as f:
+        return json.load(f)
+
+
+def test_segment_epilogue_exact(golden_dir):
+    cases = load_cases(golden_dir)
+    assert len(cases) >= 10
+    for c in cases:
+        audio = GI.signal("sine_noise", max(c["n"], 1), c["sr"], 21)[: c["n"]]
+        seg = StubSegmenter(c["cluster_codebook"], c["texts"])
+        got = seg.segment(audio, c["sr"], spec_time_step=c["sts"], **c["kwargs"])
+        assert got == c["expected"], c["name"]
+
+
+def test_dbscan_interval_equals_sklearn():
+    """The banded DBSCAN used for large inputs yields sklearn's partition (same labels up to noise)."""
+    from sklearn.cluster import DBSCAN
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        n = int(rng.integers(1, 200))
+        on = np.sort(rng.uniform(0, 20, n))
+        pts = np.stack([on, on + rng.uniform(0.01, 0.5, n)], 1)
+        pts = np.concatenate([pts, pts[: n // 2] + rng.normal(0, 0.01, (n // 2, 2))])
+        eps, ms = float(rng.choice([0.01, 0.02, 0.08])), int(rng.integers(2, 4))
+        dist = (np.abs(pts[:, None, 0] - pts[None, :, 0]) + np.abs(pts[:, None, 1] - pts[None, :, 1])) / 2
+        want = DBSCAN(eps=eps, min_samples=ms, metric="precomputed").fit_predict(dist)
+        got = postprocess.dbscan_interval(pts, eps, ms)
+        assert np.array_equal(want, got)
+
+
+def test_shard_bounds_is_reference_split():
+    # ceil(N / n_dev) contiguous items per device, in order (reference model.py:172-175)
+    assert shard_bounds(10, 4) == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert shard_bounds(8, 8) == [(i, i + 1) for i in range(8)]
+    assert shard_bounds(3, 8) == [(0, 1), (1, 2), (2, 3)]
+    assert shard_bounds(0, 4) == []
+    assert shard_bounds(120, 8) == [(i * 15, i * 15 + 15) for i in range(8)]
+
+
+def test_defaults_follow_reference():
+    """segment() defaults (reference model.py:406-425): num_trials=1, num_beams=4, batch_size=4, max_length=448;
+    min_segment_length = 2*sts, eps = 8*sts."""
+    import inspect
+    sig = inspect.signature(SegmenterBase.segment)
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert (d["num_trials"], d["num_beams"], d["batch_size"], d["max_length"], d["top_k"], d["top_p"], d["length_penalty"]) \
+        == (1, 4, 4, 448, 1, 1.0, 1.0)
+    assert d["consolidation_method"] == "clustering" and d["status_monitor"] is None
+
+
+def test_scoring_helpers():
+    seg = SegmenterBase()
+    pred = {"onset": [0.1, 1.0, 2.0], "offset": [0.5, 1.5, 2.5], "cluster": ["a", "b", "a"]}
+    lab = {"onset": [0.105, 1.2, 2.0], "offset": [0.5, 1.7, 2.5], "cluster": ["a", "b", "b"]}
+    # expected values recorded from the reference's SegmenterBase.segment_score / frame_score on these inputs
+    import copy
+    got = [float(v) for v in seg.segment_score(copy.deepcopy(pred), copy.deepcopy(lab), tolerance=0.01)]
+    assert got == [1.0, 3.0, 3.0, 0.3333333333333333, 0.3333333333333333, 0.3333333333333333]
+    got = [float(v) for v in seg.frame_score(copy.deepcopy(pred), copy.deepcopy(lab), time_per_frame_for_scoring=0.001)]
+    assert got == [695.0, 1400.0, 1395.0, 0.49642857142857144, 0.4982078853046595, 0.4973166368515206]
+    got = [float(v) for v in seg.frame_score(copy.deepcopy(pred), copy.deepcopy(lab), target_cluster="b", time_per_frame_for_scoring=0.001)]
+    assert got == [300.0, 500.0, 1000.0, 0.6, 0.3, 0.4]

@@ -1,0 +1,72 @@
+"""Pins oracle/whisper_ref.py against outputs of HF `generate` driven through the reference's own
+WhisperSegmenterForEval on the tiny trained model (tools/make_golden.py -> tests/golden/tiny_generate.*)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as GI
+from oracle import frontend as F
+from oracle import whisper_ref as W
+from tools import tiny_model as TM
+
+
+@pytest.fixture(scope="module")
+def tiny(golden_dir):
+    from safetensors.torch import load_file
+    mdir = os.path.join(golden_dir, "tiny_model")
+    sd = {k: v.float() for k, v in load_file(os.path.join(mdir, "model.safetensors")).items()}
+    with open(os.path.join(mdir, "config.json")) as f:
+        cfg = json.load(f)
+    with open(os.path.join(golden_dir, "tiny_generate.json")) as f:
+        runs = json.load(f)
+    return sd, W.RefConfig.from_hf_dict(cfg), runs, np.load(os.path.join(golden_dir, "tiny_generate.npz"))
+
+
+def content(tokens):
+    """generated ids before the first EOS, prompt stripped (HF 4.38.2 returns the prompt, 5.15 does not)."""
+    c = W.canonical(tokens, 3, TM.EOT, TM.PROMPT)
+    return c[:-1] if c and c[-1] == TM.EOT else c
+
+
+def test_encoder_and_first_logits(tiny):
+    sd, rc, runs, z = tiny
+    audio = GI.tiny_recording(100, 3)
+    sliced = F.sliced_audio_features(audio, TM.SR, 0, TM.STS, 1)
+    feats = torch.from_numpy(np.stack([s[2] for s in sliced]))
+    assert np.max(np.abs(feats.numpy()[:, :, ::GI.COL_STRIDE] - z["features_cols"])) <= 1e-4
+    enc = W.encoder_forward(sd, rc, feats)
+    assert np.max(np.abs(enc.numpy()[:, ::25, :] - z["enc_out_sample"])) <= 2e-4
+    gp = W.GenParams(prompt=TM.PROMPT, eos_token_id=TM.EOT, pad_token_id=TM.EOT, max_length=8, num_beams=1)
+    _, logits = W.generate(sd, rc, feats, gp, return_first_logits=True)
+    assert np.max(np.abs(logits.numpy() - z["first_logits"])) <= 2e-3
+
+
+def test_token_sequences_match_hf(tiny):
+    """Greedy and beam search (beams 1/2/4, default and short max_length, EOS at varied lengths)."""
+    sd, rc, runs, _ = tiny
+    n_checked = 0
+    for run in runs:
+        kw = run["kwargs"]
+        audio = GI.tiny_recording(run["seed"], run["n_windows"])
+        sliced = F.sliced_audio_features(audio, TM.SR, 0, TM.STS, kw.get("num_trials", 1))
+        feats = torch.from_numpy(np.stack([s[2] for s in sliced]))
+        gp = W.GenParams(prompt=TM.PROMPT, eos_token_id=TM.EOT, pad_token_id=TM.EOT, max_length=kw.get("max_length", 448),
+                         num_beams=kw["num_beams"], suppress_tokens=TM.SUPPRESS, begin_suppress_tokens=TM.BEGIN_SUPPRESS)
+        pos = 0
+        for batch in run["token_batches"]:
+            out = W.generate(sd, rc, feats[pos:pos + len(batch)], gp)
+            for want, got in zip(batch, out.tolist()):
+                assert content(got) == content(want), (kw, pos)
+                n_checked += 1
+            pos += len(batch)
+        assert pos == len(sliced)
+    assert n_checked >= 20
+
+
+def test_eos_fires_at_varied_lengths(tiny):
+    _, _, runs, _ = tiny
+    lengths = {len(content(row)) for run in runs for b in run["token_batches"] for row in b}
+    assert len(lengths) >= 5

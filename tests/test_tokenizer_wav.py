@@ -1,0 +1,43 @@
+import io
+import os
+import struct
+
+import numpy as np
+
+from tools import tiny_model as TM
+from whisperseg_amd.tokenizer import WhisperSegTokenizer
+from whisperseg_amd.wavio import load_wav
+
+
+def test_tokenizer_roundtrip(golden_dir):
+    tok = WhisperSegTokenizer.from_pretrained(os.path.join(golden_dir, "tiny_model"))
+    assert tok.convert_tokens_to_ids(["<|startoftranscript|>", "<|en|>", "<|notimestamps|>"]) == TM.PROMPT
+    assert tok.eos_token_id == TM.EOT == tok.pad_token_id
+    ids = TM.PROMPT + TM.label_tokens([(0.24, 1.0, 2), (3.0, 3.5, 0)])
+    text = tok.batch_decode([ids])[0]
+    assert text == "<|startoftranscript|><|en|><|notimestamps|><|unknown|><|12|>2<|50|><|150|>0<|175|><|endoftext|>"
+    assert tok.decode([TM.TIME0 + 7, 16, 15, TM.TIME0 + 9]) == "<|7|>10<|9|>"       # multi-digit cluster id
+    assert tok.decode(ids, skip_special_tokens=True) == "20"
+
+
+def _wav(fmt_tag, bits, channels, sr, payload):
+    block = channels * bits // 8
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(payload)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, fmt_tag, channels, sr, sr * block, block, bits)
+    return hdr + b"data" + struct.pack("<I", len(payload)) + payload
+
+
+def test_wav_formats(golden_dir):
+    x, sr = load_wav(os.path.join(golden_dir, "meerkat_5s.wav"))
+    assert sr == 16000 and x.shape == (80000,) and x.dtype == np.float32 and 0 < np.abs(x).max() <= 1
+    pcm = np.array([0, 16384, -32768, 32767], "<i2")
+    y, sr = load_wav(io.BytesIO(_wav(1, 16, 1, 8000, pcm.tobytes())))
+    assert sr == 8000 and y.tolist() == [0.0, 0.5, -1.0, 32767 / 32768]
+    st = np.array([[1000, 3000], [-2000, 2000]], "<i2")
+    y, _ = load_wav(io.BytesIO(_wav(1, 16, 2, 8000, st.tobytes())))
+    assert np.allclose(y, [2000 / 32768, 0.0])
+    f = np.array([0.25, -0.5], "<f4")
+    y, _ = load_wav(io.BytesIO(_wav(3, 32, 1, 48000, f.tobytes())))
+    assert y.tolist() == [0.25, -0.5]
+    b24 = bytes([0, 0, 0x40, 0, 0, 0xC0])
+    y, _ = load_wav(io.BytesIO(_wav(1, 24, 1, 48000, b24)))
+    assert y.tolist() == [0.5, -0.5]

@@ -1,0 +1,305 @@
+"""Generate tests/golden/* by running the REFERENCE itself (imported read-only from /root/reference,
+tools/ref_import.py) and its HuggingFace backend in the build container.
+
+    python tools/make_golden.py [--only frontend|windows|parse|tiny]
+
+Only inputs (seeds, parameters, hand-written generated texts) and expected outputs are stored — never
+reference source.  The tests regenerate the inputs from tests/golden_inputs.py.
+
+Files written
+  frontend.json        G1 n_fft ladder; G2 mel filterbank checksums + sampled rows
+  logmel.npz           G3 log-mel windows (every 4th column) from BOTH HF paths (numpy float64 = what
+                       the pinned transformers 4.38.2 runs; torch float32 = what 5.15 dispatches to)
+  windows.json         G4 window tables (trial_id, offset_time, clip_seconds) from get_sliced_audios_features
+  parse_cases.json     G5 segment() driven through a SegmenterBase subclass with a stubbed backend
+  tiny_generate.npz/json  G6/G7 encoder output, first-step logits, token ids and segment() results of the
+                       tiny trained model driven through the reference's WhisperSegmenterForEval
+  meerkat_5s.wav       first 5 s of a 16 kHz example clip (input data for the CLI plumbing test)
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from ref_import import import_reference  # noqa: E402
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import golden_inputs as GI  # noqa: E402
+from tools import tiny_model as TM  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def make_frontend(ref_audio, ref_model):
+    srs = [8000, 16000, 32000, 32001, 44100, 48000, 80000, 80001, 96000, 150000, 150001, 250000, 300000, 300001, 384000]
+    g1 = {str(sr): ref_audio.get_n_fft_given_sr(sr) for sr in srs}
+    g2 = {}
+    for sr, sts, min_f in [(16000, 0.01, 0), (32000, 0.0025, 0), (48000, 0.0025, 0), (300000, 0.0005, 35000), (44100, 0.0025, 500)]:
+        fe = ref_audio.WhisperSegFeatureExtractor(sr, sts, min_frequency=min_f)
+        mf = np.asarray(fe.mel_filters, dtype=np.float64)
+        rows = [0, 1, 7, mf.shape[0] // 3, mf.shape[0] // 2, mf.shape[0] - 2, mf.shape[0] - 1]
+        g2[f"{sr}_{min_f}"] = dict(shape=list(mf.shape), sha256=hashlib.sha256(mf.tobytes()).hexdigest(),
+                                   hop=fe.hop_length, n_fft=fe.n_fft,
+                                   rows={str(r): mf[r].tolist() for r in rows}, col_sums=mf.sum(0).tolist())
+    with open(os.path.join(OUT, "frontend.json"), "w") as f:
+        json.dump({"n_fft": g1, "mel_filters": g2}, f)
+    arrays = {}
+    for name, sr, sts, min_f, kind, seed in GI.LOGMEL_CASES:
+        x = GI.signal(kind, GI.window_len(sr, sts), sr, seed)
+        fe = ref_audio.WhisperSegFeatureExtractor(sr, sts, min_frequency=min_f)
+        a = fe._np_extract_fbank_features(x[None].astype(np.float32), "cpu")[0]
+        b = fe(x, sampling_rate=sr, padding="do_not_pad")["input_features"][0]
+        arrays[name + "__np"] = np.asarray(a, np.float32)[:, ::GI.COL_STRIDE]
+        arrays[name + "__default"] = np.asarray(b, np.float32)[:, ::GI.COL_STRIDE]
+        arrays[name + "__shape"] = np.array(a.shape)
+        print(name, a.shape, float(np.abs(a - b).max()))
+    np.savez_compressed(os.path.join(OUT, "logmel.npz"), **arrays)
+
+
+class _StubSegmenter:
+    pass
+
+
+def make_windows(ref_audio, ref_model):
+    seg = ref_model.SegmenterBase()
+    seg.total_spec_columns = 1000
+    out = []
+    for sr, sts, n, trials in GI.WINDOW_TABLE_CASES:
+        audio = GI.signal("sine_noise", max(n, 1), sr, 11)[:n]
+        # features are expensive and irrelevant here: patch the extractor call away
+        orig = ref_audio.WhisperSegFeatureExtractor.__call__
+
+        def fake(self, clip, sampling_rate=None, padding=None):
+            return {"input_features": [np.zeros((80, len(clip) // self.hop_length), np.float32)]}
+        ref_audio.WhisperSegFeatureExtractor.__call__ = fake
+        ref_model.WhisperSegFeatureExtractor.__call__ = fake
+        try:
+            rows = seg.get_sliced_audios_features(audio, sr, 0, sts, trials)
+        finally:
+            ref_audio.WhisperSegFeatureExtractor.__call__ = orig
+            ref_model.WhisperSegFeatureExtractor.__call__ = orig
+        out.append(dict(sr=sr, sts=sts, n=n, trials=trials,
+                        table=[[int(r[0]), float(r[1]), float(r[3])] for r in rows]))
+    with open(os.path.join(OUT, "windows.json"), "w") as f:
+        json.dump(out, f)
+
+
+def tok(i):
+    return "<|%d|>" % i
+
+
+def seg_text(segs, species="<|unknown|>", tail="<|endoftext|>"):
+    return "<|startoftranscript|><|en|><|notimestamps|>" + species + "".join(tok(a) + str(c) + tok(b) for a, c, b in segs) + tail
+
+
+PARSE_CASES = [
+    # name, sr, sts, n_samples, kwargs, per-window texts (callable on number of windows)
+    dict(name="stitch_across_windows", sr=16000, sts=0.01, n=16000 * 25, kwargs={},
+         texts=[seg_text([(10, 0, 60), (450, 1, 500)]), seg_text([(0, 1, 30), (100, 2, 130)]), seg_text([(5, 0, 40)])]),
+    dict(name="no_stitch_different_cluster", sr=16000, sts=0.01, n=16000 * 20, kwargs={},
+         texts=[seg_text([(450, 1, 500)]), seg_text([(0, 2, 30)])]),
+    dict(name="unknown_cluster_zero_length_reversed", sr=16000, sts=0.01, n=16000 * 9, kwargs={},
+         texts=[seg_text([(10, 7, 60), (70, 0, 70), (90, 1, 80), (100, 2, 150), (200, 12, 230)])]),
+    dict(name="clamp_and_min_length", sr=16000, sts=0.01, n=16000 * 4 + 123, kwargs={"min_segment_length": 0.05},
+         texts=[seg_text([(0, 0, 1), (10, 1, 12), (20, 2, 60), (190, 0, 260)])]),
+    dict(name="blur_collapse_and_duplicates", sr=16000, sts=0.0025, n=16000 * 2, kwargs={},
+         texts=[seg_text([(10, 0, 11), (10, 0, 11), (20, 1, 40), (20, 1, 40), (50, 2, 56)])]),
+    dict(name="garbage_text", sr=16000, sts=0.01, n=16000 * 5, kwargs={},
+         texts=["<|startoftranscript|><|en|><|notimestamps|><|unknown|>abc<|12|><|13|>5<|20|>0<|25|> 1 <|30|>1<|35|><|endoftext|><|endoftext|>"]),
+    dict(name="empty_audio", sr=16000, sts=0.01, n=0, kwargs={}, texts=[seg_text([])]),
+    dict(name="one_sample", sr=32000, sts=0.0025, n=1, kwargs={}, texts=[seg_text([(0, 0, 5)])]),
+    dict(name="three_trials_clustering", sr=16000, sts=0.01, n=16000 * 12, kwargs={"num_trials": 3},
+         texts=None),
+    dict(name="three_trials_voting", sr=16000, sts=0.01, n=16000 * 12,
+         kwargs={"num_trials": 3, "consolidation_method": "voting"}, texts=None),
+    dict(name="two_trials_eps", sr=32000, sts=0.0025, n=32000 * 4, kwargs={"num_trials": 2, "eps": 0.004}, texts=None),
+]
+
+
+def trial_texts(ref_rows, sts, seed, jitter):
+    """Plausible multi-trial outputs: the same ground-truth events seen through each window's offset, with
+    per-trial jitter and one spurious / one relabelled segment to make consolidation do something."""
+    rng = np.random.default_rng(seed)
+    truth = [(0.52, 1.31, 0), (2.05, 2.64, 1), (3.3, 3.9, 2), (6.0, 6.2, 0), (9.4, 11.0, 1), (11.2, 11.6, 2)]
+    texts = []
+    for k, (trial_id, offset_time, _, clip_s) in enumerate(ref_rows):
+        segs = []
+        for on, off, c in truth:
+            a, b = on - offset_time, off - offset_time
+            if b <= 0 or a >= 1000 * sts:
+                continue
+            ia = int(np.clip(np.round(a / sts / 2) + rng.integers(-jitter, jitter + 1), 0, 500))
+            ib = int(np.clip(np.round(b / sts / 2) + rng.integers(-jitter, jitter + 1), 0, 500))
+            cc = c if not (trial_id == 1 and c == 2) else 1
+            segs.append((ia, cc, ib))
+        if trial_id == 2 and k % 2 == 0:
+            segs.append((400, 0, 410))
+        texts.append(seg_text(segs))
+    return texts
+
+
+def make_parse(ref_audio, ref_model):
+    codebook = {"a": 0, "b": 1, "c": 2}
+    results = []
+    for case in PARSE_CASES:
+        class Stub(ref_model.SegmenterBase):
+            def __init__(self, texts_fn):
+                super().__init__()
+                self.total_spec_columns = 1000
+                self.cluster_codebook = codebook
+                self.texts_fn = texts_fn
+                self.seen = None
+
+            def generate_segment_text(self, sliced, *a, **k):
+                self.seen = sliced
+                return self.texts_fn(sliced)
+
+        sr, sts, n = case["sr"], case["sts"], case["n"]
+        audio = GI.signal("sine_noise", max(n, 1), sr, 21)[:n]
+        if case["texts"] is not None:
+            fixed = case["texts"]
+            fn = lambda sliced, fixed=fixed: list(fixed)  # noqa: E731
+        else:
+            fn = lambda sliced, sts=sts, name=case["name"]: trial_texts(sliced, sts, len(name), 2)  # noqa: E731
+        stub = Stub(fn)
+        res = stub.segment(audio, sr, spec_time_step=sts, **case["kwargs"])
+        texts = fn(stub.seen)
+        assert len(texts) == len(stub.seen), (case["name"], len(texts), len(stub.seen))
+        results.append(dict(name=case["name"], sr=sr, sts=sts, n=n, kwargs=case["kwargs"], texts=texts,
+                            cluster_codebook=codebook, expected=res))
+        print(case["name"], len(stub.seen), "windows ->", len(res["onset"]), "segments")
+    with open(os.path.join(OUT, "parse_cases.json"), "w") as f:
+        json.dump(results, f)
+
+
+class FakeTokenizer:
+    """Only what the reference touches (model.py:610-611, 620): ids of the prompt tokens, pad/eos, batch_decode."""
+
+    def __init__(self):
+        self.enc = dict(TM.base_vocab())
+        self.enc.update(TM.added_tokens())
+        self.dec = {v: k for k, v in self.enc.items()}
+        self.pad_token_id = TM.EOT
+        self.eos_token_id = TM.EOT
+
+    def convert_tokens_to_ids(self, toks):
+        return [self.enc[t] for t in toks]
+
+    def batch_decode(self, ids, skip_special_tokens=False):
+        return ["".join(self.dec.get(int(i), "") for i in row) for row in ids.tolist()]
+
+
+def make_tiny(ref_audio, ref_model):
+    from safetensors.torch import load_file
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+    mdir = os.path.join(OUT, "tiny_model")
+    cd = json.load(open(os.path.join(mdir, "config.json")))
+    extra = {k: cd.pop(k) for k in ("total_spec_columns", "cluster_codebook", "default_segmentation_config", "model_type")}
+    cfg = WhisperConfig(**cd, suppress_tokens=None, begin_suppress_tokens=None)
+    hf = WhisperForConditionalGeneration(cfg).eval()
+    sd = {k: v.float() for k, v in load_file(os.path.join(mdir, "model.safetensors")).items()}
+    sd["proj_out.weight"] = sd["model.decoder.embed_tokens.weight"]
+    hf.load_state_dict(sd, strict=True)
+    hf.config.total_spec_columns = extra["total_spec_columns"]
+    hf.config.cluster_codebook = extra["cluster_codebook"]
+    hf.config.default_segmentation_config = extra["default_segmentation_config"]
+    hf.generation_config.suppress_tokens = TM.SUPPRESS
+    hf.generation_config.begin_suppress_tokens = TM.BEGIN_SUPPRESS
+    hf.generation_config.max_length = 448
+    captured = []
+
+    class Shim:
+        """The reference calls model.generate(inputs=...); transformers 5.15 only accepts input_features=
+        (SURVEY §8c).  5.15 also counts max_length EXCLUDING the prompt (generation_whisper.py:1934-1940),
+        while the pinned 4.38.2 counts it INCLUDING the prompt; pass max_length-3 so the effective total
+        equals what the pinned version would produce for the caller's max_length."""
+        config = hf.config
+
+        def parameters(self):
+            return hf.parameters()
+
+        def generate(self, inputs=None, **kw):
+            kw["max_length"] = max(1, kw["max_length"] - 3)
+            kw.pop("top_k", None)
+            kw.pop("top_p", None)
+            kw["do_sample"] = False
+            ids = hf.generate(input_features=inputs, **kw)
+            captured.append(ids.clone())
+            return ids
+
+    segm = ref_model.WhisperSegmenterForEval(model=Shim(), tokenizer=FakeTokenizer())
+    arrays, meta = {}, []
+    runs = [  # seed, n_windows, kwargs
+        (100, 3, dict(num_beams=1, num_trials=1, batch_size=4)),
+        (100, 3, dict(num_beams=4, num_trials=1, batch_size=4)),
+        (100, 3, dict(num_beams=4, num_trials=3, batch_size=3)),
+        (102, 4, dict(num_beams=4, num_trials=1, batch_size=2, max_length=20)),
+        (103, 2, dict(num_beams=2, num_trials=1, batch_size=8)),
+        (100, 2, dict(num_beams=4, num_trials=3, batch_size=8, consolidation_method="voting")),
+        (101, 2, dict(num_beams=4, num_trials=3, batch_size=3)),
+        (105, 2, dict(num_beams=1, num_trials=1, batch_size=8, max_length=12)),
+    ]
+    for ridx, (seed, nw, kw) in enumerate(runs):
+        audio = GI.tiny_recording(seed, nw)
+        captured.clear()
+        res = segm.segment(audio, TM.SR, **kw)
+        ids = [c.tolist() for c in captured]
+        meta.append(dict(seed=seed, n_windows=nw, kwargs=kw, expected=res, token_batches=ids))
+        print("run", ridx, kw, "->", len(res["onset"]), "segments; batches", [len(b) for b in ids])
+    # G6: encoder output + first-step logits for 3 windows of run 0's recording
+    audio = GI.tiny_recording(100, 3)
+    sliced = segm.get_sliced_audios_features(audio, TM.SR, 0, TM.STS, 1)
+    feats = torch.from_numpy(np.asarray([s[2] for s in sliced]))
+    with torch.no_grad():
+        enc = hf.model.encoder(feats).last_hidden_state
+        dec_in = torch.tensor([TM.PROMPT] * feats.shape[0])
+        logits = hf(input_features=feats, decoder_input_ids=dec_in).logits[:, -1]
+    arrays["features_cols"] = feats.numpy()[:, :, ::GI.COL_STRIDE]
+    arrays["enc_out_sample"] = enc.numpy()[:, ::25, :]
+    arrays["first_logits"] = logits.numpy()
+    np.savez_compressed(os.path.join(OUT, "tiny_generate.npz"), **arrays)
+    with open(os.path.join(OUT, "tiny_generate.json"), "w") as f:
+        json.dump(meta, f)
+
+
+def make_wav():
+    import shutil
+    import struct
+    src = "/root/reference/data/example_subset/Meerkat/test/VALP007_AL_6_15DEC2022_MF_ML.wav"
+    with open(src, "rb") as f:
+        raw = f.read()
+    # canonical 44-byte header for this file; keep the first 5 s of PCM16 mono 16 kHz
+    pos = raw.find(b"data")
+    n_bytes = 5 * 16000 * 2
+    data = raw[pos + 8: pos + 8 + n_bytes]
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16) \
+        + b"data" + struct.pack("<I", len(data))
+    with open(os.path.join(OUT, "meerkat_5s.wav"), "wb") as f:
+        f.write(hdr + data)
+    del shutil
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    ref_audio, ref_model = import_reference()
+    steps = dict(frontend=make_frontend, windows=make_windows, parse=make_parse, tiny=make_tiny)
+    for name, fn in steps.items():
+        if args.only in (None, name):
+            print("==", name)
+            fn(ref_audio, ref_model)
+    if args.only in (None, "wav"):
+        make_wav()
+
+
+if __name__ == "__main__":
+    main()

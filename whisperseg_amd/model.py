@@ -1,0 +1,291 @@
+"""Segmenter API — host-side mirror of reference model.py (SegmenterBase :118-470, WhisperSegmenterForEval
+:572-622, WhisperSegmenter :625-676, WhisperSegmenterFast :678-746) on top of the MI355X engine.
+
+Same class names, constructor signatures, `segment()` keyword arguments / defaults and return value
+({"onset": [...], "offset": [...], "cluster": [...]}); same backend seam
+(`generate_segment_text_core(...)` writing `generated_texts_dict[thread_id]`).  What differs is where the
+work happens: windows are cut, transformed to log-mel and decoded on the GPU by libwseg; this file only
+does bookkeeping.  There is no CPU execution path — constructing a segmenter without a gfx950 device or
+without libwseg.so raises.
+"""
+import json
+import os
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib, postprocess, scoring
+from .audio_utils import get_feature_extractor, get_n_fft_given_sr
+from .engine import DEFAULT_BEGIN_SUPPRESS_TOKENS, DEFAULT_SUPPRESS_TOKENS, Engine
+from .tokenizer import WhisperSegTokenizer
+from .utils import RATIO_DECODING_TIME_STEP_TO_SPEC_TIME_STEP
+from .windows import shard_bounds, window_table
+
+PROMPT_TOKENS = ["<|startoftranscript|>", "<|en|>", "<|notimestamps|>"]   # reference model.py:656
+
+
+def _read_json(path, default=None):
+    if not os.path.exists(path):
+        return default
+    with open(path) as f:
+        return json.load(f)
+
+
+def resolve_model_dir(model_path):
+    """Directory holding config.json + weights.  Accepts the reference's two layouts: a plain HF
+    checkpoint dir (model.py:633) or a converted dir with an `hf_model/` subfolder (model.py:694-702)."""
+    if os.path.exists(os.path.join(model_path, "config.json")):
+        return model_path
+    sub = os.path.join(model_path, "hf_model")
+    if os.path.exists(os.path.join(sub, "config.json")):
+        return sub
+    raise FileNotFoundError(f"{model_path}: no config.json (model download is not available offline; pass a local directory)")
+
+
+def load_generation_settings(model_dir, vocab_size):
+    """suppress_tokens / begin_suppress_tokens as HF would take them from the checkpoint's
+    generation_config.json (falling back to config.json, then to the multilingual-Whisper defaults)."""
+    for name in ("generation_config.json", "config.json"):
+        cfg = _read_json(os.path.join(model_dir, name), {}) or {}
+        if "suppress_tokens" in cfg or "begin_suppress_tokens" in cfg:
+            return list(cfg.get("suppress_tokens") or []), list(cfg.get("begin_suppress_tokens") or [])
+    if vocab_size == 51865:
+        return list(DEFAULT_SUPPRESS_TOKENS), list(DEFAULT_BEGIN_SUPPRESS_TOKENS)
+    return [], []
+
+
+class SegmenterBase:
+    def __init__(self):
+        self.segment_matcher = postprocess.SEGMENT_PATTERN
+        self.total_spec_columns = None
+        self.precision_bits = 3
+        self.cluster_codebook = None
+        self.default_segmentation_config = {}
+        self.device_list = []
+        self.suppress_tokens, self.begin_suppress_tokens = [], []
+
+    # ---- slicing + features (reference model.py:127-166), batched on the first device ------------
+    def get_sliced_audios_features(self, audio, sr, min_frequency, spec_time_step, num_trials):
+        """-> list of (trial_id, offset_time, features, clip_seconds); `features` is a float32 [80, 1000]
+        DEVICE tensor (a view into one batch tensor) instead of a numpy array."""
+        cols = self.total_spec_columns
+        chunk_length = max(30, int(np.ceil(spec_time_step * cols)))
+        device = self.device_list[0]
+        extractor = get_feature_extractor(sr, spec_time_step, min_frequency, chunk_length, cols, device)
+        table = window_table(len(audio), sr, spec_time_step, num_trials, cols)
+        clip_len = int(cols * spec_time_step * sr)
+        pcm = torch.as_tensor(np.ascontiguousarray(audio, dtype=np.float32)).to(device, non_blocking=True)
+        starts = torch.tensor([w.start for w in table], dtype=torch.int64).to(device, non_blocking=True)
+        feats = extractor.extract_windows(pcm, starts, clip_len)
+        return [(w.trial_id, w.offset_time, feats[i], w.clip_seconds) for i, w in enumerate(table)]
+
+    # ---- device fan-out (reference model.py:169-189) ---------------------------------------------
+    def generate_segment_text(self, sliced_audios_features, batch_size, max_length, num_beams, top_k=1, top_p=1.0,
+                              length_penalty=1.0, status_monitor=None):
+        texts_by_shard, errors, threads = {}, {}, []
+
+        def run(shard, thread_id, monitor):
+            try:
+                self.generate_segment_text_core(shard, batch_size, max_length, num_beams, top_k, top_p, length_penalty,
+                                                texts_by_shard, thread_id, monitor)
+            except BaseException as exc:      # the reference loses worker errors; we re-raise them
+                errors[thread_id] = exc
+
+        bounds = shard_bounds(len(sliced_audios_features), len(self.device_list))
+        for thread_id, (lo, hi) in enumerate(bounds):
+            args = (sliced_audios_features[lo:hi], thread_id, status_monitor if thread_id == 0 else None)
+            if len(bounds) == 1:
+                run(*args)
+            else:
+                t = threading.Thread(target=run, args=args)
+                t.start()
+                threads.append(t)
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[min(errors)]
+        out = []
+        for thread_id in sorted(texts_by_shard):
+            out += texts_by_shard[thread_id]
+        return out
+
+    def generate_segment_text_core(self, sliced_audios_features, batch_size, max_length, num_beams, top_k, top_p,
+                                   length_penalty, generated_texts_dict, thread_id, status_monitor=None):
+        raise NotImplementedError
+
+    def _decode_batches(self, engine, tokenizer, sliced, batch_size, max_length, num_beams, top_k, top_p,
+                        length_penalty, status_monitor):
+        if num_beams == 1 and top_k != 1:
+            raise NotImplementedError("sampling (num_beams=1 with top_k != 1) is not implemented; the reference's "
+                                      "default top_k=1 is the deterministic argmax")
+        prompt = tokenizer.convert_tokens_to_ids(PROMPT_TOKENS)
+        texts = []
+        n = len(sliced)
+        for pos in range(0, n, batch_size):
+            batch = torch.stack([item[2].to(engine.device) for item in sliced[pos:pos + batch_size]])
+            tokens, lengths = engine.generate(batch, prompt, tokenizer.eos_token_id, tokenizer.pad_token_id,
+                                              max_length=max_length, num_beams=num_beams, length_penalty=length_penalty,
+                                              suppress_tokens=self.suppress_tokens,
+                                              begin_suppress_tokens=self.begin_suppress_tokens)
+            tokens, lengths = tokens.cpu().numpy(), lengths.cpu().numpy()
+            texts += tokenizer.batch_decode([row[:ln] for row, ln in zip(tokens, lengths)], skip_special_tokens=False)
+            if status_monitor is not None:
+                status_monitor["progress"] = int(100 * min(1, (pos + batch_size) / n))
+        return texts
+
+    # ---- text -> segments (reference model.py:191-394) -------------------------------------------
+    def extract_segments(self, text, spec_time_step):
+        return postprocess.extract_segments(text, spec_time_step, self.cluster_codebook, self.segment_matcher)
+
+    def parse_generation(self, generated_text_list, sliced_audios_features, min_segment_length, audio_duration,
+                         spec_time_step, num_trials, eps, time_per_frame_for_voting, consolidation_method):
+        return postprocess.parse_generation(generated_text_list, sliced_audios_features, self.cluster_codebook,
+                                            min_segment_length, audio_duration, spec_time_step, num_trials, eps,
+                                            time_per_frame_for_voting, consolidation_method, self.precision_bits,
+                                            self.segment_matcher)
+
+    def custom_distance(self, segment1, segment2):
+        return postprocess.custom_distance(segment1, segment2)
+
+    def consolidate_trials_by_clustering(self, trials, eps, min_samples):
+        return postprocess.consolidate_by_clustering(trials, eps, min_samples)
+
+    def consolidate_trials_by_voting(self, trials, time_per_frame_for_voting):
+        return postprocess.consolidate_by_voting(trials, time_per_frame_for_voting, self.cluster_codebook)
+
+    # ---- the public entry point (reference model.py:397-470) -------------------------------------
+    @torch.no_grad()
+    def segment(self, audio, sr, min_frequency=None, spec_time_step=None, min_segment_length=None, eps=None,
+                time_per_frame_for_voting=None, consolidation_method="clustering", max_length=448, batch_size=4,
+                num_trials=1, num_beams=4, top_k=1, top_p=1.0, length_penalty=1.0, status_monitor=None):
+        defaults = self.default_segmentation_config
+        if min_frequency is None:
+            min_frequency = defaults.get("min_frequency", 0)
+        if spec_time_step is None:
+            spec_time_step = defaults.get("spec_time_step", 0.0025)
+        if min_segment_length is None:
+            min_segment_length = spec_time_step * RATIO_DECODING_TIME_STEP_TO_SPEC_TIME_STEP
+        if eps is None:
+            eps = spec_time_step * RATIO_DECODING_TIME_STEP_TO_SPEC_TIME_STEP * 4
+        if time_per_frame_for_voting is None:
+            time_per_frame_for_voting = spec_time_step
+        sliced = self.get_sliced_audios_features(audio, sr, min_frequency, spec_time_step, num_trials)
+        texts = self.generate_segment_text(sliced, batch_size, max_length, num_beams, top_k, top_p, length_penalty,
+                                           status_monitor)
+        prediction = self.parse_generation(texts, sliced, min_segment_length, len(audio) / sr, spec_time_step,
+                                           num_trials, eps, time_per_frame_for_voting, consolidation_method)
+        prediction = postprocess.correct_fft_blur(prediction, get_n_fft_given_sr(sr), sr)
+        return postprocess.drop_consecutive_duplicates(prediction)
+
+    # ---- scoring helpers (reference model.py:474-569) --------------------------------------------
+    def segment_score(self, prediction, label, target_cluster=None, tolerance=None):
+        if tolerance is None:
+            tolerance = self.default_segmentation_config.get("spec_time_step", 0.0025) * 4
+        return scoring.segment_score(prediction, label, target_cluster, tolerance)
+
+    def frame_score(self, prediction, label, target_cluster=None, time_per_frame_for_scoring=None):
+        if time_per_frame_for_scoring is None:
+            time_per_frame_for_scoring = min(0.001, self.default_segmentation_config.get("spec_time_step", 0.0025))
+        return scoring.frame_score(prediction, label, target_cluster, time_per_frame_for_scoring)
+
+    # ---- shared construction helpers ---------------------------------------------------------------
+    def _adopt_config(self, hf_config):
+        self.total_spec_columns = hf_config["total_spec_columns"]
+        self.cluster_codebook = hf_config["cluster_codebook"]
+        self.inverse_cluster_codebook = {cid: name for name, cid in self.cluster_codebook.items()}
+        if "default_segmentation_config" in hf_config:
+            self.default_segmentation_config.update(hf_config["default_segmentation_config"])
+
+
+def _resolve_devices(device, device_ids):
+    if device is None:
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+    if str(device).startswith("cpu"):
+        raise _lib.WsegError("whisperseg_amd has no CPU execution path: an MI355X (gfx950) device is required")
+    _lib.load(require_device=True)
+    return [torch.device("cuda", int(i)) for i in device_ids]
+
+
+class WhisperSegmenter(SegmenterBase):
+    """reference model.py:625-676: one model replica (+ tokenizer) per entry of device_ids."""
+
+    def __init__(self, model_path, device=None, device_ids=[0, ], dtype=None):
+        super().__init__()
+        self.device_list = _resolve_devices(device, device_ids)
+        model_dir = resolve_model_dir(model_path)
+        dtype = dtype or os.environ.get("WHISPERSEG_AMD_DTYPE", "bf16")
+        self.model_list = [Engine.from_pretrained(model_dir, device=dev, dtype=dtype) for dev in self.device_list]
+        self.tokenizer_list = [WhisperSegTokenizer.from_pretrained(model_dir, language="english") for _ in self.device_list]
+        hf_config = _read_json(os.path.join(model_dir, "config.json"))
+        self._adopt_config(hf_config)
+        self.suppress_tokens, self.begin_suppress_tokens = load_generation_settings(model_dir, hf_config["vocab_size"])
+
+    def generate_segment_text_core(self, sliced_audios_features, batch_size, max_length, num_beams, top_k, top_p,
+                                   length_penalty, generated_texts_dict, thread_id, status_monitor=None):
+        generated_texts_dict[thread_id] = self._decode_batches(
+            self.model_list[thread_id], self.tokenizer_list[thread_id], sliced_audios_features, batch_size, max_length,
+            num_beams, top_k, top_p, length_penalty, status_monitor)
+
+
+class WhisperSegmenterFast(WhisperSegmenter):
+    """reference model.py:678-746 is the CTranslate2 backend.  Here the bf16 MFMA engine *is* the fast
+    path, so this is WhisperSegmenter pinned to bf16.  A CTranslate2-converted directory (binary
+    `model.bin` + `hf_model/` without HF weights) cannot be read and raises, which makes
+    `scripts/segment.py`'s try-Fast-then-fallback idiom (reference scripts/segment.py:34-37) behave as
+    it does upstream when ctranslate2 is missing."""
+
+    def __init__(self, model_path, device=None, device_ids=[0, ]):
+        model_dir = resolve_model_dir(model_path)
+        if not any(os.path.exists(os.path.join(model_dir, n)) for n in ("model.safetensors", "pytorch_model.bin")):
+            raise FileNotFoundError(f"{model_dir} holds no HF weights (CTranslate2 model.bin is not supported)")
+        super().__init__(model_path, device=device, device_ids=device_ids, dtype="bf16")
+
+
+class WhisperSegmenterForEval(SegmenterBase):
+    """reference model.py:572-622: single device, optionally built from in-memory objects.
+
+    `model` may be an `Engine`, or any object exposing `.state_dict()` and `.config` in HF layout
+    (e.g. the HF model the reference's train.py hands over, train.py:134) — its weights are converted."""
+
+    def __init__(self, model_path=None, device=None, model=None, tokenizer=None, dtype=None):
+        super().__init__()
+        dtype = dtype or os.environ.get("WHISPERSEG_AMD_DTYPE", "bf16")
+        if model_path is not None:
+            self.device_list = _resolve_devices(device, [0]) if device is None or str(device) in ("cuda", "cpu") \
+                else _resolve_devices("cuda", [torch.device(device).index or 0])
+            model_dir = resolve_model_dir(model_path)
+            self.model = Engine.from_pretrained(model_dir, device=self.device_list[0], dtype=dtype)
+            self.tokenizer = WhisperSegTokenizer.from_pretrained(model_dir, language="english")
+            hf_config = _read_json(os.path.join(model_dir, "config.json"))
+            self.suppress_tokens, self.begin_suppress_tokens = load_generation_settings(model_dir, hf_config["vocab_size"])
+        else:
+            model = getattr(model, "module", model)
+            if isinstance(model, Engine):
+                self.model, hf_config = model, getattr(model, "hf_config", None)
+                if hf_config is None:
+                    raise ValueError("Engine passed as model= must carry .hf_config (total_spec_columns, cluster_codebook)")
+            else:
+                hf_config = model.config if isinstance(model.config, dict) else model.config.to_dict()
+                dev = device if device is not None else "cuda:0"
+                self.model = Engine.from_state_dict({k: v.detach() for k, v in model.state_dict().items()}, hf_config,
+                                                    device=dev, dtype=dtype)
+                gen = getattr(model, "generation_config", None)
+                if gen is not None:
+                    self.suppress_tokens = list(getattr(gen, "suppress_tokens", None) or [])
+                    self.begin_suppress_tokens = list(getattr(gen, "begin_suppress_tokens", None) or [])
+            self.device_list = [self.model.device]
+            self.tokenizer = tokenizer
+        self.device = self.device_list[0]
+        self.hf_config = hf_config
+        self._adopt_config(hf_config)
+
+    def update_cluster_codebook(self, cluster_codebook):
+        self.hf_config["cluster_codebook"] = cluster_codebook
+        self.cluster_codebook = cluster_codebook
+        self.inverse_cluster_codebook = {cid: name for name, cid in cluster_codebook.items()}
+
+    def generate_segment_text(self, sliced_audios_features, batch_size, max_length, num_beams, top_k=1, top_p=1.0,
+                              length_penalty=1.0, status_monitor=None):
+        return self._decode_batches(self.model, self.tokenizer, sliced_audios_features, batch_size, max_length,
+                                    num_beams, top_k, top_p, length_penalty, status_monitor)
