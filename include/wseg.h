@@ -149,6 +149,13 @@ int wseg_debug_first_logits(wseg_model* m, void* workspace, float* out, int32_t 
  * on the call's stream: [0]=encoder, [1]=cross-K/V, [2]=decode loop, [3]=number of decode steps. */
 int wseg_last_timing(const wseg_model* m, float out[4]);
 
+/* Live per-launch timing of the dominant kernel (the 128x128 bf16 MFMA GEMM) with HIP events recorded on
+ * the launching stream.  Between begin and end every launch of that kernel is bracketed by two events;
+ * end synchronises and returns the sums: algorithmic FLOPs (2*M*N*K of the real, un-padded problem),
+ * kernel milliseconds and the number of launches.  Process-wide; intended for bench.py's roofline leg. */
+int wseg_profile_begin(void);
+int wseg_profile_end(double* total_flops, double* total_ms, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,117 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise whisperseg_amd.dist (PCM broadcast, contiguous
+sharding, token all_gather, rank-order == window-order) with a deterministic stand-in for the GPU
+decode.  Property: the sharded result equals the unsharded one, because shards are independent."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+L = 16
+
+
+def fake_features(pcm, start, clip_len):
+    """Stand-in 'features' of a window: the window's mean absolute amplitude (depends on content + position)."""
+    lo, hi = max(start, 0), min(start + clip_len, pcm.numel())
+    return float(pcm[lo:hi].abs().sum()) if hi > lo else 0.0
+
+
+class FakeSegmenter:
+    """Mirrors the hooks segment_distributed uses; decode is a pure function of the window content."""
+
+    def __init__(self):
+        from whisperseg_amd.model import SegmenterBase
+        self.base = SegmenterBase()
+        self.base.total_spec_columns = 1000
+        self.base.cluster_codebook = {"a": 0, "b": 1, "c": 2}
+        self.default_segmentation_config = {}
+        self.device_list = [torch.device("cpu")]
+        self.parse_generation = self.base.parse_generation
+
+    def sliced_features_from_device_pcm(self, pcm, sr, min_frequency, spec_time_step, num_trials, rank=0, world=1):
+        from whisperseg_amd.windows import shard_bounds, window_table
+        table = window_table(int(pcm.numel()), sr, spec_time_step, num_trials, 1000)
+        bounds = shard_bounds(len(table), world)
+        lo, hi = bounds[rank] if rank < len(bounds) else (len(table), len(table))
+        clip_len = int(1000 * spec_time_step * sr)
+        shard = [(w.trial_id, w.offset_time, fake_features(pcm, w.start, clip_len), w.clip_seconds) for w in table[lo:hi]]
+        rows = [(w.trial_id, w.offset_time, None, w.clip_seconds) for w in table]
+        return {"table": rows, "shard": shard, "n_total": len(table), "lo": lo, "hi": hi}
+
+    def decode_shard_tokens(self, shard, **gen):
+        toks = torch.zeros((len(shard), L), dtype=torch.int32)
+        lens = torch.zeros((len(shard),), dtype=torch.int32)
+        for i, (_, _, f, _) in enumerate(shard):
+            k = int(f * 7) % 5 + 1                       # number of segments, content dependent
+            row = [9000]
+            for j in range(k):
+                on = (int(f * 13) + 40 * j) % 400
+                row += [on, 100 + (int(f) + j) % 3, on + 20 + j]
+            toks[i, : len(row)] = torch.tensor(row[:L], dtype=torch.int32)
+            lens[i] = min(len(row), L)
+        return toks, lens
+
+    def tokens_to_texts(self, tokens, lengths):
+        out = []
+        for row, ln in zip(tokens, lengths):
+            row = [int(t) for t in row[:ln]]
+            txt = "<|unknown|>"
+            for j in range(1, len(row) - 2, 3):
+                txt += "<|%d|>%d<|%d|>" % (row[j], row[j + 1] - 100, row[j + 2])
+            out.append(txt)
+        return out
+
+
+def make_audio():
+    rng = np.random.default_rng(5)
+    return (0.1 * rng.standard_normal(16000 * 47 + 321)).astype(np.float32)
+
+
+def worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from whisperseg_amd import dist as wd
+    wd.init_from_env(backend="gloo")
+    seg = FakeSegmenter()
+    audio = make_audio() if rank == 0 else None
+    res = [wd.segment_distributed(seg, audio, 16000, spec_time_step=0.01, num_trials=nt, batch_size=2) for nt in (1, 3)]
+    lo, hi = wd.my_shard(15, rank, world)
+    q.put((rank, res, (lo, hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_sharded_equals_unsharded_gloo():
+    from whisperseg_amd import dist as wd
+    seg = FakeSegmenter()
+    single = [wd.segment_distributed(seg, make_audio(), 16000, spec_time_step=0.01, num_trials=nt, batch_size=2) for nt in (1, 3)]
+    assert len(single[0]["onset"]) > 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res, _ in results:
+        assert res == single, rank
+    shards = sorted(r[2] for r in results)
+    assert shards == [(0, 8), (8, 15)]
+
+
+def test_gather_rows_single_process():
+    from whisperseg_amd import dist as wd
+    t = torch.arange(12, dtype=torch.int32).reshape(3, 4)
+    ln = torch.tensor([4, 2, 3], dtype=torch.int32)
+    a, b = wd.gather_rows(t, ln, 3)
+    assert torch.equal(a, t) and torch.equal(b, ln)
+    assert wd.my_shard(10, 3, 4) == (9, 10) and wd.my_shard(3, 5, 8) == (3, 3)

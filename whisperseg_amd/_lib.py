@@ -44,6 +44,8 @@ SYMBOLS = {
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "wseg_debug_first_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "wseg_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 4)]),
+    "wseg_profile_begin": (C.c_int, []),
+    "wseg_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
 _lib = None
@@ -57,6 +59,10 @@ def load(require_device=False):
     """dlopen libwseg.so and bind every symbol.  Raises if the library is absent."""
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64; it must be in the process BEFORE libwseg.so is dlopen'ed so that
+        # both resolve to ONE HIP runtime (two runtimes in one process cannot both own the device: the
+        # second one reports "No HIP GPUs are available").
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise WsegError(f"{LIB_PATH} not found: build it with `python -m whisperseg_amd.build` "
                             "(there is no CPU fallback for the MI355X path)")

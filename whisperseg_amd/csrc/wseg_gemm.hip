@@ -11,6 +11,7 @@
 // f32 path (exact-parity mode): plain VALU 64x64 tile, fmaf chain in k order.
 //
 // Both paths share one epilogue (epi_apply), also used by the split-K reduction kernel.
+#include <vector>
 #include "wseg_kernels.h"
 
 namespace wseg {
@@ -269,6 +270,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// Live profiler of the dominant kernel (wseg_profile_begin / wseg_profile_end)
+// ------------------------------------------------------------------------------------------------
+struct GemmProfiler {
+  bool on = false;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  std::vector<double> flops;
+  hipEvent_t get() {
+    if (used == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); }
+    return pool[used++];
+  }
+};
+static GemmProfiler g_prof;
+
+// ------------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------------
 template <int EPI>
@@ -279,8 +295,11 @@ static int launch_bf16(const GemmArgs& g, hipStream_t s) {
   if (g.M > 64) {
     if (g.N % 128) { set_error("gemm bf16: N %d %% 128 != 0", g.N); return WSEG_ERR_INVALID; }
     dim3 grid(g.N / 128, cdiv(g.M, 128), 1);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g_prof.on) { e0 = g_prof.get(); e1 = g_prof.get(); g_prof.flops.push_back(2.0 * g.M * g.N * g.K); (void)hipEventRecord(e0, s); }
     hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 2, 2, EPI, false>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
                        g.K, g.ep, (float*)nullptr, 0);
+    if (g_prof.on) (void)hipEventRecord(e1, s);
     WSEG_LAUNCH_CHECK();
     return WSEG_OK;
   }
@@ -346,3 +365,27 @@ int launch_gemm(int dtype, EpiKind epi, const GemmArgs& g, hipStream_t s) {
 }
 
 }  // namespace wseg
+
+extern "C" int wseg_profile_begin(void) {
+  using namespace wseg;
+  g_prof.on = true;
+  g_prof.used = 0;
+  g_prof.flops.clear();
+  return WSEG_OK;
+}
+
+extern "C" int wseg_profile_end(double* total_flops, double* total_ms, int64_t* launches) {
+  using namespace wseg;
+  if (!total_flops || !total_ms || !launches) { set_error("wseg_profile_end: null argument"); return WSEG_ERR_INVALID; }
+  g_prof.on = false;
+  double fl = 0.0, ms = 0.0;
+  for (size_t i = 0; i < g_prof.flops.size(); ++i) {
+    WSEG_HIP_CHECK(hipEventSynchronize(g_prof.pool[2 * i + 1]));
+    float t = 0.f;
+    WSEG_HIP_CHECK(hipEventElapsedTime(&t, g_prof.pool[2 * i], g_prof.pool[2 * i + 1]));
+    ms += t;
+    fl += g_prof.flops[i];
+  }
+  *total_flops = fl; *total_ms = ms; *launches = (int64_t)g_prof.flops.size();
+  return WSEG_OK;
+}

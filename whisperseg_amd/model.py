@@ -69,16 +69,27 @@ class SegmenterBase:
     def get_sliced_audios_features(self, audio, sr, min_frequency, spec_time_step, num_trials):
         """-> list of (trial_id, offset_time, features, clip_seconds); `features` is a float32 [80, 1000]
         DEVICE tensor (a view into one batch tensor) instead of a numpy array."""
+        device = self.device_list[0]
+        pcm = torch.as_tensor(np.ascontiguousarray(audio, dtype=np.float32)).to(device, non_blocking=True)
+        out = self.sliced_features_from_device_pcm(pcm, sr, min_frequency, spec_time_step, num_trials)
+        return out["shard"]
+
+    def sliced_features_from_device_pcm(self, pcm, sr, min_frequency, spec_time_step, num_trials, rank=0, world=1):
+        """Window table of a recording already resident in HBM + log-mel features of THIS rank's contiguous
+        shard of it (world == 1: everything).  Returns {"table": all rows without features, "shard": this
+        rank's rows with device features, "n_total", "lo", "hi"}."""
         cols = self.total_spec_columns
         chunk_length = max(30, int(np.ceil(spec_time_step * cols)))
-        device = self.device_list[0]
-        extractor = get_feature_extractor(sr, spec_time_step, min_frequency, chunk_length, cols, device)
-        table = window_table(len(audio), sr, spec_time_step, num_trials, cols)
+        extractor = get_feature_extractor(sr, spec_time_step, min_frequency, chunk_length, cols, pcm.device)
+        table = window_table(int(pcm.numel()), sr, spec_time_step, num_trials, cols)
+        bounds = shard_bounds(len(table), world)
+        lo, hi = bounds[rank] if rank < len(bounds) else (len(table), len(table))
         clip_len = int(cols * spec_time_step * sr)
-        pcm = torch.as_tensor(np.ascontiguousarray(audio, dtype=np.float32)).to(device, non_blocking=True)
-        starts = torch.tensor([w.start for w in table], dtype=torch.int64).to(device, non_blocking=True)
+        starts = torch.tensor([w.start for w in table[lo:hi]], dtype=torch.int64).to(pcm.device, non_blocking=True)
         feats = extractor.extract_windows(pcm, starts, clip_len)
-        return [(w.trial_id, w.offset_time, feats[i], w.clip_seconds) for i, w in enumerate(table)]
+        shard = [(w.trial_id, w.offset_time, feats[i], w.clip_seconds) for i, w in enumerate(table[lo:hi])]
+        rows = [(w.trial_id, w.offset_time, None, w.clip_seconds) for w in table]
+        return {"table": rows, "shard": shard, "n_total": len(table), "lo": lo, "hi": hi}
 
     # ---- device fan-out (reference model.py:169-189) ---------------------------------------------
     def generate_segment_text(self, sliced_audios_features, batch_size, max_length, num_beams, top_k=1, top_p=1.0,
@@ -114,25 +125,52 @@ class SegmenterBase:
                                    length_penalty, generated_texts_dict, thread_id, status_monitor=None):
         raise NotImplementedError
 
-    def _decode_batches(self, engine, tokenizer, sliced, batch_size, max_length, num_beams, top_k, top_p,
-                        length_penalty, status_monitor):
+    def _decode_token_batches(self, engine, tokenizer, sliced, batch_size, max_length, num_beams, top_k, top_p,
+                              length_penalty, status_monitor=None):
+        """-> list of (tokens int32 [b, L] device, lengths int32 [b] device), one entry per batch."""
         if num_beams == 1 and top_k != 1:
             raise NotImplementedError("sampling (num_beams=1 with top_k != 1) is not implemented; the reference's "
                                       "default top_k=1 is the deterministic argmax")
         prompt = tokenizer.convert_tokens_to_ids(PROMPT_TOKENS)
-        texts = []
+        out = []
         n = len(sliced)
         for pos in range(0, n, batch_size):
             batch = torch.stack([item[2].to(engine.device) for item in sliced[pos:pos + batch_size]])
-            tokens, lengths = engine.generate(batch, prompt, tokenizer.eos_token_id, tokenizer.pad_token_id,
-                                              max_length=max_length, num_beams=num_beams, length_penalty=length_penalty,
-                                              suppress_tokens=self.suppress_tokens,
-                                              begin_suppress_tokens=self.begin_suppress_tokens)
-            tokens, lengths = tokens.cpu().numpy(), lengths.cpu().numpy()
-            texts += tokenizer.batch_decode([row[:ln] for row, ln in zip(tokens, lengths)], skip_special_tokens=False)
+            out.append(engine.generate(batch, prompt, tokenizer.eos_token_id, tokenizer.pad_token_id,
+                                       max_length=max_length, num_beams=num_beams, length_penalty=length_penalty,
+                                       suppress_tokens=self.suppress_tokens,
+                                       begin_suppress_tokens=self.begin_suppress_tokens))
             if status_monitor is not None:
                 status_monitor["progress"] = int(100 * min(1, (pos + batch_size) / n))
+        return out
+
+    def _decode_batches(self, engine, tokenizer, sliced, batch_size, max_length, num_beams, top_k, top_p,
+                        length_penalty, status_monitor):
+        texts = []
+        for tokens, lengths in self._decode_token_batches(engine, tokenizer, sliced, batch_size, max_length, num_beams,
+                                                          top_k, top_p, length_penalty, status_monitor):
+            tokens, lengths = tokens.cpu().numpy(), lengths.cpu().numpy()
+            texts += tokenizer.batch_decode([row[:ln] for row, ln in zip(tokens, lengths)], skip_special_tokens=False)
         return texts
+
+    # ---- hooks used by whisperseg_amd.dist.segment_distributed (one process per GPU) ----------------
+    def _first_engine(self):
+        if hasattr(self, "model_list"):
+            return self.model_list[0], self.tokenizer_list[0]
+        return self.model, self.tokenizer
+
+    def decode_shard_tokens(self, shard, batch_size=4, max_length=448, num_beams=4, length_penalty=1.0):
+        engine, tokenizer = self._first_engine()
+        L = int(min(max_length, engine.geo["dec_positions"]))
+        parts = self._decode_token_batches(engine, tokenizer, shard, batch_size, max_length, num_beams, 1, 1.0, length_penalty)
+        if not parts:
+            return (torch.zeros((0, L), dtype=torch.int32, device=engine.device),
+                    torch.zeros((0,), dtype=torch.int32, device=engine.device))
+        return torch.cat([p[0] for p in parts], 0), torch.cat([p[1] for p in parts], 0)
+
+    def tokens_to_texts(self, tokens, lengths):
+        _, tokenizer = self._first_engine()
+        return tokenizer.batch_decode([row[:ln] for row, ln in zip(tokens, lengths)], skip_special_tokens=False)
 
     # ---- text -> segments (reference model.py:191-394) -------------------------------------------
     def extract_segments(self, text, spec_time_step):
