@@ -71,11 +71,17 @@ def cpu_baseline(args, sr, sts, win_len):
     a bounded sample of the same workload."""
     from oracle import frontend as OF
     from oracle import whisper_ref as OW
-    cores = os.cpu_count() or 1
+    # threads actually used: the affinity mask (not os.cpu_count(): a container may see far more CPUs than
+    # it can run on, and hundreds of OpenMP threads on 8-row decode GEMMs only spin), capped at 16.
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
     cfg = hf_config(args.model)
     rc = OW.RefConfig.from_hf_dict(cfg)
-    sd = OW.random_state_dict(rc, seed=0)
+    sd = OW.random_state_dict(rc, seed=0, fast=True)
     n = args.cpu_windows
     pcm = synth_pcm(n, win_len, sr, 1000)
     gp = OW.GenParams(prompt=PROMPT, eos_token_id=EOS, pad_token_id=EOS, max_length=3 + args.gen_tokens,

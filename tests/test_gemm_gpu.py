@@ -1,0 +1,40 @@
+"""libwseg GEMM (bf16 MFMA tiles incl. the split-K skinny family, and the f32 exact kernel) vs torch fp32."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # M, N, K
+    (500, 128, 128), (1500, 384, 128), (4000, 1280, 1280), (1000, 512, 256), (3, 384, 128), (32, 3840, 1280),
+    (48, 1280, 5120), (128, 1280, 1280), (200, 5120, 1280), (512, 1280, 5120), (20, 51968, 128), (257, 256, 64),
+]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("epi", [0, 1, 2])
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_gemm_matches_torch(gpu_lib, M, N, K, epi, dtype):
+    from whisperseg_amd import _lib
+    if dtype == "f32" and M * N * K > 3e9:
+        pytest.skip("f32 exact kernel is for small problems")
+    td = torch.bfloat16 if dtype == "bf16" else torch.float32
+    g = torch.Generator(device="cuda").manual_seed(M * 31 + N * 7 + K)
+    Mp = (M + 127) // 128 * 128
+    A = (torch.rand(Mp, K, device="cuda", generator=g) * 2 - 1).to(td)
+    W = ((torch.rand(N, K, device="cuda", generator=g) * 2 - 1) * K ** -0.5).to(td)      # asymmetric operands
+    bias = (torch.rand(N, device="cuda", generator=g) - 0.5).to(td)
+    res = (torch.rand(Mp, N, device="cuda", generator=g) - 0.5).to(td)
+    out = torch.full((Mp, N), float("nan"), device="cuda", dtype=td)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    _lib.check(gpu_lib.wseg_debug_gemm(1 if dtype == "bf16" else 0, epi, M, N, K, A.data_ptr(), W.data_ptr(), bias.data_ptr(),
+                                       res.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+    ref = A[:M].float() @ W.float().T + bias.float()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    if epi == 2:
+        ref = ref + res[:M].float()
+    got = out[:M].float()
+    assert torch.isfinite(got).all()
+    tol = 2e-2 if dtype == "bf16" else 2e-5          # bf16 output rounding (2^-8) dominates; f32 is accumulation order only
+    assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    assert torch.isnan(out[M:]).all() or M == Mp      # rows beyond M are never written

@@ -1,0 +1,44 @@
+"""GEMM tuning probe: TFLOP/s of libwseg's bf16 GEMM on the encoder / decoder shapes (random [-1,1) data).
+    python tools/gemm_bench.py [--windows 32]"""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from whisperseg_amd import _lib
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--windows", type=int, default=32)
+ap.add_argument("--iters", type=int, default=20)
+a = ap.parse_args()
+lib = _lib.load(require_device=True)
+d, f = 1280, 5120
+M = a.windows * 500
+shapes = [("qkv", M, 3 * d, d, 0), ("o-proj", M, d, d, 2), ("fc1", M, f, d, 1), ("fc2", M, d, f, 2), ("conv2", M, d, 3 * d, 1),
+          ("4096^3", 4096, 4096, 4096, 0), ("dec fc1 R=128", 128, f, d, 1), ("dec fc2 R=128", 128, d, f, 2), ("dec o R=128", 128, d, d, 2),
+          ("dec fc1 R=32", 32, f, d, 1), ("dec fc2 R=32", 32, d, f, 2), ("dec qkv R=32", 32, 3 * d, d, 0), ("lm head R=128", 128, 51968, d, 0)]
+ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+for name, m, n, k, epi in shapes:
+    mp = (m + 127) // 128 * 128
+    A = (torch.rand(mp, k, device="cuda") * 2 - 1).to(torch.bfloat16)
+    W = (torch.rand(n, k, device="cuda") * 2 - 1).to(torch.bfloat16)
+    bias = torch.rand(n, device="cuda").to(torch.bfloat16)
+    res = torch.rand(mp, n, device="cuda").to(torch.bfloat16)
+    out = torch.empty(mp, n, device="cuda", dtype=torch.bfloat16)
+    st = _lib.stream_ptr()
+
+    def run():
+        _lib.check(lib.wseg_debug_gemm(1, epi, m, n, k, A.data_ptr(), W.data_ptr(), bias.data_ptr(), res.data_ptr(), out.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), st))
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(a.iters):
+        run()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / a.iters * 1e3
+    ref = (A[:m].float() @ W.float().T + bias.float())
+    if epi == 1: ref = torch.nn.functional.gelu(ref)
+    if epi == 2: ref = ref + res[:m].float()
+    err = (out[:m].float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-9)
+    gb = (m * k + n * k + m * n * (2 if epi == 2 else 1)) * 2 / 1e9
+    print(f"{name:16s} M={m:6d} N={n:6d} K={k:5d}: {us:8.1f} us  {2*m*n*k/us/1e6:7.1f} TFLOP/s  {gb/us*1e6/1e3:6.2f} TB/s  relerr {err:.1e}", flush=True)

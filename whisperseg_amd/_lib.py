@@ -44,6 +44,8 @@ SYMBOLS = {
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "wseg_debug_first_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "wseg_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 4)]),
+    "wseg_debug_gemm": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "wseg_profile_begin": (C.c_int, []),
     "wseg_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

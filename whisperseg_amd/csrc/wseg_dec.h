@@ -45,7 +45,8 @@ int launch_dec_self_attn(int dtype, const DecodeState& st, const void* q, const 
 int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const void* ck, const void* cv, void* out,
                           int H, int Tk, int d, hipStream_t s);
 // log-softmax + suppress + running score -> top-2nb per row (beam) / argmax of the processed logits (greedy)
-int launch_row_topk(const DecodeState& st, const float* logits, hipStream_t s);
+// scratch: part_val/part_idx [R][16][16], part_stat [R][16][2]
+int launch_row_topk(const DecodeState& st, const float* logits, float* part_val, int* part_idx, float* part_stat, hipStream_t s);
 int launch_beam_step(const DecodeState& st, hipStream_t s);
 int launch_greedy_step(const DecodeState& st, hipStream_t s);
 int launch_finalize(const DecodeState& st, int* out_tokens, int* out_lengths, hipStream_t s);

@@ -115,34 +115,67 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
 
 // ------------------------------------------------------------------------------------------------
 // Cross-attention, one workgroup per (window, head); all beams of the window in one pass over K and V.
+// HBM-bound (128 KiB of K/V per workgroup).  8 lanes cover one 128-byte K/V row (16 B each), so a wave
+// reads 8 consecutive rows = 1 KiB fully coalesced per instruction and 4 rows are in flight per lane.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T> __device__ __forceinline__ void load8(const T* p, float v[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float v[8]) {
+  const float4 a = ((const float4*)p)[0], b = ((const float4*)p)[1];
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float v[8]) {
+  const uint4 t = *(const uint4*)p;
+  const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+}
+
+template <typename T, int NB>
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(DecodeState st, const T* __restrict__ q, const T* __restrict__ ck,
                                                              const T* __restrict__ cv, T* __restrict__ out, int H, int Tk, int d) {
-  __shared__ float sq[MAX_BEAMS][64];
-  __shared__ float sc[MAX_BEAMS][512];
-  __shared__ float red[4][MAX_BEAMS][64];
-  __shared__ float sinv[MAX_BEAMS];
+  __shared__ float sc[NB][512];
+  __shared__ float red[4][NB][64];
+  __shared__ float sinv[NB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = blockIdx.x / H, h = blockIdx.x - w * H;
   const int nb = st.nb;
-  for (int i = tid; i < nb * 64; i += 256) {
-    const int j = i >> 6, e = i & 63;
-    sq[j][e] = El<T>::ld(q + (size_t)(w * nb + j) * d + h * 64 + e);
-  }
-  __syncthreads();
+  const int sub = lane & 7, rowl = lane >> 3;          // 8 lanes per row, 8 rows per wave-instruction
   const T* Kb = ck + ((size_t)w * H + h) * Tk * 64;
   const T* Vb = cv + ((size_t)w * H + h) * Tk * 64;
-  for (int t = tid; t < Tk; t += 256) {
-    float kv[64];
-    load_row64<T>(Kb + (size_t)t * 64, kv);
+  // this lane's 8-dim slice of every beam's (pre-scaled) query
+  float qv[NB][8];
 #pragma unroll
-    for (int j = 0; j < MAX_BEAMS; ++j) {
-      if (j < nb) {
+  for (int j = 0; j < NB; ++j) {
+    if (j < nb) load8<T>(q + (size_t)(w * nb + j) * d + h * 64 + sub * 8, qv[j]);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qv[j][e] = 0.f;
+    }
+  }
+  // scores: rows t = it*32 + wave*8 + rowl
+  for (int t0 = 0; t0 < Tk; t0 += 128) {
+    float kv[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * 32 + wave * 8 + rowl;
+      if (t < Tk) load8<T>(Kb + (size_t)t * 64 + sub * 8, kv[u]);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kv[u][e] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * 32 + wave * 8 + rowl;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
         float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 64; ++e) s = fmaf(sq[j][e], kv[e], s);
-        sc[j][t] = s;
+        for (int e = 0; e < 8; ++e) s = fmaf(qv[j][e], kv[u][e], s);
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (sub == 0 && t < Tk && j < nb) sc[j][t] = s;
       }
     }
   }
@@ -157,19 +190,52 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(DecodeState st, con
     if (lane == 0) sinv[j] = 1.0f / sum;
   }
   __syncthreads();
-  float acc[MAX_BEAMS];
+  float acc[NB][8];
 #pragma unroll
-  for (int j = 0; j < MAX_BEAMS; ++j) acc[j] = 0.f;
-  const int per = (Tk + 3) / 4, t0 = wave * per, t1 = min(Tk, t0 + per);
-  for (int t = t0; t < t1; ++t) {
-    const float v = El<T>::ld(Vb + (size_t)t * 64 + lane);
+  for (int j = 0; j < NB; ++j)
 #pragma unroll
-    for (int j = 0; j < MAX_BEAMS; ++j)
-      if (j < nb) acc[j] = fmaf(sc[j][t], v, acc[j]);
+    for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+  for (int t0 = 0; t0 < Tk; t0 += 128) {
+    float vv[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * 32 + wave * 8 + rowl;
+      if (t < Tk) load8<T>(Vb + (size_t)t * 64 + sub * 8, vv[u]);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vv[u][e] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * 32 + wave * 8 + rowl;
+      if (t < Tk) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const float p = j < nb ? sc[j][t] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[j][e] = fmaf(p, vv[u][e], acc[j][e]);
+        }
+      }
+    }
   }
+  // reduce over the 8 row-lanes of the wave (lanes with equal `sub`), then over the 4 waves through LDS
 #pragma unroll
-  for (int j = 0; j < MAX_BEAMS; ++j)
-    if (j < nb) red[wave][j][lane] = acc[j];
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = acc[j][e];
+      a += __shfl_xor(a, 8, 64);
+      a += __shfl_xor(a, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      acc[j][e] = a;
+    }
+  if (rowl == 0) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[wave][j][sub * 8 + e] = acc[j][e];
+  }
   __syncthreads();
   for (int i = tid; i < nb * 64; i += 256) {
     const int j = i >> 6, e = i & 63;
@@ -183,50 +249,42 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(DecodeState st, con
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool better(float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); }
 
+// Stage 1: grid (NSEG, R).  Each workgroup scans one slice of a row's logits: slice max, slice
+// sum(exp(x - slice max)) and the slice's top-KC of the processed logits (suppressed ids -> -inf).
+// log_softmax is a per-row shift, so ranking raw logits == ranking log-probs; the shift is applied to the
+// few surviving candidates in stage 2.
 template <int KC>
-__global__ __launch_bounds__(256) void row_topk_kernel(DecodeState st, const float* __restrict__ logits) {
+__global__ __launch_bounds__(256) void row_topk_partial_kernel(DecodeState st, const float* __restrict__ logits, int nseg,
+                                                               float* __restrict__ part_val, int* __restrict__ part_idx,
+                                                               float* __restrict__ part_stat) {
   __shared__ float s_red[4];
   __shared__ float s_bv[4];
   __shared__ int s_bi[4];
   __shared__ int s_bt[4];
-  __shared__ float s_bcast[2];
   __shared__ int s_winner;
-  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int seg = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int V = st.V;
+  const int per = (V + nseg - 1) / nseg;
+  const int lo = seg * per, hi = min(V, lo + per);
   const float* x = logits + (size_t)r * st.ldv;
-  const bool greedy = st.nb == 1;
-  const int Kc = greedy ? 1 : 2 * st.nb;
   const int cur_len = *st.pos + 1;
-  const unsigned char begin_bit = (cur_len == st.P) ? 2 : 0;
-
-  float shift = 0.f, lse = 0.f, base = 0.f;
-  if (!greedy) {
-    float mx = -3.0e38f;
-    for (int i = tid; i < V; i += 256) mx = fmaxf(mx, x[i]);
-    mx = wave_max(mx);
-    if (lane == 0) s_red[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-    __syncthreads();
-    float sum = 0.f;
-    for (int i = tid; i < V; i += 256) sum += expf(x[i] - mx);
-    sum = wave_sum(sum);
-    if (lane == 0) s_red[wave] = sum;
-    __syncthreads();
-    sum = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-    shift = mx;
-    lse = logf(sum);
-    base = st.run_score[r];
-  }
+  const unsigned char bits = 1 | ((cur_len == st.P) ? 2 : 0);
+  float mx = -3.0e38f;
+  for (int i = lo + tid; i < hi; i += 256) mx = fmaxf(mx, x[i]);
+  mx = wave_max(mx);
+  if (lane == 0) s_red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  __syncthreads();
+  float sum = 0.f;
   float tv[KC];
   int ti[KC];
 #pragma unroll
   for (int j = 0; j < KC; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
-  for (int i = tid; i < V; i += 256) {
+  for (int i = lo + tid; i < hi; i += 256) {
     float v = x[i];
-    if (!greedy) v = ((v - shift) - lse);
-    if (st.sup_mask[i] & (1 | begin_bit)) v = -INFINITY;
-    if (!greedy) v = v + base;
+    sum += expf(v - mx);
+    if (st.sup_mask[i] & bits) v = -INFINITY;
     if (better(v, i, tv[KC - 1], ti[KC - 1])) {
 #pragma unroll
       for (int j = KC - 1; j >= 0; --j) {
@@ -237,8 +295,14 @@ __global__ __launch_bounds__(256) void row_topk_kernel(DecodeState st, const flo
       }
     }
   }
-  // block merge: Kc rounds of arg-best over the per-thread heads
-  for (int k = 0; k < Kc; ++k) {
+  sum = wave_sum(sum);
+  if (lane == 0) s_red[wave] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    part_stat[((size_t)r * nseg + seg) * 2 + 0] = mx;
+    part_stat[((size_t)r * nseg + seg) * 2 + 1] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  }
+  for (int k = 0; k < KC; ++k) {
     float bv = tv[0];
     int bi = ti[0], bt = tid;
 #pragma unroll
@@ -252,8 +316,8 @@ __global__ __launch_bounds__(256) void row_topk_kernel(DecodeState st, const flo
     if (tid == 0) {
       float fv = s_bv[0]; int fi = s_bi[0], ft = s_bt[0];
       for (int q = 1; q < 4; ++q) if (better(s_bv[q], s_bi[q], fv, fi)) { fv = s_bv[q]; fi = s_bi[q]; ft = s_bt[q]; }
-      st.cand_val[(size_t)r * Kc + k] = fv;
-      st.cand_tok[(size_t)r * Kc + k] = fi;
+      part_val[((size_t)r * nseg + seg) * KC + k] = fv;
+      part_idx[((size_t)r * nseg + seg) * KC + k] = fi;
       s_winner = ft;
     }
     __syncthreads();
@@ -263,6 +327,55 @@ __global__ __launch_bounds__(256) void row_topk_kernel(DecodeState st, const flo
       tv[KC - 1] = -INFINITY; ti[KC - 1] = 0x7fffffff;
     }
     __syncthreads();
+  }
+}
+
+// Stage 2: one wave per row merges the slices: global max / log-sum-exp, then the row's top-Kc candidates as
+// log_softmax(x) (+ -inf for suppressed ids) + running beam score — HF generation/utils.py:3374-3395.
+template <int KC>
+__global__ __launch_bounds__(64) void row_topk_merge_kernel(DecodeState st, int nseg, const float* __restrict__ part_val,
+                                                            const int* __restrict__ part_idx, const float* __restrict__ part_stat) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const bool greedy = st.nb == 1;
+  const int Kc = greedy ? 1 : 2 * st.nb;
+  float mx = -3.0e38f;
+  for (int s = lane; s < nseg; s += 64) mx = fmaxf(mx, part_stat[((size_t)r * nseg + s) * 2]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int s = lane; s < nseg; s += 64) sum += part_stat[((size_t)r * nseg + s) * 2 + 1] * expf(part_stat[((size_t)r * nseg + s) * 2] - mx);
+  sum = wave_sum(sum);
+  const float lse = logf(sum);
+  const float base = greedy ? 0.f : st.run_score[r];
+  const int n = nseg * KC;                 // <= 16 * 16 = 256 candidates: 4 per lane
+  float cv[4];
+  int ci[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = lane + u * 64;
+    cv[u] = c < n ? part_val[(size_t)r * n + c] : -INFINITY;
+    ci[u] = c < n ? part_idx[(size_t)r * n + c] : 0x7fffffff;
+  }
+  for (int k = 0; k < Kc; ++k) {
+    float bv = cv[0]; int bi = ci[0], bu = 0;
+#pragma unroll
+    for (int u = 1; u < 4; ++u) if (better(cv[u], ci[u], bv, bi)) { bv = cv[u]; bi = ci[u]; bu = u; }
+    float wv = bv; int wi = bi, wl = lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(wv, o, 64);
+      const int oi = __shfl_xor(wi, o, 64), ol = __shfl_xor(wl, o, 64);
+      if (better(ov, oi, wv, wi)) { wv = ov; wi = oi; wl = ol; }
+    }
+    if (lane == wl) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (u == bu) { cv[u] = -INFINITY; ci[u] = 0x7fffffff; }
+    }
+    if (lane == 0) {
+      float v = wv;
+      if (!greedy) v = ((wv - mx) - lse) + base;     // -inf stays -inf
+      st.cand_val[(size_t)r * Kc + k] = v;
+      st.cand_tok[(size_t)r * Kc + k] = wi;
+    }
   }
 }
 
@@ -436,20 +549,37 @@ int launch_dec_self_attn(int dtype, const DecodeState& st, const void* q, const 
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
+template <typename T>
+static void launch_cross_t(const DecodeState& st, const T* q, const T* ck, const T* cv, T* out, int H, int Tk, int d, hipStream_t s) {
+  dim3 grid(st.W * H), block(256);
+  if (st.nb <= 1) hipLaunchKernelGGL((dec_cross_attn_kernel<T, 1>), grid, block, 0, s, st, q, ck, cv, out, H, Tk, d);
+  else if (st.nb <= 2) hipLaunchKernelGGL((dec_cross_attn_kernel<T, 2>), grid, block, 0, s, st, q, ck, cv, out, H, Tk, d);
+  else if (st.nb <= 4) hipLaunchKernelGGL((dec_cross_attn_kernel<T, 4>), grid, block, 0, s, st, q, ck, cv, out, H, Tk, d);
+  else hipLaunchKernelGGL((dec_cross_attn_kernel<T, 8>), grid, block, 0, s, st, q, ck, cv, out, H, Tk, d);
+}
 int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const void* ck, const void* cv, void* out, int H, int Tk, int d, hipStream_t s) {
   if (Tk > 512) { set_error("cross-attention: %d encoder positions > 512", Tk); return WSEG_ERR_INVALID; }
-  if (dtype == WSEG_BF16) hipLaunchKernelGGL((dec_cross_attn_kernel<bf16_t>), dim3(st.W * H), dim3(256), 0, s, st, (const bf16_t*)q, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)out, H, Tk, d);
-  else hipLaunchKernelGGL((dec_cross_attn_kernel<float>), dim3(st.W * H), dim3(256), 0, s, st, (const float*)q, (const float*)ck, (const float*)cv, (float*)out, H, Tk, d);
+  if (dtype == WSEG_BF16) launch_cross_t<bf16_t>(st, (const bf16_t*)q, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)out, H, Tk, d, s);
+  else launch_cross_t<float>(st, (const float*)q, (const float*)ck, (const float*)cv, (float*)out, H, Tk, d, s);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
-int launch_row_topk(const DecodeState& st, const float* logits, hipStream_t s) {
-  const int R = st.W * st.nb;
+int row_topk_segments(int R) {
+  int nseg = (512 + R - 1) / R;
+  return nseg < 1 ? 1 : (nseg > 16 ? 16 : nseg);
+}
+template <int KC>
+static void launch_topk_t(const DecodeState& st, const float* logits, float* pv, int* pi, float* ps, hipStream_t s) {
+  const int R = st.W * st.nb, nseg = row_topk_segments(R);
+  hipLaunchKernelGGL((row_topk_partial_kernel<KC>), dim3(nseg, R), dim3(256), 0, s, st, logits, nseg, pv, pi, ps);
+  hipLaunchKernelGGL((row_topk_merge_kernel<KC>), dim3(R), dim3(64), 0, s, st, nseg, pv, pi, ps);
+}
+int launch_row_topk(const DecodeState& st, const float* logits, float* part_val, int* part_idx, float* part_stat, hipStream_t s) {
   const int Kc = st.nb == 1 ? 1 : 2 * st.nb;
-  if (Kc == 1) hipLaunchKernelGGL((row_topk_kernel<1>), dim3(R), dim3(256), 0, s, st, logits);
-  else if (Kc <= 4) hipLaunchKernelGGL((row_topk_kernel<4>), dim3(R), dim3(256), 0, s, st, logits);
-  else if (Kc <= 8) hipLaunchKernelGGL((row_topk_kernel<8>), dim3(R), dim3(256), 0, s, st, logits);
-  else hipLaunchKernelGGL((row_topk_kernel<16>), dim3(R), dim3(256), 0, s, st, logits);
+  if (Kc == 1) launch_topk_t<1>(st, logits, part_val, part_idx, part_stat, s);
+  else if (Kc <= 4) launch_topk_t<4>(st, logits, part_val, part_idx, part_stat, s);
+  else if (Kc <= 8) launch_topk_t<8>(st, logits, part_val, part_idx, part_stat, s);
+  else launch_topk_t<16>(st, logits, part_val, part_idx, part_stat, s);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }

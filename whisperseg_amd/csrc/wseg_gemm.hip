@@ -11,6 +11,7 @@
 // f32 path (exact-parity mode): plain VALU 64x64 tile, fmaf chain in k order.
 //
 // Both paths share one epilogue (epi_apply), also used by the split-K reduction kernel.
+#include <stdlib.h>
 #include <vector>
 #include "wseg_kernels.h"
 
@@ -120,7 +121,7 @@ template <int BM, int BN, int WM, int WN, int EPI, bool SPLIT>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, int lda,
                                                         const bf16_t* __restrict__ W, int ldw,
                                                         int M, int N, int k_len, EpiParams ep,
-                                                        float* __restrict__ part, int m_pad) {
+                                                        float* __restrict__ part, int m_pad, int ntm) {
   constexpr int BK = 64;
   constexpr int TM = BM / WM, TN = BN / WN;      // wave tile
   constexpr int MI = TM / 16, NI = TN / 16;      // 16x16 MFMA tiles per wave
@@ -133,7 +134,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  if (ntm > 0) {
+    // 1-D grid, XCD-aware: workgroup b runs on XCD b % 8 (observed dispatch order, speed only), so give
+    // every XCD a contiguous run of tiles (bijective remap), ordered m-fastest inside groups of 8 m-tiles:
+    // neighbours in time and on the same L2 share the weight tile and 8 activation tiles.
+    const int nblk = gridDim.x, bid = blockIdx.x, ntn = N / BN;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    constexpr int GM = 8;
+    const int per_group = GM * ntn, grp = swz / per_group, rem = swz - grp * per_group;
+    const int gm = min(GM, ntm - grp * GM);
+    m0 = (grp * GM + rem % gm) * BM;
+    n0 = (rem / gm) * BN;
+  }
   const int kbeg = blockIdx.z * k_len;
   const int nk = k_len / BK;
 
@@ -292,43 +306,51 @@ static int launch_bf16(const GemmArgs& g, hipStream_t s) {
   const bf16_t* A = (const bf16_t*)g.A;
   const bf16_t* W = (const bf16_t*)g.W;
   if (g.K % 64 || g.N % 64) { set_error("gemm bf16: K %d / N %d not tile multiples", g.K, g.N); return WSEG_ERR_INVALID; }
-  if (g.M > 64) {
-    if (g.N % 128) { set_error("gemm bf16: N %d %% 128 != 0", g.N); return WSEG_ERR_INVALID; }
-    dim3 grid(g.N / 128, cdiv(g.M, 128), 1);
+  const long big_blocks = (long)cdiv(g.M, 128) * (g.N / 128);
+  if (g.M > 128 && g.N % 128 == 0 && big_blocks >= 128) {
+    static const bool no_swz = getenv("WSEG_NO_XCD_SWIZZLE") != nullptr;
+    const int ntm = cdiv(g.M, 128);
+    dim3 grid(g.N / 128, ntm, 1);
+    if (!no_swz) grid = dim3((g.N / 128) * ntm, 1, 1);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g_prof.on) { e0 = g_prof.get(); e1 = g_prof.get(); g_prof.flops.push_back(2.0 * g.M * g.N * g.K); (void)hipEventRecord(e0, s); }
     hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 2, 2, EPI, false>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
-                       g.K, g.ep, (float*)nullptr, 0);
+                       g.K, g.ep, (float*)nullptr, 0, no_swz ? 0 : ntm);
     if (g_prof.on) (void)hipEventRecord(e1, s);
     WSEG_LAUNCH_CHECK();
     return WSEG_OK;
   }
-  // skinny: decoder step.  Choose split-K so that ~256+ workgroups stream the weight matrix.
-  const int bm = g.M <= 32 ? 32 : 64;
-  const int blocks = g.N / 64;
+  // skinny family (decoder steps, small encoders): BN = 64, BM in {32, 64, 128}; split K across workgroups
+  // until ~256+ of them stream the weight matrix.  Partials are reduced (in a fixed order) by a second kernel
+  // that applies the epilogue.
+  const int bm = g.M <= 32 ? 32 : (g.M <= 64 ? 64 : 128);
+  const int mt = cdiv(g.M, bm), m_pad = mt * bm;
+  const int blocks = (g.N / 64) * mt;
   int splits = 1;
   if (g.splitk_ws) {
-    while (blocks * splits < 256 && (g.K / (splits * 2)) % 64 == 0 && g.K / (splits * 2) >= 128 && splits < 16) splits *= 2;
-    const size_t need = (size_t)splits * bm * g.N * sizeof(float);
-    if (splits > 1 && need > g.splitk_ws_bytes) splits = 1;
+    while (blocks * splits < 256 && (g.K / (splits * 2)) % 64 == 0 && g.K / (splits * 2) >= 128 && splits < 16 &&
+           (size_t)(splits * 2) * m_pad * g.N * sizeof(float) <= g.splitk_ws_bytes)
+      splits *= 2;
   }
-  dim3 grid(blocks, 1, splits);
+  dim3 grid(g.N / 64, mt, splits);
   const int k_len = g.K / splits;
+#define WSEG_SKINNY(BM_, WM_, WN_, SPLIT_)                                                                              \
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM_, 64, WM_, WN_, EPI, SPLIT_>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, \
+                     k_len, g.ep, SPLIT_ ? g.splitk_ws : (float*)nullptr, m_pad, 0)
   if (splits == 1) {
-    if (bm == 32)
-      hipLaunchKernelGGL((gemm_bf16_kernel<32, 64, 1, 4, EPI, false>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, k_len, g.ep, (float*)nullptr, 0);
-    else
-      hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 1, 4, EPI, false>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, k_len, g.ep, (float*)nullptr, 0);
+    if (bm == 32) WSEG_SKINNY(32, 1, 4, false);
+    else if (bm == 64) WSEG_SKINNY(64, 1, 4, false);
+    else WSEG_SKINNY(128, 2, 2, false);
     WSEG_LAUNCH_CHECK();
     return WSEG_OK;
   }
-  if (bm == 32)
-    hipLaunchKernelGGL((gemm_bf16_kernel<32, 64, 1, 4, EPI, true>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, k_len, g.ep, g.splitk_ws, bm);
-  else
-    hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 1, 4, EPI, true>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, k_len, g.ep, g.splitk_ws, bm);
+  if (bm == 32) WSEG_SKINNY(32, 1, 4, true);
+  else if (bm == 64) WSEG_SKINNY(64, 1, 4, true);
+  else WSEG_SKINNY(128, 2, 2, true);
+#undef WSEG_SKINNY
   WSEG_LAUNCH_CHECK();
   const int work = g.M * (g.N / 4);
-  hipLaunchKernelGGL((splitk_reduce_kernel<EPI, bf16_t>), dim3(cdiv(work, 256)), dim3(256), 0, s, g.splitk_ws, splits, bm, g.M, g.N, g.ep);
+  hipLaunchKernelGGL((splitk_reduce_kernel<EPI, bf16_t>), dim3(cdiv(work, 256)), dim3(256), 0, s, g.splitk_ws, splits, m_pad, g.M, g.N, g.ep);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
@@ -365,6 +387,18 @@ int launch_gemm(int dtype, EpiKind epi, const GemmArgs& g, hipStream_t s) {
 }
 
 }  // namespace wseg
+
+extern "C" int wseg_debug_gemm(int32_t dtype, int32_t epi, int32_t M, int32_t N, int32_t K, const void* A, const void* W,
+                               const void* bias, const void* resid, void* out, void* splitk_ws, size_t splitk_ws_bytes,
+                               void* stream) {
+  using namespace wseg;
+  if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || epi < 0 || epi > 2) { set_error("wseg_debug_gemm: bad argument"); return WSEG_ERR_INVALID; }
+  GemmArgs g;
+  g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K;
+  g.ep.bias = bias; g.ep.out = out; g.ep.ldc = N; g.ep.resid = resid;
+  g.splitk_ws = (float*)splitk_ws; g.splitk_ws_bytes = splitk_ws_bytes;
+  return launch_gemm(dtype, epi == 0 ? EPI_STORE : (epi == 1 ? EPI_GELU : EPI_RESID), g, (hipStream_t)stream);
+}
 
 extern "C" int wseg_profile_begin(void) {
   using namespace wseg;

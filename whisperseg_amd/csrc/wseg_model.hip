@@ -25,6 +25,7 @@ struct Plan {   // workspace carve-up (all offsets 256-byte aligned)
   size_t total = 0;
   char *a1, *h1, *a2, *x, *y, *q, *k, *vt, *hbuf, *enc_out;
   char *ck, *cv, *sk, *sv, *dx, *dy, *dq, *dattn, *dh, *logits, *first_logits, *splitk, *mask;
+  char *tk_val, *tk_idx, *tk_stat;
   size_t splitk_bytes;
   DecodeState st;
 };
@@ -93,9 +94,12 @@ void make_plan(const wseg_model* m, int W, int nb, int L, char* base, Plan& p) {
   p.logits = take(Rp * (size_t)m->vp * 4);
   p.first_logits = take(R * (size_t)m->vp * 4);
   const size_t maxn = 3 * d > ffn ? 3 * d : ffn;
-  p.splitk_bytes = (size_t)16 * 64 * maxn * 4;
+  p.splitk_bytes = (size_t)8 * Rp * maxn * 4;
   p.splitk = take(p.splitk_bytes);
   p.mask = take(align_up((size_t)c.vocab, 4));
+  p.tk_val = take(R * 256 * 4);
+  p.tk_idx = take(R * 256 * 4);
+  p.tk_stat = take(R * 16 * 2 * 4);
   DecodeState& st = p.st;
   st.W = W; st.nb = nb; st.L = L; st.V = c.vocab; st.ldv = m->vp;
   st.pos = (int*)take(256);
@@ -386,7 +390,7 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
     } else {
       if (t == P - 1)
         WSEG_HIP_CHECK(hipMemcpyAsync(p.first_logits, p.logits, (size_t)n_windows * nb * m->vp * 4, hipMemcpyDeviceToDevice, s));
-      WSEG_TRY(launch_row_topk(st, (const float*)p.logits, s));
+      WSEG_TRY(launch_row_topk(st, (const float*)p.logits, (float*)p.tk_val, (int*)p.tk_idx, (float*)p.tk_stat, s));
       if (nb == 1) WSEG_TRY(launch_greedy_step(st, s));
       else WSEG_TRY(launch_beam_step(st, s));
       m->poll[t] = -1;
