@@ -7,7 +7,8 @@ One "step" = one pass of the whole hot path over one batch of synthetic windows 
 resident in HBM -> log-mel kernels -> Whisper encoder -> cross-K/V -> beam-search decode (libwseg) ->
 token ids to the host -> detokenise + regex parse (the CPU epilogue).  Workload (BASELINE.json metric):
 whisperseg-large geometry (1550 M), bf16, 30 s windows (spec_time_step 0.03 @ 16 kHz, 480 000 samples,
-SURVEY §8d), seeded random weights (no checkpoint exists offline), synthetic 16 kHz sine+noise, beams 4,
+SURVEY §8d), by default 120 windows = one 1-hour recording per GPU per step (BASELINE.json configs[3], sharded
+weakly: every GPU gets its own hour), all 120 windows decoded as one batch, seeded random weights (no checkpoint exists offline), synthetic 16 kHz sine+noise, beams 4,
 decode length pinned to --gen-tokens with EOS suppressed (random weights never emit a meaningful EOS).
 Windows are independent, so ranks shard them with no data-path collective ("weak" scaling: fixed
 windows per GPU); the only exchange is the all_gather of token ids to every rank.
@@ -101,7 +102,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="large", choices=sorted(GEOMETRY))
-    ap.add_argument("--windows", type=int, default=32, help="30 s windows per GPU per step")
+    ap.add_argument("--windows", type=int, default=120,
+                    help="30 s windows per GPU per step (default 120 = one 1-hour recording per GPU, BASELINE config[3])")
     ap.add_argument("--batch", type=int, default=0, help="windows per generate call (0 = all windows of the step)")
     ap.add_argument("--gen-tokens", type=int, default=32)
     ap.add_argument("--beams", type=int, default=4)

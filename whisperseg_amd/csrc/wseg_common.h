@@ -57,6 +57,22 @@ template <> struct El<bf16_t> {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// erf-GELU for the bf16 path: Abramowitz & Stegun 7.1.26 rational approximation of erf (|error| <= 1.5e-7, far
+// below the 2^-9 relative rounding of the bf16 result), ~14 VALU instructions instead of libm erff's ~50.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = 1.0f - p * t * __expf(-z * z);        // erf(|x| / sqrt 2)
+  return 0.5f * x * (1.0f + copysignf(e, x));
+}
+template <typename T> __device__ __forceinline__ float gelu_for(float x);
+template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }
+template <> __device__ __forceinline__ float gelu_for<uint16_t>(float x) { return gelu_erf_fast(x); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

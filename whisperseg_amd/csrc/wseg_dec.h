@@ -28,6 +28,8 @@ struct DecodeState {
   float* cand_val;                 // [R][Kc]
   int* cand_tok;                   // [R][Kc]
   int* active;                     // [L]      number of windows still improvable after each step
+  int* flags;                      // [L]      per step: epoch*4 + (1 = some window still improvable, 2 = none); 0 = not run yet
+  int epoch;                       // per-call tag so that late copies of an earlier call are never misread
   const unsigned char* sup_mask;   // [V] bit0: always suppressed, bit1: suppressed at the first generated position
 };
 
@@ -39,11 +41,14 @@ int launch_embed(int dtype, const DecodeState& st, const void* tok_emb, const vo
 int launch_prompt_feed(const DecodeState& st, hipStream_t s);
 int launch_advance(const DecodeState& st, hipStream_t s);
 // decoder self-attention over the KV cache [R][H][L][64] with per-position ancestry
-int launch_dec_self_attn(int dtype, const DecodeState& st, const void* q, const void* kc, const void* vc, void* out,
-                         int H, int d, hipStream_t s);
+// qkv_part != nullptr: q/k/v of this step arrive as split-K partials [z][m_pad][3d] (+ qkv_bias); the kernel finishes the
+// reduction, appends k/v to the cache and uses them (saves the separate reduction launch).
+int launch_dec_self_attn(int dtype, const DecodeState& st, const void* q, void* kc, void* vc, void* out,
+                         int H, int d, const PartialInfo* qkv_part, const void* qkv_bias, float scale, hipStream_t s);
 // cross-attention: the nb beams of a window share K/V [W][H][Tk][64]
+// q_part != nullptr: the query arrives as split-K partials [z][m_pad][d] (+ q_bias, scaled by `scale`)
 int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const void* ck, const void* cv, void* out,
-                          int H, int Tk, int d, hipStream_t s);
+                          int H, int Tk, int d, const PartialInfo* q_part, const void* q_bias, float scale, hipStream_t s);
 // log-softmax + suppress + running score -> top-2nb per row (beam) / argmax of the processed logits (greedy)
 // scratch: part_val/part_idx [R][16][16], part_stat [R][16][2]
 int launch_row_topk(const DecodeState& st, const float* logits, float* part_val, int* part_idx, float* part_stat, hipStream_t s);

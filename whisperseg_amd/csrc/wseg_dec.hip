@@ -29,8 +29,8 @@ __global__ void decode_init_kernel(DecodeState st) {
     st.tokens_in[i] = st.prompt[0];
   }
   for (int i = blockIdx.x * 256 + threadIdx.x; i < W; i += gridDim.x * 256) st.unsat[i] = 1;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < L; i += gridDim.x * 256) st.active[i] = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *st.pos = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < L; i += gridDim.x * 256) { st.active[i] = 0; st.flags[i] = 0; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { st.pos[0] = 0; st.pos[1] = st.epoch; }   // epoch lives in device memory: the step graph is reused across calls
 }
 
 __global__ void suppress_mask_kernel(unsigned char* mask, int V, const int* sup, int n_sup, const int* bsup, int n_bsup) {
@@ -58,65 +58,16 @@ __global__ void prompt_feed_kernel(DecodeState st) {
   st.tokens_in[i] = st.prompt[pos + 1 < st.P ? pos + 1 : st.P - 1];
 }
 
-__global__ void advance_kernel(DecodeState st) { *st.pos += 1; }
-
-// ------------------------------------------------------------------------------------------------
-// Self-attention, one wave per (row, head).
-// ------------------------------------------------------------------------------------------------
-template <typename T> __device__ __forceinline__ void load_row64(const T* p, float v[64]);
-template <> __device__ __forceinline__ void load_row64<float>(const float* p, float v[64]) {
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { const float4 t = ((const float4*)p)[i]; v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w; }
-}
-template <> __device__ __forceinline__ void load_row64<bf16_t>(const bf16_t* p, float v[64]) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const uint4 t = ((const uint4*)p)[i];
-    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { v[8 * i + 2 * j] = __uint_as_float(w[j] << 16); v[8 * i + 2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const T* __restrict__ q, const T* __restrict__ kc,
-                                                           const T* __restrict__ vc, T* __restrict__ out, int H, int d) {
-  __shared__ float sq[64];
-  __shared__ float sp[512];
-  __shared__ int srow[512];
-  const int lane = threadIdx.x;
-  const int r = blockIdx.x / H, h = blockIdx.x - r * H;
-  const int w = r / st.nb;
-  const int L = st.L;
-  const int n = *st.pos + 1;                      // keys 0 .. pos (the current token's K/V were just appended)
-  sq[lane] = El<T>::ld(q + (size_t)r * d + h * 64 + lane);
-  const unsigned char* anc = st.anc + (size_t)r * L;
-  for (int t = lane; t < n; t += 64) srow[t] = w * st.nb + (t == n - 1 ? (r - w * st.nb) : (int)anc[t]);
-  __syncthreads();
-  float mx = -3.0e38f;
-  for (int t = lane; t < n; t += 64) {
-    float kv[64];
-    load_row64<T>(kc + (((size_t)srow[t] * H + h) * L + t) * 64, kv);
-    float s = 0.f;
-#pragma unroll
-    for (int e = 0; e < 64; ++e) s = fmaf(sq[e], kv[e], s);
-    sp[t] = s;
-    mx = fmaxf(mx, s);
-  }
-  mx = wave_max(mx);
-  float sum = 0.f;
-  for (int t = lane; t < n; t += 64) { const float p = expf(sp[t] - mx); sp[t] = p; sum += p; }
-  sum = wave_sum(sum);
-  __syncthreads();
-  float acc = 0.f;
-  for (int t = 0; t < n; ++t) acc = fmaf(sp[t], El<T>::ld(vc + (((size_t)srow[t] * H + h) * L + t) * 64 + lane), acc);
-  El<T>::st(out + (size_t)r * d + h * 64 + lane, acc / sum);
+// Last kernel of every step (single thread): publish the step's verdict for the host poll, then move on.
+__global__ void advance_kernel(DecodeState st) {
+  const int pos = *st.pos;
+  if (pos >= st.P - 1) st.flags[pos] = st.pos[1] * 4 + (st.active[pos] == 0 ? 2 : 1);
+  *st.pos = pos + 1;
 }
 
 // ------------------------------------------------------------------------------------------------
-// Cross-attention, one workgroup per (window, head); all beams of the window in one pass over K and V.
-// HBM-bound (128 KiB of K/V per workgroup).  8 lanes cover one 128-byte K/V row (16 B each), so a wave
-// reads 8 consecutive rows = 1 KiB fully coalesced per instruction and 4 rows are in flight per lane.
+// Self-attention, one wave per (row, head).  8 lanes cover one 128-byte K/V row, so one wave instruction
+// gathers 8 cache rows (each found through the ancestry table) and 4 instructions are in flight per lane.
 // ------------------------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ void load8(const T* p, float v[8]);
 template <> __device__ __forceinline__ void load8<float>(const float* p, float v[8]) {
@@ -130,9 +81,155 @@ template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float
   for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
 }
 
+// sum_z part[z][row][col .. col+8) + bias[col .. col+8)   (fixed order z = 0, 1, ...: deterministic)
+template <typename T>
+__device__ __forceinline__ void reduce8(const PartialInfo& pi, int row, int col, const T* bias, float v[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  const float* pp = pi.part + (size_t)row * pi.n + col;
+  const size_t zs = (size_t)pi.m_pad * pi.n;
+  for (int z = 0; z < pi.splits; ++z) {
+    const float4 a = *(const float4*)(pp + z * zs), b = *(const float4*)(pp + z * zs + 4);
+    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+  }
+  if (bias) {
+    float bb[8];
+    load8<T>(bias + col, bb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += bb[e];
+  }
+}
+
+template <typename T> __device__ __forceinline__ void store8(T* p, const float v[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float v[8]) {
+  ((float4*)p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+  ((float4*)p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float v[8]) {
+  uint32_t w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w[j] = (uint32_t)f2bf(v[2 * j]) | ((uint32_t)f2bf(v[2 * j + 1]) << 16);
+  *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const T* __restrict__ q, T* __restrict__ kc,
+                                                           T* __restrict__ vc, T* __restrict__ out, int H, int d,
+                                                           PartialInfo pi, const T* __restrict__ qkv_bias, float scale) {
+  __shared__ float sp[512];
+  __shared__ int srow[512];
+  __shared__ float snk[64], snv[64];        // this step's own key / value (fused-reduction path)
+  const int lane = threadIdx.x, sub = lane & 7, rowl = lane >> 3;
+  const int r = blockIdx.x / H, h = blockIdx.x - r * H;
+  const int w = r / st.nb;
+  const int L = st.L;
+  const int n = *st.pos + 1;                      // keys 0 .. pos (the current token's K/V were just appended)
+  float qv[8];
+  const bool fused = pi.part != nullptr;
+  if (fused) {
+    // finish the split-K reduction of q | k | v for this (row, head); values are rounded to the storage type
+    // exactly as the unfused epilogue would have stored and re-loaded them
+    reduce8<T>(pi, r, h * 64 + sub * 8, qkv_bias, qv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] = El<T>::rnd(qv[e] * scale);
+    if (rowl < 2) {
+      float nv[8];
+      reduce8<T>(pi, r, (rowl + 1) * d + h * 64 + sub * 8, qkv_bias, nv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) nv[e] = El<T>::rnd(nv[e]);
+      T* dst = (rowl == 0 ? kc : vc) + (((size_t)r * H + h) * L + (n - 1)) * 64 + sub * 8;
+      store8<T>(dst, nv);
+      float* sh = rowl == 0 ? snk : snv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sh[sub * 8 + e] = nv[e];
+    }
+  } else {
+    load8<T>(q + (size_t)r * d + h * 64 + sub * 8, qv);
+  }
+  const unsigned char* anc = st.anc + (size_t)r * L;
+  for (int t = lane; t < n; t += 64) srow[t] = w * st.nb + (t == n - 1 ? (r - w * st.nb) : (int)anc[t]);
+  __syncthreads();
+  for (int t0 = 0; t0 < n; t0 += 32) {
+    float kv[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * 8 + rowl;
+      if (fused && t == n - 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kv[u][e] = snk[sub * 8 + e];
+      } else if (t < n) load8<T>(kc + (((size_t)srow[t] * H + h) * L + t) * 64 + sub * 8, kv[u]);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kv[u][e] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * 8 + rowl;
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s = fmaf(qv[e], kv[u][e], s);
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      if (sub == 0 && t < n) sp[t] = s;
+    }
+  }
+  __syncthreads();
+  float mx = -3.0e38f;
+  for (int t = lane; t < n; t += 64) mx = fmaxf(mx, sp[t]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int t = lane; t < n; t += 64) { const float p = expf(sp[t] - mx); sp[t] = p; sum += p; }
+  sum = wave_sum(sum);
+  __syncthreads();
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int t0 = 0; t0 < n; t0 += 32) {
+    float vv[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * 8 + rowl;
+      if (fused && t == n - 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vv[u][e] = snv[sub * 8 + e];
+      } else if (t < n) load8<T>(vc + (((size_t)srow[t] * H + h) * L + t) * 64 + sub * 8, vv[u]);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vv[u][e] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u * 8 + rowl;
+      const float p = t < n ? sp[t] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, vv[u][e], acc[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float a = acc[e];
+    a += __shfl_xor(a, 8, 64);
+    a += __shfl_xor(a, 16, 64);
+    a += __shfl_xor(a, 32, 64);
+    acc[e] = a;
+  }
+  if (rowl == 0) {
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) El<T>::st(out + (size_t)r * d + h * 64 + sub * 8 + e, acc[e] * inv);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cross-attention, one workgroup per (window, head); all beams of the window in one pass over K and V.
+// HBM-bound (128 KiB of K/V per workgroup).  8 lanes cover one 128-byte K/V row (16 B each), so a wave
+// reads 8 consecutive rows = 1 KiB fully coalesced per instruction and 4 rows are in flight per lane.
+// ------------------------------------------------------------------------------------------------
 template <typename T, int NB>
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(DecodeState st, const T* __restrict__ q, const T* __restrict__ ck,
-                                                             const T* __restrict__ cv, T* __restrict__ out, int H, int Tk, int d) {
+                                                             const T* __restrict__ cv, T* __restrict__ out, int H, int Tk, int d,
+                                                             PartialInfo pi, const T* __restrict__ q_bias, float scale) {
   __shared__ float sc[NB][512];
   __shared__ float red[4][NB][64];
   __shared__ float sinv[NB];
@@ -146,7 +243,11 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(DecodeState st, con
   float qv[NB][8];
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
-    if (j < nb) load8<T>(q + (size_t)(w * nb + j) * d + h * 64 + sub * 8, qv[j]);
+    if (j < nb && pi.part != nullptr) {
+      reduce8<T>(pi, w * nb + j, h * 64 + sub * 8, q_bias, qv[j]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qv[j][e] = El<T>::rnd(qv[j][e] * scale);
+    } else if (j < nb) load8<T>(q + (size_t)(w * nb + j) * d + h * 64 + sub * 8, qv[j]);
     else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) qv[j][e] = 0.f;
@@ -541,26 +642,33 @@ int launch_advance(const DecodeState& st, hipStream_t s) {
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
-int launch_dec_self_attn(int dtype, const DecodeState& st, const void* q, const void* kc, const void* vc, void* out, int H, int d, hipStream_t s) {
+int launch_dec_self_attn(int dtype, const DecodeState& st, const void* q, void* kc, void* vc, void* out, int H, int d,
+                         const PartialInfo* qkv_part, const void* qkv_bias, float scale, hipStream_t s) {
   if (st.L > 512) { set_error("self-attention: max_length %d > 512", st.L); return WSEG_ERR_INVALID; }
   const int R = st.W * st.nb;
-  if (dtype == WSEG_BF16) hipLaunchKernelGGL((dec_self_attn_kernel<bf16_t>), dim3(R * H), dim3(64), 0, s, st, (const bf16_t*)q, (const bf16_t*)kc, (const bf16_t*)vc, (bf16_t*)out, H, d);
-  else hipLaunchKernelGGL((dec_self_attn_kernel<float>), dim3(R * H), dim3(64), 0, s, st, (const float*)q, (const float*)kc, (const float*)vc, (float*)out, H, d);
+  PartialInfo pi;
+  if (qkv_part) pi = *qkv_part;
+  if (dtype == WSEG_BF16) hipLaunchKernelGGL((dec_self_attn_kernel<bf16_t>), dim3(R * H), dim3(64), 0, s, st, (const bf16_t*)q, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)out, H, d, pi, (const bf16_t*)qkv_bias, scale);
+  else hipLaunchKernelGGL((dec_self_attn_kernel<float>), dim3(R * H), dim3(64), 0, s, st, (const float*)q, (float*)kc, (float*)vc, (float*)out, H, d, pi, (const float*)qkv_bias, scale);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
 template <typename T>
-static void launch_cross_t(const DecodeState& st, const T* q, const T* ck, const T* cv, T* out, int H, int Tk, int d, hipStream_t s) {
+static void launch_cross_t(const DecodeState& st, const T* q, const T* ck, const T* cv, T* out, int H, int Tk, int d,
+                           const PartialInfo& pi, const T* qb, float scale, hipStream_t s) {
   dim3 grid(st.W * H), block(256);
-  if (st.nb <= 1) hipLaunchKernelGGL((dec_cross_attn_kernel<T, 1>), grid, block, 0, s, st, q, ck, cv, out, H, Tk, d);
-  else if (st.nb <= 2) hipLaunchKernelGGL((dec_cross_attn_kernel<T, 2>), grid, block, 0, s, st, q, ck, cv, out, H, Tk, d);
-  else if (st.nb <= 4) hipLaunchKernelGGL((dec_cross_attn_kernel<T, 4>), grid, block, 0, s, st, q, ck, cv, out, H, Tk, d);
-  else hipLaunchKernelGGL((dec_cross_attn_kernel<T, 8>), grid, block, 0, s, st, q, ck, cv, out, H, Tk, d);
+  if (st.nb <= 1) hipLaunchKernelGGL((dec_cross_attn_kernel<T, 1>), grid, block, 0, s, st, q, ck, cv, out, H, Tk, d, pi, qb, scale);
+  else if (st.nb <= 2) hipLaunchKernelGGL((dec_cross_attn_kernel<T, 2>), grid, block, 0, s, st, q, ck, cv, out, H, Tk, d, pi, qb, scale);
+  else if (st.nb <= 4) hipLaunchKernelGGL((dec_cross_attn_kernel<T, 4>), grid, block, 0, s, st, q, ck, cv, out, H, Tk, d, pi, qb, scale);
+  else hipLaunchKernelGGL((dec_cross_attn_kernel<T, 8>), grid, block, 0, s, st, q, ck, cv, out, H, Tk, d, pi, qb, scale);
 }
-int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const void* ck, const void* cv, void* out, int H, int Tk, int d, hipStream_t s) {
+int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const void* ck, const void* cv, void* out, int H, int Tk, int d,
+                          const PartialInfo* q_part, const void* q_bias, float scale, hipStream_t s) {
   if (Tk > 512) { set_error("cross-attention: %d encoder positions > 512", Tk); return WSEG_ERR_INVALID; }
-  if (dtype == WSEG_BF16) launch_cross_t<bf16_t>(st, (const bf16_t*)q, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)out, H, Tk, d, s);
-  else launch_cross_t<float>(st, (const float*)q, (const float*)ck, (const float*)cv, (float*)out, H, Tk, d, s);
+  PartialInfo pi;
+  if (q_part) pi = *q_part;
+  if (dtype == WSEG_BF16) launch_cross_t<bf16_t>(st, (const bf16_t*)q, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)out, H, Tk, d, pi, (const bf16_t*)q_bias, scale, s);
+  else launch_cross_t<float>(st, (const float*)q, (const float*)ck, (const float*)cv, (float*)out, H, Tk, d, pi, (const float*)q_bias, scale, s);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }

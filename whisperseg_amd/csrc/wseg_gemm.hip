@@ -53,7 +53,7 @@ __device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, fl
     Vec4<T>::st((T*)ep.out + (size_t)m * ep.ldc + n0, v);
   } else if constexpr (EPI == EPI_GELU) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+    for (int i = 0; i < 4; ++i) v[i] = gelu_for<T>(v[i]);
     Vec4<T>::st((T*)ep.out + (size_t)m * ep.ldc + n0, v);
   } else if constexpr (EPI == EPI_RESID) {
     float r[4];
@@ -65,7 +65,7 @@ __device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, fl
     float p[4];
     Vec4<T>::ld((const T*)ep.pos + (size_t)(m % ep.pos_rows) * ep.ldc + n0, p);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]) + p[i];
+    for (int i = 0; i < 4; ++i) v[i] = gelu_for<T>(v[i]) + p[i];
     Vec4<T>::st((T*)ep.out + (size_t)m * ep.ldc + n0, v);
   } else if constexpr (EPI == EPI_QKV_ENC) {
     const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
@@ -117,7 +117,7 @@ __device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, fl
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // SPLIT: write fp32 partials [z][m_pad][n] (epilogue applied later by splitk_reduce_kernel).
-template <int BM, int BN, int WM, int WN, int EPI, bool SPLIT>
+template <int BM, int BN, int WM, int WN, int EPI, bool SPLIT, int NST = 2>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, int lda,
                                                         const bf16_t* __restrict__ W, int ldw,
                                                         int M, int N, int k_len, EpiParams ep,
@@ -128,9 +128,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
   constexpr int A_IT = BM * 8 / 256, W_IT = BN * 8 / 256;
   constexpr int NLD = A_IT + W_IT;
   static_assert(WM * WN == 4 && A_IT >= 1 && W_IT >= 1, "tile config");
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * BK];
-  bf16_t* sA = smem;                   // [2][BM*64]
-  bf16_t* sW = smem + 2 * BM * BK;     // [2][BN*64]
+  __shared__ __attribute__((aligned(16))) bf16_t smem[NST * (BM + BN) * BK];
+  bf16_t* sA = smem;                     // [NST][BM*64]
+  bf16_t* sW = smem + NST * BM * BK;     // [NST][BN*64]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -180,14 +180,28 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fg = lane >> 4;
-  issue(0, 0);
+  // NST-deep LDS ring.  NST == 2: prefetch one tile ahead.  NST > 2 (decoder weight streams, few K tiles per
+  // workgroup): NST-1 tiles are kept in flight; past the end the last tile is re-issued so the counted vmcnt
+  // stays a compile-time constant.
+  if constexpr (NST == 2) {
+    issue(0, 0);
+  } else {
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) issue(t < nk ? t : nk - 1, t);
+  }
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) {
-      issue(kt + 1, buf ^ 1);
-      wait_vmcnt<NLD>();
+    const int buf = kt % NST;
+    if constexpr (NST == 2) {
+      if (kt + 1 < nk) {
+        issue(kt + 1, buf ^ 1);
+        wait_vmcnt<NLD>();
+      } else {
+        wait_vmcnt<0>();
+      }
     } else {
-      wait_vmcnt<0>();
+      const int nt = kt + NST - 1;
+      issue(nt < nk ? nt : nk - 1, nt % NST);
+      wait_vmcnt<NLD*(NST - 1)>();
     }
     __builtin_amdgcn_s_barrier();
     const bf16_t* cA = sA + buf * BM * BK + (wm * TM) * BK;
@@ -301,13 +315,132 @@ static GemmProfiler g_prof;
 // ------------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------------
+#define WSEG_TRY_(expr) do { int _s = (expr); if (_s != WSEG_OK) return _s; } while (0)
+
+// skinny family (decoder steps, small encoders): BN = 64, BM in {32, 64, 128}; K is split across workgroups until
+// ~256+ of them stream the weight matrix.  Partials are reduced (in a fixed order) by a second kernel that
+// applies the epilogue (or the fused residual + LayerNorm).
+struct SkinnyPlan { int bm, mt, m_pad, splits, k_len; };
+
+static SkinnyPlan plan_skinny(const GemmArgs& g) {
+  SkinnyPlan sp;
+  // largest row tile that still yields >= 160 workgroups without splitting K; otherwise 128 rows + split-K
+  sp.bm = g.M <= 32 ? 32 : (g.M <= 64 ? 64 : 128);
+  if (g.M > 64) {
+    const int nt = g.N / 64;
+    if (nt * cdiv(g.M, 128) < 160 && nt * cdiv(g.M, 64) >= 160) sp.bm = 64;
+  }
+  sp.mt = cdiv(g.M, sp.bm);
+  sp.m_pad = sp.mt * sp.bm;
+  const int blocks = (g.N / 64) * sp.mt;
+  sp.splits = 1;
+  if (g.splitk_ws) {
+    // split K (in whole 64-wide tiles, >= 2 tiles per split) until ~256 workgroups stream the weights
+    const int nk = g.K / 64;
+    for (int cand = 2; cand <= 16 && blocks * sp.splits < 256; ++cand) {
+      if (nk % cand || nk / cand < 2) continue;
+      if ((size_t)cand * sp.m_pad * g.N * sizeof(float) > g.splitk_ws_bytes) break;
+      sp.splits = cand;
+    }
+  }
+  sp.k_len = g.K / sp.splits;
+  return sp;
+}
+
+// fp32 partial sums [splits][m_pad][N] into g.splitk_ws (valid for splits == 1 too)
+static int launch_skinny_partial(const GemmArgs& g, const SkinnyPlan& sp, hipStream_t s) {
+  const bf16_t* A = (const bf16_t*)g.A;
+  const bf16_t* W = (const bf16_t*)g.W;
+  if (!g.splitk_ws || (size_t)sp.splits * sp.m_pad * g.N * sizeof(float) > g.splitk_ws_bytes) {
+    set_error("split-K workspace missing or too small");
+    return WSEG_ERR_STATE;
+  }
+  dim3 grid(g.N / 64, sp.mt, sp.splits);
+#define WSEG_SKINNY_P(BM_, WM_, WN_)                                                                                     \
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM_, 64, WM_, WN_, EPI_STORE, true, (BM_ <= 64 ? 4 : 3)>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, \
+                     g.N, sp.k_len, g.ep, g.splitk_ws, sp.m_pad, 0)
+  if (sp.bm == 32) WSEG_SKINNY_P(32, 1, 4);
+  else if (sp.bm == 64) WSEG_SKINNY_P(64, 1, 4);
+  else WSEG_SKINNY_P(128, 2, 2);
+#undef WSEG_SKINNY_P
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+
+// x[m][:] = resid[m][:] + bias + sum_z part[z][m][:]  (stored in the model dtype), then y[m][:] = LayerNorm(x[m][:]).
+// One wave per row.  LayerNorm is computed from the ROUNDED x so that the result is bit-identical to running the
+// generic reduction and layernorm_kernel back to back.
+// One workgroup per row, one 8-element chunk per thread (d <= 2048), all split partials loaded up front.
+__global__ __launch_bounds__(256) void splitk_reduce_resid_ln_kernel(const float* __restrict__ part, int splits, int m_pad, int M,
+                                                                     int d, const bf16_t* __restrict__ bias, bf16_t* __restrict__ x,
+                                                                     const bf16_t* __restrict__ gam, const bf16_t* __restrict__ bet,
+                                                                     bf16_t* __restrict__ y) {
+  __shared__ float s_red[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = tid * 8;
+  const bool act = c < d;
+  float v[8];
+  float sum = 0.f;
+  if (act) {
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* pp = part + (size_t)row * d + c;
+    const size_t zs = (size_t)m_pad * d;
+#pragma unroll 4
+    for (int z = 0; z < splits; ++z) {
+      const float4 p0 = *(const float4*)(pp + z * zs), p1 = *(const float4*)(pp + z * zs + 4);
+      a[0] += p0.x; a[1] += p0.y; a[2] += p0.z; a[3] += p0.w; a[4] += p1.x; a[5] += p1.y; a[6] += p1.z; a[7] += p1.w;
+    }
+    const uint4 t = *(const uint4*)(x + (size_t)row * d + c);
+    const uint4 u = *(const uint4*)(bias + c);
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w}, zb[4] = {u.x, u.y, u.z, u.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float r0 = __uint_as_float(w[j] << 16), r1 = __uint_as_float(w[j] & 0xffff0000u);
+      const float b0 = __uint_as_float(zb[j] << 16), b1 = __uint_as_float(zb[j] & 0xffff0000u);
+      const bf16_t q0 = f2bf(r0 + (a[2 * j] + b0)), q1 = f2bf(r1 + (a[2 * j + 1] + b1));
+      v[2 * j] = bf2f(q0); v[2 * j + 1] = bf2f(q1);
+      o[j] = (uint32_t)q0 | ((uint32_t)q1 << 16);
+    }
+    *(uint4*)(x + (size_t)row * d + c) = make_uint4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += v[j];
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) s_red[wave] = sum;
+  __syncthreads();
+  const float mean = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / (float)d;
+  __syncthreads();
+  float sq = 0.f;
+  if (act) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float t = v[j] - mean; sq += t * t; }
+  }
+  sq = wave_sum(sq);
+  if (lane == 0) s_red[wave] = sq;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf(((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / (float)d + 1e-5f);
+  if (act) {
+    const uint4 tg = *(const uint4*)(gam + c), tb = *(const uint4*)(bet + c);
+    const uint32_t wg[4] = {tg.x, tg.y, tg.z, tg.w}, wb[4] = {tb.x, tb.y, tb.z, tb.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float y0 = (v[2 * j] - mean) * rstd * __uint_as_float(wg[j] << 16) + __uint_as_float(wb[j] << 16);
+      const float y1 = (v[2 * j + 1] - mean) * rstd * __uint_as_float(wg[j] & 0xffff0000u) + __uint_as_float(wb[j] & 0xffff0000u);
+      o[j] = (uint32_t)f2bf(y0) | ((uint32_t)f2bf(y1) << 16);
+    }
+    *(uint4*)(y + (size_t)row * d + c) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 template <int EPI>
 static int launch_bf16(const GemmArgs& g, hipStream_t s) {
   const bf16_t* A = (const bf16_t*)g.A;
   const bf16_t* W = (const bf16_t*)g.W;
   if (g.K % 64 || g.N % 64) { set_error("gemm bf16: K %d / N %d not tile multiples", g.K, g.N); return WSEG_ERR_INVALID; }
   const long big_blocks = (long)cdiv(g.M, 128) * (g.N / 128);
-  if (g.M > 128 && g.N % 128 == 0 && big_blocks >= 128) {
+  if (g.M > 128 && g.N % 128 == 0 && big_blocks >= 256) {
     static const bool no_swz = getenv("WSEG_NO_XCD_SWIZZLE") != nullptr;
     const int ntm = cdiv(g.M, 128);
     dim3 grid(g.N / 128, ntm, 1);
@@ -320,37 +453,22 @@ static int launch_bf16(const GemmArgs& g, hipStream_t s) {
     WSEG_LAUNCH_CHECK();
     return WSEG_OK;
   }
-  // skinny family (decoder steps, small encoders): BN = 64, BM in {32, 64, 128}; split K across workgroups
-  // until ~256+ of them stream the weight matrix.  Partials are reduced (in a fixed order) by a second kernel
-  // that applies the epilogue.
-  const int bm = g.M <= 32 ? 32 : (g.M <= 64 ? 64 : 128);
-  const int mt = cdiv(g.M, bm), m_pad = mt * bm;
-  const int blocks = (g.N / 64) * mt;
-  int splits = 1;
-  if (g.splitk_ws) {
-    while (blocks * splits < 256 && (g.K / (splits * 2)) % 64 == 0 && g.K / (splits * 2) >= 128 && splits < 16 &&
-           (size_t)(splits * 2) * m_pad * g.N * sizeof(float) <= g.splitk_ws_bytes)
-      splits *= 2;
-  }
-  dim3 grid(g.N / 64, mt, splits);
-  const int k_len = g.K / splits;
-#define WSEG_SKINNY(BM_, WM_, WN_, SPLIT_)                                                                              \
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM_, 64, WM_, WN_, EPI, SPLIT_>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, \
-                     k_len, g.ep, SPLIT_ ? g.splitk_ws : (float*)nullptr, m_pad, 0)
-  if (splits == 1) {
-    if (bm == 32) WSEG_SKINNY(32, 1, 4, false);
-    else if (bm == 64) WSEG_SKINNY(64, 1, 4, false);
-    else WSEG_SKINNY(128, 2, 2, false);
+  SkinnyPlan sp = plan_skinny(g);
+  if (sp.splits == 1) {
+    dim3 grid(g.N / 64, sp.mt, 1);
+#define WSEG_SKINNY(BM_, WM_, WN_)                                                                                      \
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM_, 64, WM_, WN_, EPI, false, (BM_ <= 64 ? 4 : 3)>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, \
+                     g.K, g.ep, (float*)nullptr, sp.m_pad, 0)
+    if (sp.bm == 32) WSEG_SKINNY(32, 1, 4);
+    else if (sp.bm == 64) WSEG_SKINNY(64, 1, 4);
+    else WSEG_SKINNY(128, 2, 2);
+#undef WSEG_SKINNY
     WSEG_LAUNCH_CHECK();
     return WSEG_OK;
   }
-  if (bm == 32) WSEG_SKINNY(32, 1, 4, true);
-  else if (bm == 64) WSEG_SKINNY(64, 1, 4, true);
-  else WSEG_SKINNY(128, 2, 2, true);
-#undef WSEG_SKINNY
-  WSEG_LAUNCH_CHECK();
+  WSEG_TRY_(launch_skinny_partial(g, sp, s));
   const int work = g.M * (g.N / 4);
-  hipLaunchKernelGGL((splitk_reduce_kernel<EPI, bf16_t>), dim3(cdiv(work, 256)), dim3(256), 0, s, g.splitk_ws, splits, m_pad, g.M, g.N, g.ep);
+  hipLaunchKernelGGL((splitk_reduce_kernel<EPI, bf16_t>), dim3(cdiv(work, 256)), dim3(256), 0, s, g.splitk_ws, sp.splits, sp.m_pad, g.M, g.N, g.ep);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
@@ -367,6 +485,41 @@ static int launch_f32(const GemmArgs& g, hipStream_t s) {
 template <int EPI>
 static int launch_any(int dtype, const GemmArgs& g, hipStream_t s) {
   return dtype == WSEG_BF16 ? launch_bf16<EPI>(g, s) : launch_f32<EPI>(g, s);
+}
+
+int launch_gemm_partial(int dtype, const GemmArgs& g, PartialInfo* info, bool* ok, hipStream_t s) {
+  *ok = false;
+  const long big_blocks = (long)cdiv(g.M, 128) * (g.N / 128);
+  const bool big = g.M > 128 && g.N % 128 == 0 && big_blocks >= 256;
+  if (dtype != WSEG_BF16 || big || !g.splitk_ws || g.K % 64 || g.N % 64) return WSEG_OK;
+  SkinnyPlan sp = plan_skinny(g);
+  if ((size_t)sp.splits * sp.m_pad * g.N * sizeof(float) > g.splitk_ws_bytes) return WSEG_OK;
+  WSEG_TRY_(launch_skinny_partial(g, sp, s));
+  info->part = g.splitk_ws; info->splits = sp.splits; info->m_pad = sp.m_pad; info->n = g.N;
+  *ok = true;
+  return WSEG_OK;
+}
+
+// x = x + (A W^T + bias); y = LayerNorm(x) * gamma + beta.   bf16 decoder rows: split-K partials + ONE fused
+// reduction/residual/LayerNorm kernel; otherwise the generic GEMM (EPI_RESID) followed by launch_layernorm.
+int launch_gemm_resid_ln(int dtype, const GemmArgs& g0, const void* gamma, const void* beta, void* y, hipStream_t s) {
+  GemmArgs g = g0;
+  const int d = g.N;
+  const long big_blocks = (long)cdiv(g.M, 128) * (g.N / 128);
+  const bool big = g.M > 128 && g.N % 128 == 0 && big_blocks >= 256;
+  if (dtype == WSEG_BF16 && !big && g.splitk_ws && d % 8 == 0 && d <= 2048 && g.ep.bias && g.ep.resid == g.ep.out && g.ep.ldc == d &&
+      g.K % 64 == 0 && g.N % 64 == 0) {
+    SkinnyPlan sp = plan_skinny(g);
+    if ((size_t)sp.splits * sp.m_pad * g.N * sizeof(float) <= g.splitk_ws_bytes) {
+      WSEG_TRY_(launch_skinny_partial(g, sp, s));
+      hipLaunchKernelGGL(splitk_reduce_resid_ln_kernel, dim3(g.M), dim3(256), 0, s, g.splitk_ws, sp.splits, sp.m_pad, g.M, d,
+                         (const bf16_t*)g.ep.bias, (bf16_t*)g.ep.out, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y);
+      WSEG_LAUNCH_CHECK();
+      return WSEG_OK;
+    }
+  }
+  WSEG_TRY_(launch_gemm(dtype, EPI_RESID, g, s));
+  return launch_layernorm(dtype, g.ep.out, gamma, beta, y, g.M, d, s);
 }
 
 int launch_gemm(int dtype, EpiKind epi, const GemmArgs& g, hipStream_t s) {

@@ -52,6 +52,13 @@ struct GemmArgs {
 // dtype: WSEG_F32 (exact VALU kernel) or WSEG_BF16 (MFMA).  M may be any value as long as A has
 // round_up(M,128) readable rows; N % 128 == 0 rows of W readable; K % 64 == 0.
 int launch_gemm(int dtype, EpiKind epi, const GemmArgs& g, hipStream_t s);
+// Split-K partial sums only (bf16 decoder rows): part[z][m_pad][N] fp32 in g.splitk_ws, no epilogue.  The consumer
+// kernel (decoder self-/cross-attention) finishes the reduction itself.  Returns false in *ok when the shape is not
+// served by the skinny family (caller falls back to launch_gemm).
+struct PartialInfo { const float* part = nullptr; int splits = 0; int m_pad = 0; int n = 0; };
+int launch_gemm_partial(int dtype, const GemmArgs& g, PartialInfo* info, bool* ok, hipStream_t s);
+// g.ep: bias, resid == out == x, ldc == N.  x += A W^T + bias;  y = LayerNorm(x)  (fused for bf16 decoder rows)
+int launch_gemm_resid_ln(int dtype, const GemmArgs& g, const void* gamma, const void* beta, void* y, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // Encoder-side kernels (wseg_enc.hip)

@@ -46,8 +46,12 @@ struct wseg_model {
   int last_steps = 0;
   int last_W = 0, last_nb = 0, last_L = 0;
   bool timing_valid = false;
-  int* poll = nullptr;       // pinned host ints, one per decode step
-  std::vector<hipEvent_t> step_ev;
+  int* poll = nullptr;       // pinned host mirror of DecodeState::flags (one int per decode position)
+  int epoch = 0;
+  // decode-step graph (hipGraph): captured once per (workspace, geometry, parameters), replayed per step
+  hipGraphExec_t step_graph = nullptr;
+  hipStream_t cap_stream = nullptr;   // capture happens on a private stream (the legacy NULL stream cannot capture)
+  std::vector<unsigned char> step_graph_key;
 };
 
 namespace {
@@ -94,7 +98,7 @@ void make_plan(const wseg_model* m, int W, int nb, int L, char* base, Plan& p) {
   p.logits = take(Rp * (size_t)m->vp * 4);
   p.first_logits = take(R * (size_t)m->vp * 4);
   const size_t maxn = 3 * d > ffn ? 3 * d : ffn;
-  p.splitk_bytes = (size_t)8 * Rp * maxn * 4;
+  p.splitk_bytes = (size_t)8 * Rp * maxn * 4;   // fp32 partials of the decoder-step GEMMs
   p.splitk = take(p.splitk_bytes);
   p.mask = take(align_up((size_t)c.vocab, 4));
   p.tk_val = take(R * 256 * 4);
@@ -115,6 +119,8 @@ void make_plan(const wseg_model* m, int W, int nb, int L, char* base, Plan& p) {
   st.cand_val = (float*)take(R * MAX_CAND * 4);
   st.cand_tok = (int*)take(R * MAX_CAND * 4);
   st.active = (int*)take((size_t)L * 4);
+  st.flags = (int*)take((size_t)L * 4);
+  st.epoch = 0;
   st.sup_mask = (const unsigned char*)p.mask;
   p.total = (size_t)(cur - base);
 }
@@ -190,35 +196,58 @@ int run_decoder_step(wseg_model* m, Plan& p, bool want_logits, hipStream_t s) {
   const size_t cross_stride = (size_t)st.W * H * Tk * 64 * es;
   WSEG_TRY(launch_embed(dt, st, m->dec_tok, m->dec_pos, p.dx, d, s));
   EpiParams e;
+  auto gemm_resid_ln = [&](const void* A, int K, const void* Wt, const void* bias, const void* g_, const void* b_) -> int {
+    GemmArgs g;
+    g.A = A; g.lda = K; g.W = Wt; g.ldw = K; g.M = R; g.N = d; g.K = K;
+    g.ep.bias = bias; g.ep.out = p.dx; g.ep.resid = p.dx; g.ep.ldc = d;
+    g.splitk_ws = (float*)p.splitk; g.splitk_ws_bytes = p.splitk_bytes;
+    return launch_gemm_resid_ln(dt, g, g_, b_, p.dy, s);
+  };
+  // y = LN1(x) of layer 0; every later LayerNorm is fused into the reduction of the GEMM that precedes it
+  WSEG_TRY(launch_layernorm(dt, p.dx, m->dec[0].ln1_g, m->dec[0].ln1_b, p.dy, R, d, s));
   for (int l = 0; l < c.dec_layers; ++l) {
     const DecLayer& L = m->dec[l];
-    WSEG_TRY(launch_layernorm(dt, p.dx, L.ln1_g, L.ln1_b, p.dy, R, d, s));
-    e = EpiParams();
-    e.bias = L.qkv_b; e.q = p.dq; e.k = p.sk + l * self_stride; e.v = p.sv + l * self_stride;
-    e.d_model = d; e.n_heads = H; e.t_pad = st.L; e.pos_ptr = st.pos; e.scale = 0.125f;
-    WSEG_TRY(gemm(m, EPI_QKV_DEC, p.dy, d, L.qkv_w, d, R, 3 * d, d, e, &p, s));
-    WSEG_TRY(launch_dec_self_attn(dt, st, p.dq, p.sk + l * self_stride, p.sv + l * self_stride, p.dattn, H, d, s));
-    e = EpiParams();
-    e.bias = L.o_b; e.out = p.dx; e.resid = p.dx; e.ldc = d;
-    WSEG_TRY(gemm(m, EPI_RESID, p.dattn, d, L.o_w, d, R, d, d, e, &p, s));
-    WSEG_TRY(launch_layernorm(dt, p.dx, L.ln2_g, L.ln2_b, p.dy, R, d, s));
-    e = EpiParams();
-    e.bias = L.cq_b; e.out = p.dq; e.ldc = d; e.scale = 0.125f;
-    WSEG_TRY(gemm(m, EPI_SCALE, p.dy, d, L.cq_w, d, R, d, d, e, &p, s));
-    WSEG_TRY(launch_dec_cross_attn(dt, st, p.dq, p.ck + l * cross_stride, p.cv + l * cross_stride, p.dattn, H, Tk, d, s));
-    e = EpiParams();
-    e.bias = L.co_b; e.out = p.dx; e.resid = p.dx; e.ldc = d;
-    WSEG_TRY(gemm(m, EPI_RESID, p.dattn, d, L.co_w, d, R, d, d, e, &p, s));
-    WSEG_TRY(launch_layernorm(dt, p.dx, L.ln3_g, L.ln3_b, p.dy, R, d, s));
+    {   // q|k|v projection: partial sums only when possible; the attention kernel finishes the reduction
+      GemmArgs g;
+      g.A = p.dy; g.lda = d; g.W = L.qkv_w; g.ldw = d; g.M = R; g.N = 3 * d; g.K = d;
+      g.splitk_ws = (float*)p.splitk; g.splitk_ws_bytes = p.splitk_bytes;
+      PartialInfo pi; bool ok = false;
+      WSEG_TRY(launch_gemm_partial(dt, g, &pi, &ok, s));
+      if (ok) {
+        WSEG_TRY(launch_dec_self_attn(dt, st, nullptr, p.sk + l * self_stride, p.sv + l * self_stride, p.dattn, H, d, &pi, L.qkv_b, 0.125f, s));
+      } else {
+        e = EpiParams();
+        e.bias = L.qkv_b; e.q = p.dq; e.k = p.sk + l * self_stride; e.v = p.sv + l * self_stride;
+        e.d_model = d; e.n_heads = H; e.t_pad = st.L; e.pos_ptr = st.pos; e.scale = 0.125f;
+        WSEG_TRY(gemm(m, EPI_QKV_DEC, p.dy, d, L.qkv_w, d, R, 3 * d, d, e, &p, s));
+        WSEG_TRY(launch_dec_self_attn(dt, st, p.dq, p.sk + l * self_stride, p.sv + l * self_stride, p.dattn, H, d, nullptr, nullptr, 0.125f, s));
+      }
+    }
+    WSEG_TRY(gemm_resid_ln(p.dattn, d, L.o_w, L.o_b, L.ln2_g, L.ln2_b));                    // x += attn Wo ; y = LN2(x)
+    {   // cross-attention query: same scheme
+      GemmArgs g;
+      g.A = p.dy; g.lda = d; g.W = L.cq_w; g.ldw = d; g.M = R; g.N = d; g.K = d;
+      g.splitk_ws = (float*)p.splitk; g.splitk_ws_bytes = p.splitk_bytes;
+      PartialInfo pi; bool ok = false;
+      WSEG_TRY(launch_gemm_partial(dt, g, &pi, &ok, s));
+      if (ok) {
+        WSEG_TRY(launch_dec_cross_attn(dt, st, nullptr, p.ck + l * cross_stride, p.cv + l * cross_stride, p.dattn, H, Tk, d, &pi, L.cq_b, 0.125f, s));
+      } else {
+        e = EpiParams();
+        e.bias = L.cq_b; e.out = p.dq; e.ldc = d; e.scale = 0.125f;
+        WSEG_TRY(gemm(m, EPI_SCALE, p.dy, d, L.cq_w, d, R, d, d, e, &p, s));
+        WSEG_TRY(launch_dec_cross_attn(dt, st, p.dq, p.ck + l * cross_stride, p.cv + l * cross_stride, p.dattn, H, Tk, d, nullptr, nullptr, 0.125f, s));
+      }
+    }
+    WSEG_TRY(gemm_resid_ln(p.dattn, d, L.co_w, L.co_b, L.ln3_g, L.ln3_b));                  // x += cross Wo ; y = LN3(x)
     e = EpiParams();
     e.bias = L.fc1_b; e.out = p.dh; e.ldc = ffn;
     WSEG_TRY(gemm(m, EPI_GELU, p.dy, d, L.fc1_w, d, R, ffn, d, e, &p, s));
-    e = EpiParams();
-    e.bias = L.fc2_b; e.out = p.dx; e.resid = p.dx; e.ldc = d;
-    WSEG_TRY(gemm(m, EPI_RESID, p.dh, ffn, L.fc2_w, ffn, R, d, ffn, e, &p, s));
+    const bool last = l + 1 == c.dec_layers;                                                 // x += fc2 ; y = next LN1 / final LN
+    WSEG_TRY(gemm_resid_ln(p.dh, ffn, L.fc2_w, L.fc2_b, last ? m->dec_ln_g : m->dec[l + 1].ln1_g,
+                           last ? m->dec_ln_b : m->dec[l + 1].ln1_b));
   }
   if (want_logits) {
-    WSEG_TRY(launch_layernorm(dt, p.dx, m->dec_ln_g, m->dec_ln_b, p.dy, R, d, s));
     e = EpiParams();
     e.out_f32 = (float*)p.logits; e.ldc = m->vp;
     WSEG_TRY(gemm(m, EPI_F32, p.dy, d, m->dec_tok, d, R, m->vp, d, e, nullptr, s));
@@ -282,7 +311,8 @@ extern "C" int wseg_model_create(const wseg_model_config* cfg, wseg_model** out)
 extern "C" void wseg_model_destroy(wseg_model* m) {
   if (!m) return;
   if (m->ev_ok) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(m->ev[i]);
-  for (hipEvent_t e : m->step_ev) (void)hipEventDestroy(e);
+  if (m->step_graph) (void)hipGraphExecDestroy(m->step_graph);
+  if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
   if (m->poll) (void)hipHostFree(m->poll);
   delete m;
 }
@@ -351,14 +381,11 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
     m->ev_ok = true;
   }
   if (!m->poll) WSEG_HIP_CHECK(hipHostMalloc((void**)&m->poll, 512 * sizeof(int), hipHostMallocDefault));
-  while ((int)m->step_ev.size() < L) {
-    hipEvent_t e;
-    WSEG_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    m->step_ev.push_back(e);
-  }
   DecodeState& st = p.st;
   st.P = P; st.eos = gp->eos_token_id; st.pad = gp->pad_token_id; st.max_length = L; st.length_penalty = gp->length_penalty;
   for (int i = 0; i < 8; ++i) st.prompt[i] = i < P ? gp->prompt[i] : 0;
+  m->epoch = (m->epoch % 100000000) + 1;
+  st.epoch = m->epoch;
 
   m->timing_valid = false;
   WSEG_HIP_CHECK(hipEventRecord(m->ev[0], s));
@@ -379,30 +406,62 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
   WSEG_TRY(launch_build_suppress_mask((unsigned char*)p.mask, c.vocab, gp->suppress_tokens, gp->n_suppress,
                                       gp->begin_suppress_tokens, gp->n_begin_suppress, s));
   WSEG_TRY(launch_decode_init(st, s));
-  int steps = 0, checked = P - 1;
+
+  // One generated-token step: decoder layers, LM head, candidates, bookkeeping, verdict mirror, advance.
+  auto enqueue_gen_step = [&](bool snapshot_logits, hipStream_t q) -> int {
+    WSEG_TRY(run_decoder_step(m, p, true, q));
+    if (snapshot_logits)
+      WSEG_HIP_CHECK(hipMemcpyAsync(p.first_logits, p.logits, (size_t)n_windows * nb * m->vp * 4, hipMemcpyDeviceToDevice, q));
+    WSEG_TRY(launch_row_topk(st, (const float*)p.logits, (float*)p.tk_val, (int*)p.tk_idx, (float*)p.tk_stat, q));
+    if (nb == 1) WSEG_TRY(launch_greedy_step(st, q));
+    else WSEG_TRY(launch_beam_step(st, q));
+    WSEG_TRY(launch_advance(st, q));
+    WSEG_HIP_CHECK(hipMemcpyAsync(m->poll, st.flags, (size_t)L * sizeof(int), hipMemcpyDeviceToHost, q));
+    return WSEG_OK;
+  };
+  // The step reads every step-dependent value (position, tokens, ancestry) from device memory, so ONE captured
+  // graph serves all steps: replay costs ~1.6 us per kernel instead of ~5 us per eager launch.
+  static const bool use_graph = getenv("WSEG_NO_GRAPH") == nullptr;
+  std::vector<unsigned char> key;
+  {
+    auto put = [&](const void* ptr, size_t n) { const unsigned char* b = (const unsigned char*)ptr; key.insert(key.end(), b, b + n); };
+    void* base = aligned_base(workspace);
+    put(&base, sizeof(base)); put(&n_windows, 4); put(&nb, 4); put(&L, 4);
+    put(&st.P, 4); put(&st.eos, 4); put(&st.pad, 4); put(&st.length_penalty, 4); put(st.prompt, sizeof(st.prompt));
+  }
+  int steps = 0;
   bool stop = false;
+  auto check_stop = [&](int upto) {
+    for (int t = P - 1; t < upto && !stop; ++t)
+      if (((volatile int*)m->poll)[t] == st.epoch * 4 + 2) stop = true;
+  };
   for (int t = 0; t < L - 1 && !stop; ++t) {
-    const bool gen = t >= P - 1;
-    WSEG_TRY(run_decoder_step(m, p, gen, s));
-    ++steps;
-    if (!gen) {
+    if (t < P - 1) {
+      WSEG_TRY(run_decoder_step(m, p, false, s));
       WSEG_TRY(launch_prompt_feed(st, s));
+      WSEG_TRY(launch_advance(st, s));
+    } else if (t == P - 1 || !use_graph) {
+      WSEG_TRY(enqueue_gen_step(t == P - 1, s));
     } else {
-      if (t == P - 1)
-        WSEG_HIP_CHECK(hipMemcpyAsync(p.first_logits, p.logits, (size_t)n_windows * nb * m->vp * 4, hipMemcpyDeviceToDevice, s));
-      WSEG_TRY(launch_row_topk(st, (const float*)p.logits, (float*)p.tk_val, (int*)p.tk_idx, (float*)p.tk_stat, s));
-      if (nb == 1) WSEG_TRY(launch_greedy_step(st, s));
-      else WSEG_TRY(launch_beam_step(st, s));
-      m->poll[t] = -1;
-      WSEG_HIP_CHECK(hipMemcpyAsync(&m->poll[t], st.active + t, sizeof(int), hipMemcpyDeviceToHost, s));
-      WSEG_HIP_CHECK(hipEventRecord(m->step_ev[t], s));
+      if (!m->step_graph || m->step_graph_key != key) {
+        if (m->step_graph) { (void)hipGraphExecDestroy(m->step_graph); m->step_graph = nullptr; }
+        hipGraph_t graph = nullptr;
+        if (!m->cap_stream) WSEG_HIP_CHECK(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+        WSEG_HIP_CHECK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue_gen_step(false, m->cap_stream);
+        const hipError_t ec = hipStreamEndCapture(m->cap_stream, &graph);
+        if (rc != WSEG_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (ec != hipSuccess) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ec)); return WSEG_ERR_HIP; }
+        WSEG_HIP_CHECK(hipGraphInstantiate(&m->step_graph, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        m->step_graph_key = key;
+      }
+      WSEG_HIP_CHECK(hipGraphLaunch(m->step_graph, s));
     }
-    WSEG_TRY(launch_advance(st, s));
-    // lagged, non-blocking poll: stop enqueueing once an already-finished step reported no improvable window
-    while (checked < t && hipEventQuery(m->step_ev[checked]) == hipSuccess) {
-      if (m->poll[checked] == 0) { stop = true; break; }
-      ++checked;
-    }
+    ++steps;
+    // lagged, non-blocking poll of the pinned verdict mirror: stop enqueueing once a finished step reported that
+    // no window can still improve (steps already enqueued are harmless: finished beams are frozen)
+    check_stop(t);
   }
   WSEG_TRY(launch_finalize(st, out_tokens, out_lengths, s));
   WSEG_HIP_CHECK(hipEventRecord(m->ev[3], s));
