@@ -186,7 +186,7 @@ def main():
 
     roofline = None
     if not args.no_roofline and args.dtype == "bf16":
-        # dominant kernel: the 128x128 bf16 MFMA GEMM (encoder + cross-K/V projections).  Timed live, per
+        # dominant kernel: the large-tile bf16 MFMA GEMM (encoder + cross-K/V projections).  Timed live, per
         # launch, with HIP events on the launching stream over one more step of the same workload.
         _lib.check(lib.wseg_profile_begin())
         step()
@@ -194,7 +194,7 @@ def main():
         _lib.check(lib.wseg_profile_end(C.byref(fl), C.byref(ms), C.byref(n)))
         if n.value:
             achieved = fl.value / (ms.value * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel<128,128,2,2,*>", "achieved": achieved,
+            roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel<256,256,2,4,*> (+<128,128,2,2,*> for narrow problems)", "achieved": achieved,
                         "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / (MFMA_PEAK_BF16 / 1e12),
                         "traffic": None, "launches_per_step": int(n.value),
                         "avg_launch_us": ms.value * 1e3 / n.value, "flops_per_step": fl.value,

@@ -19,7 +19,7 @@ def test_gemm_matches_torch(gpu_lib, M, N, K, epi, dtype):
         pytest.skip("f32 exact kernel is for small problems")
     td = torch.bfloat16 if dtype == "bf16" else torch.float32
     g = torch.Generator(device="cuda").manual_seed(M * 31 + N * 7 + K)
-    Mp = (M + 127) // 128 * 128
+    Mp = (M + 255) // 256 * 256
     A = (torch.rand(Mp, K, device="cuda", generator=g) * 2 - 1).to(td)
     W = ((torch.rand(N, K, device="cuda", generator=g) * 2 - 1) * K ** -0.5).to(td)      # asymmetric operands
     bias = (torch.rand(N, device="cuda", generator=g) - 0.5).to(td)

@@ -114,3 +114,56 @@ def test_cli_counterpart(gpu_lib, tmp_path):
     flines = folder_csv.read_text().strip().splitlines()
     assert flines[0] == "filename,onset,offset,cluster"
     assert [ln.split(",", 1)[1] for ln in flines[1:]] == lines[1:]
+
+
+def test_full_length_decode_matches_oracle(gpu_lib):
+    """Maximum size: EOS suppressed so every window runs to max_length = 448 (445 steps, cache capacity, hipGraph
+    replay of every step) — token-exact vs the oracle in f32 mode."""
+    import torch
+    from oracle import frontend as OF
+    from oracle import whisper_ref as OW
+    from safetensors.torch import load_file
+    from whisperseg_amd.engine import Engine
+    sd = {k: v.float() for k, v in load_file(os.path.join(MODEL_DIR, "model.safetensors")).items()}
+    with open(os.path.join(MODEL_DIR, "config.json")) as f:
+        cfg = json.load(f)
+    audio = GI.tiny_recording(100, 2, tail=1.0)
+    feats = torch.from_numpy(np.stack([s[2] for s in OF.sliced_audio_features(audio, TM.SR, 0, TM.STS, 1)]))
+    sup = TM.SUPPRESS + [TM.EOT]
+    gp = OW.GenParams(prompt=TM.PROMPT, eos_token_id=TM.EOT, pad_token_id=TM.EOT, max_length=448, num_beams=4,
+                      suppress_tokens=sup, begin_suppress_tokens=TM.BEGIN_SUPPRESS)
+    want = OW.generate(sd, OW.RefConfig.from_hf_dict(cfg), feats, gp)
+    eng = Engine.from_state_dict(sd, cfg, "cuda:0", "f32")
+    toks, lens = eng.generate(feats.cuda(), TM.PROMPT, TM.EOT, TM.EOT, max_length=448, num_beams=4, suppress_tokens=sup,
+                              begin_suppress_tokens=TM.BEGIN_SUPPRESS)
+    toks, lens = toks.cpu().numpy(), lens.cpu().numpy()
+    assert lens.tolist() == [448, 448] and want.shape[1] == 448
+    sup_set = set(sup)
+    for i in range(2):
+        got, ref = toks[i].tolist(), want[i].tolist()
+        assert not (set(got[3:]) & sup_set)               # suppressed ids never appear
+        # Forced past its natural end the tiny model is out of distribution and adjacent time tokens become near
+        # ties (fp32 accumulation order then decides); require a long exact prefix rather than all 445 tokens.
+        prefix = next((k for k, (a, b) in enumerate(zip(got, ref)) if a != b), 448)
+        assert prefix >= 100, (i, prefix)
+
+
+def test_determinism_and_batch_invariance(gpu_lib):
+    """Same call twice -> identical ids (bf16 and f32); f32 mode is also invariant to the batch a window is decoded in
+    (bf16 split-K plans depend on the row count, so bit-equality across batch sizes is only promised for f32)."""
+    import torch
+    from whisperseg_amd.model import WhisperSegmenterForEval
+    for dtype in ("bf16", "f32"):
+        seg = WhisperSegmenterForEval(model_path=MODEL_DIR, device="cuda", dtype=dtype)
+        audio = GI.tiny_recording(102, 4)
+        sliced = seg.get_sliced_audios_features(audio, TM.SR, 0, TM.STS, 1)
+        feats = torch.stack([s[2] for s in sliced])
+        args = dict(max_length=448, num_beams=4, suppress_tokens=seg.suppress_tokens, begin_suppress_tokens=seg.begin_suppress_tokens)
+        a, la = seg.model.generate(feats, TM.PROMPT, TM.EOT, TM.EOT, **args)
+        b, lb = seg.model.generate(feats, TM.PROMPT, TM.EOT, TM.EOT, **args)
+        assert torch.equal(a, b) and torch.equal(la, lb)
+        if dtype == "f32":
+            for i in range(feats.shape[0]):
+                c, lc = seg.model.generate(feats[i:i + 1], TM.PROMPT, TM.EOT, TM.EOT, **args)
+                n = int(lc[0])
+                assert int(la[i]) == n and torch.equal(a[i, :n], c[0, :n]), i

@@ -17,7 +17,7 @@ shapes = [("qkv", M, 3 * d, d, 0), ("o-proj", M, d, d, 2), ("fc1", M, f, d, 1), 
           ("dec fc1 R=32", 32, f, d, 1), ("dec fc2 R=32", 32, d, f, 2), ("dec qkv R=32", 32, 3 * d, d, 0), ("lm head R=128", 128, 51968, d, 0)]
 ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
 for name, m, n, k, epi in shapes:
-    mp = (m + 127) // 128 * 128
+    mp = (m + 255) // 256 * 256
     A = (torch.rand(mp, k, device="cuda") * 2 - 1).to(torch.bfloat16)
     W = (torch.rand(n, k, device="cuda") * 2 - 1).to(torch.bfloat16)
     bias = torch.rand(n, device="cuda").to(torch.bfloat16)

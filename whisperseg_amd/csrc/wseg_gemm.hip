@@ -107,6 +107,77 @@ __device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, fl
   }
 }
 
+// 8 consecutive columns n0..n0+7 of row m (bf16 path, LDS-staged epilogue): 16-byte loads / stores.
+__device__ __forceinline__ void ld8_bf16(const bf16_t* p, float v[8]) {
+  const uint4 t = *(const uint4*)p;
+  const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+}
+__device__ __forceinline__ void st8_bf16(bf16_t* p, const float v[8]) {
+  uint32_t w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w[j] = (uint32_t)f2bf(v[2 * j]) | ((uint32_t)f2bf(v[2 * j + 1]) << 16);
+  *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <int EPI>
+__device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, float v[8]) {
+  typedef bf16_t T;
+  if (ep.bias) {
+    float b[8];
+    ld8_bf16((const T*)ep.bias + n0, b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += b[i];
+  }
+  if constexpr (EPI == EPI_STORE) {
+    st8_bf16((T*)ep.out + (size_t)m * ep.ldc + n0, v);
+  } else if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = gelu_for<T>(v[i]);
+    st8_bf16((T*)ep.out + (size_t)m * ep.ldc + n0, v);
+  } else if constexpr (EPI == EPI_RESID) {
+    float r[8];
+    ld8_bf16((const T*)ep.resid + (size_t)m * ep.ldc + n0, r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = r[i] + v[i];
+    st8_bf16((T*)ep.out + (size_t)m * ep.ldc + n0, v);
+  } else if constexpr (EPI == EPI_GELU_POS) {
+    float p[8];
+    ld8_bf16((const T*)ep.pos + (size_t)(m % ep.pos_rows) * ep.ldc + n0, p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = gelu_for<T>(v[i]) + p[i];
+    st8_bf16((T*)ep.out + (size_t)m * ep.ldc + n0, v);
+  } else if constexpr (EPI == EPI_QKV_ENC) {
+    const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
+    const int b = m / ep.t_len, t = m - b * ep.t_len;
+    const size_t bh = (size_t)b * ep.n_heads + h;
+    if (sec == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] *= ep.scale;
+      st8_bf16((T*)ep.q + (bh * ep.t_pad + t) * 64 + e, v);
+    } else if (sec == 1) {
+      st8_bf16((T*)ep.k + (bh * ep.t_pad + t) * 64 + e, v);
+    } else {
+      T* vt = (T*)ep.v + (bh * 64 + e) * ep.t_pad + t;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) vt[(size_t)i * ep.t_pad] = f2bf(v[i]);
+    }
+  } else if constexpr (EPI == EPI_KV_CROSS) {
+    const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
+    const int b = m / ep.t_len, t = m - b * ep.t_len;
+    T* dst = (T*)(sec == 0 ? ep.k : ep.v) + (((size_t)b * ep.n_heads + h) * ep.t_len + t) * 64 + e;
+    st8_bf16(dst, v);
+  } else if constexpr (EPI == EPI_F32) {
+    float* o = ep.out_f32 + (size_t)m * ep.ldc + n0;
+    *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    epi_apply<EPI, T>(ep, m, n0, v);
+    epi_apply<EPI, T>(ep, m, n0 + 4, v + 4);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // bf16 MFMA kernel
 // ------------------------------------------------------------------------------------------------
@@ -118,16 +189,17 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 // SPLIT: write fp32 partials [z][m_pad][n] (epilogue applied later by splitk_reduce_kernel).
 template <int BM, int BN, int WM, int WN, int EPI, bool SPLIT, int NST = 2>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, int lda,
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const bf16_t* __restrict__ A, int lda,
                                                         const bf16_t* __restrict__ W, int ldw,
                                                         int M, int N, int k_len, EpiParams ep,
                                                         float* __restrict__ part, int m_pad, int ntm) {
   constexpr int BK = 64;
   constexpr int TM = BM / WM, TN = BN / WN;      // wave tile
   constexpr int MI = TM / 16, NI = TN / 16;      // 16x16 MFMA tiles per wave
-  constexpr int A_IT = BM * 8 / 256, W_IT = BN * 8 / 256;
+  constexpr int NT = WM * WN * 64;               // threads per workgroup (4 or 8 waves)
+  constexpr int A_IT = BM * 8 / NT, W_IT = BN * 8 / NT;
   constexpr int NLD = A_IT + W_IT;
-  static_assert(WM * WN == 4 && A_IT >= 1 && W_IT >= 1, "tile config");
+  static_assert((WM * WN == 4 || WM * WN == 8) && A_IT >= 1 && W_IT >= 1, "tile config");
   __shared__ __attribute__((aligned(16))) bf16_t smem[NST * (BM + BN) * BK];
   bf16_t* sA = smem;                     // [NST][BM*64]
   bf16_t* sW = smem + NST * BM * BK;     // [NST][BN*64]
@@ -156,21 +228,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
   const bf16_t* w_src[W_IT];
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
-    const int p = it * 256 + tid, row = p >> 3, sl = (p & 7) ^ (row & 7);
+    const int p = it * NT + tid, row = p >> 3, sl = (p & 7) ^ (row & 7);
     a_src[it] = A + (size_t)(m0 + row) * lda + kbeg + sl * 8;
   }
 #pragma unroll
   for (int it = 0; it < W_IT; ++it) {
-    const int p = it * 256 + tid, row = p >> 3, sl = (p & 7) ^ (row & 7);
+    const int p = it * NT + tid, row = p >> 3, sl = (p & 7) ^ (row & 7);
     w_src[it] = W + (size_t)(n0 + row) * ldw + kbeg + sl * 8;
   }
   auto issue = [&](int kt, int buf) {
 #pragma unroll
     for (int it = 0; it < A_IT; ++it)
-      WSEG_GLDS16(a_src[it] + kt * BK, sA + buf * BM * BK + (it * 256 + wave * 64) * 8);
+      WSEG_GLDS16(a_src[it] + kt * BK, sA + buf * BM * BK + (it * NT + wave * 64) * 8);
 #pragma unroll
     for (int it = 0; it < W_IT; ++it)
-      WSEG_GLDS16(w_src[it] + kt * BK, sW + buf * BN * BK + (it * 256 + wave * 64) * 8);
+      WSEG_GLDS16(w_src[it] + kt * BK, sW + buf * BN * BK + (it * NT + wave * 64) * 8);
   };
 
   f32x4 acc[NI][MI];
@@ -206,42 +278,233 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     __builtin_amdgcn_s_barrier();
     const bf16_t* cA = sA + buf * BM * BK + (wm * TM) * BK;
     const bf16_t* cW = sW + buf * BN * BK + (wn * TN) * BK;
+    // Fragment reads are software-pipelined against the MFMAs: the activation fragments of BOTH k-steps of the tile
+    // and the next weight fragment are requested while the current weight fragment is being multiplied, so a wave
+    // only stalls on LDS at the head of a tile (the co-resident wave of the SIMD covers that).
+    auto lda = [&](int kk, int j) {
+      const int r = j * 16 + fr;
+      return *(const bf16x8*)(cA + r * BK + (((kk * 4 + fg) ^ (r & 7)) << 3));
+    };
+    auto ldw = [&](int kk, int i) {
+      const int r = i * 16 + fr;
+      return *(const bf16x8*)(cW + r * BK + (((kk * 4 + fg) ^ (r & 7)) << 3));
+    };
+    bf16x8 af0[MI], af1[MI];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[MI], wf[NI];
+    for (int j = 0; j < MI; ++j) af0[j] = lda(0, j);
+    bf16x8 wcur = ldw(0, 0);
 #pragma unroll
-      for (int j = 0; j < MI; ++j) {
-        const int r = j * 16 + fr;
-        af[j] = *(const bf16x8*)(cA + r * BK + (((kk * 4 + fg) ^ (r & 7)) << 3));
+    for (int i = 0; i < NI; ++i) {
+      const bf16x8 wnxt = (i + 1 < NI) ? ldw(0, i + 1) : ldw(1, 0);
+      if (i == NI - 1) {
+#pragma unroll
+        for (int j = 0; j < MI; ++j) af1[j] = lda(1, j);
       }
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int r = i * 16 + fr;
-        wf[i] = *(const bf16x8*)(cW + r * BK + (((kk * 4 + fg) ^ (r & 7)) << 3));
-      }
+      for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur, af0[j], acc[i][j], 0, 0, 0);
+      wcur = wnxt;
+    }
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NI; ++i) {
+      bf16x8 wnxt = wcur;
+      if (i + 1 < NI) wnxt = ldw(1, i + 1);
 #pragma unroll
-        for (int j = 0; j < MI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur, af1[j], acc[i][j], 0, 0, 0);
+      wcur = wnxt;
     }
     __builtin_amdgcn_s_barrier();
   }
 
   // epilogue: lane holds n = nb + i*16 + fg*4 + {0..3}, m = mb + j*16 + fr
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
+  if constexpr (!SPLIT && TN == 64) {
+    // Staged through LDS (free after the last barrier of the K loop): every wave transposes one 16-row x 64-column
+    // strip at a time so that 8 lanes cover one 128-byte output row with 16-byte accesses (bias, residual, store) —
+    // instead of 8-byte accesses scattered over 16 rows per instruction.
+    constexpr int LDT = TN + 4;                       // padded row stride (floats): conflict-free b128 writes
+    float* strip = (float*)smem + (size_t)wave * 16 * LDT;
+    const int rr = lane >> 3, cc = (lane & 7) * 8;
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
-      const int m = m0 + wm * TM + j * 16 + fr;
-      const int n = n0 + wn * TN + i * 16 + fg * 4;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if constexpr (SPLIT) {
-        *(float4*)(part + ((size_t)blockIdx.z * m_pad + m) * N + n) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        if (m < M) epi_apply<EPI, bf16_t>(ep, m, n, v);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        *(float4*)(strip + fr * LDT + i * 16 + fg * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      // same-wave LDS RAW: ds ops of one wave complete in order, the compiler waits lgkmcnt before the reads
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int r = hh * 8 + rr;
+        const float4 a = *(const float4*)(strip + r * LDT + cc), b = *(const float4*)(strip + r * LDT + cc + 4);
+        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        const int m = m0 + wm * TM + j * 16 + r;
+        if (m < M) epi_apply8<EPI>(ep, m, n0 + wn * TN + cc, v);
       }
     }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+        const int m = m0 + wm * TM + j * 16 + fr;
+        const int n = n0 + wn * TN + i * 16 + fg * 4;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        if constexpr (SPLIT) {
+          *(float4*)(part + ((size_t)blockIdx.z * m_pad + m) * N + n) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          if (m < M) epi_apply<EPI, bf16_t>(ep, m, n, v);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent variant for the large encoder GEMMs: the grid is one (256x256) or two (128x128) workgroups per CU and
+// every workgroup walks a strided sequence of tiles.  While the last K-tile of a tile is multiplied the first
+// K-tile of the NEXT tile is already streaming into the other LDS stage, and it keeps streaming under the LDS-staged
+// epilogue — with 20 K-tiles per tile (K = 1280) the exposed fill + epilogue were ~25 % of a tile.
+// Tile order: XCD x (workgroup id % 8, observed dispatch, speed only) owns a contiguous run of the m-fastest /
+// 8-row-group tile order; its workgroups interleave over that run, so tiles in flight on one L2 are neighbours.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_persist_kernel(const bf16_t* __restrict__ A, int lda,
+                                                                         const bf16_t* __restrict__ W, int ldw, int M, int N,
+                                                                         int K, EpiParams ep, int ntm) {
+  constexpr int BK = 64;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MI = TM / 16, NI = TN / 16;
+  constexpr int NT = WM * WN * 64;
+  constexpr int A_IT = BM * 8 / NT, W_IT = BN * 8 / NT;
+  constexpr int NLD = A_IT + W_IT;
+  constexpr int STAGE = (BM + BN) * BK;            // elements per LDS stage: [A tile | W tile]
+  static_assert(TN == 64, "staged epilogue needs 64-column wave tiles");
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int ntn = N / BN, ntiles = ntm * ntn, nk = K / BK;
+  // this workgroup's tile sequence
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int count = q + (xcd < r ? 1 : 0);
+  auto tile_coords = [&](int swz, int& m0, int& n0) {
+    constexpr int GM = 8;
+    const int per_group = GM * ntn, grp = swz / per_group, rem = swz - grp * per_group;
+    const int gm = min(GM, ntm - grp * GM);
+    m0 = (grp * GM + rem % gm) * BM;
+    n0 = (rem / gm) * BN;
+  };
+  const bf16_t* a_src[A_IT];
+  const bf16_t* w_src[W_IT];
+  auto set_src = [&](int m0, int n0) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int p = it * NT + tid, row = p >> 3, sl = (p & 7) ^ (row & 7);
+      a_src[it] = A + (size_t)(m0 + row) * lda + sl * 8;
+    }
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+      const int p = it * NT + tid, row = p >> 3, sl = (p & 7) ^ (row & 7);
+      w_src[it] = W + (size_t)(n0 + row) * ldw + sl * 8;
+    }
+  };
+  auto issue = [&](int kt, int buf) {
+    bf16_t* st = smem + buf * STAGE;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) WSEG_GLDS16(a_src[it] + kt * BK, st + (it * NT + wave * 64) * 8);
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) WSEG_GLDS16(w_src[it] + kt * BK, st + BM * BK + (it * NT + wave * 64) * 8);
+  };
+
+  int idx = loc;
+  if (idx >= count) return;
+  int m0, n0;
+  tile_coords(start + idx, m0, n0);
+  set_src(m0, n0);
+  issue(0, 0);
+  int g = 0;                                        // K-tiles consumed so far: stage parity
+  while (true) {
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nidx = idx + bpx;
+    const bool has_next = nidx < count;
+    int nm0 = 0, nn0 = 0;
+    if (has_next) tile_coords(start + nidx, nm0, nn0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = (g + kt) & 1;
+      if (kt + 1 < nk) {
+        issue(kt + 1, buf ^ 1);
+        wait_vmcnt<NLD>();
+      } else if (has_next) {
+        set_src(nm0, nn0);                          // all loads of the current tile are issued: retarget
+        issue(0, buf ^ 1);
+        wait_vmcnt<NLD>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      const bf16_t* cA = smem + buf * STAGE + (wm * TM) * BK;
+      const bf16_t* cW = smem + buf * STAGE + BM * BK + (wn * TN) * BK;
+      auto lda_f = [&](int kk, int j) {
+        const int rw = j * 16 + fr;
+        return *(const bf16x8*)(cA + rw * BK + (((kk * 4 + fg) ^ (rw & 7)) << 3));
+      };
+      auto ldw_f = [&](int kk, int i) {
+        const int rw = i * 16 + fr;
+        return *(const bf16x8*)(cW + rw * BK + (((kk * 4 + fg) ^ (rw & 7)) << 3));
+      };
+      bf16x8 af0[MI], af1[MI];
+#pragma unroll
+      for (int j = 0; j < MI; ++j) af0[j] = lda_f(0, j);
+      bf16x8 wcur = ldw_f(0, 0);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const bf16x8 wnxt = (i + 1 < NI) ? ldw_f(0, i + 1) : ldw_f(1, 0);
+        if (i == NI - 1) {
+#pragma unroll
+          for (int j = 0; j < MI; ++j) af1[j] = lda_f(1, j);
+        }
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur, af0[j], acc[i][j], 0, 0, 0);
+        wcur = wnxt;
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        bf16x8 wnxt = wcur;
+        if (i + 1 < NI) wnxt = ldw_f(1, i + 1);
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur, af1[j], acc[i][j], 0, 0, 0);
+        wcur = wnxt;
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    g += nk;
+    {
+      // LDS-staged epilogue in the stage consumed last ((g-1)&1); the other stage is receiving the next tile
+      constexpr int LDT = TN + 4;
+      float* strip = (float*)(smem + ((g - 1) & 1) * STAGE) + (size_t)wave * 16 * LDT;
+      const int rr = lane >> 3, cc = (lane & 7) * 8;
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          *(float4*)(strip + fr * LDT + i * 16 + fg * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int rw = hh * 8 + rr;
+          const float4 a = *(const float4*)(strip + rw * LDT + cc), b = *(const float4*)(strip + rw * LDT + cc + 4);
+          float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+          const int m = m0 + wm * TM + j * 16 + rw;
+          if (m < M) epi_apply8<EPI>(ep, m, n0 + wn * TN + cc, v);
+        }
+      }
+    }
+    if (!has_next) break;
+    __builtin_amdgcn_s_barrier();                   // every wave is done with its strip before the stage is refilled
+    m0 = nm0; n0 = nn0; idx = nidx;
   }
 }
 
@@ -326,9 +589,11 @@ static SkinnyPlan plan_skinny(const GemmArgs& g) {
   SkinnyPlan sp;
   // largest row tile that still yields >= 160 workgroups without splitting K; otherwise 128 rows + split-K
   sp.bm = g.M <= 32 ? 32 : (g.M <= 64 ? 64 : 128);
+  static const int force_bm = getenv("WSEG_SKINNY_BM") ? atoi(getenv("WSEG_SKINNY_BM")) : 0;   // tuning knob
   if (g.M > 64) {
     const int nt = g.N / 64;
     if (nt * cdiv(g.M, 128) < 160 && nt * cdiv(g.M, 64) >= 160) sp.bm = 64;
+    if (force_bm == 64 || force_bm == 128) sp.bm = force_bm;
   }
   sp.mt = cdiv(g.M, sp.bm);
   sp.m_pad = sp.mt * sp.bm;
@@ -442,13 +707,41 @@ static int launch_bf16(const GemmArgs& g, hipStream_t s) {
   const long big_blocks = (long)cdiv(g.M, 128) * (g.N / 128);
   if (g.M > 128 && g.N % 128 == 0 && big_blocks >= 256) {
     static const bool no_swz = getenv("WSEG_NO_XCD_SWIZZLE") != nullptr;
-    const int ntm = cdiv(g.M, 128);
-    dim3 grid(g.N / 128, ntm, 1);
-    if (!no_swz) grid = dim3((g.N / 128) * ntm, 1, 1);
+    static const bool big256 = getenv("WSEG_GEMM_128") == nullptr;   // 256x256 tiles by default where they fill the chip
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g_prof.on) { e0 = g_prof.get(); e1 = g_prof.get(); g_prof.flops.push_back(2.0 * g.M * g.N * g.K); (void)hipEventRecord(e0, s); }
-    hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 2, 2, EPI, false>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
-                       g.K, g.ep, (float*)nullptr, 0, no_swz ? 0 : ntm);
+    static const bool persist = getenv("WSEG_GEMM_NO_PERSIST") == nullptr;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0; hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+      if (n_cu <= 0) n_cu = 256;
+    }
+    if (big256 && g.N % 256 == 0 && (long)cdiv(g.M, 256) * (g.N / 256) >= 192) {
+      const int ntm = cdiv(g.M, 256), ntiles = ntm * (g.N / 256);
+      if (persist) {
+        int grid = ntiles < n_cu ? ntiles : n_cu;
+        grid &= ~7;
+        hipLaunchKernelGGL((gemm_bf16_persist_kernel<256, 256, 2, 4, EPI>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
+                           g.K, g.ep, ntm);
+      } else {
+        hipLaunchKernelGGL((gemm_bf16_kernel<256, 256, 2, 4, EPI, false>), dim3(ntiles), dim3(512), 0, s, A, g.lda, W, g.ldw,
+                           g.M, g.N, g.K, g.ep, (float*)nullptr, 0, ntm);
+      }
+    } else {
+      const int ntm = cdiv(g.M, 128), ntiles = ntm * (g.N / 128);
+      if (persist && !no_swz && ntiles >= 16) {
+        int grid = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;
+        grid &= ~7;
+        hipLaunchKernelGGL((gemm_bf16_persist_kernel<128, 128, 2, 2, EPI>), dim3(grid), dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
+                           g.K, g.ep, ntm);
+      } else {
+        dim3 grid(g.N / 128, ntm, 1);
+        if (!no_swz) grid = dim3(ntiles, 1, 1);
+        hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 2, 2, EPI, false>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
+                           g.K, g.ep, (float*)nullptr, 0, no_swz ? 0 : ntm);
+      }
+    }
     if (g_prof.on) (void)hipEventRecord(e1, s);
     WSEG_LAUNCH_CHECK();
     return WSEG_OK;

@@ -50,7 +50,7 @@ struct GemmArgs {
 };
 
 // dtype: WSEG_F32 (exact VALU kernel) or WSEG_BF16 (MFMA).  M may be any value as long as A has
-// round_up(M,128) readable rows; N % 128 == 0 rows of W readable; K % 64 == 0.
+// round_up(M,256) readable rows; N % 128 == 0 rows of W readable; K % 64 == 0.
 int launch_gemm(int dtype, EpiKind epi, const GemmArgs& g, hipStream_t s);
 // Split-K partial sums only (bf16 decoder rows): part[z][m_pad][N] fp32 in g.splitk_ws, no epilogue.  The consumer
 // kernel (decoder self-/cross-attention) finishes the reduction itself.  Returns false in *ok when the shape is not

@@ -66,8 +66,8 @@ void make_plan(const wseg_model* m, int W, int nb, int L, char* base, Plan& p) {
   const wseg_model_config& c = m->cfg;
   const size_t es = m->es;
   const size_t d = c.d_model, H = c.n_heads, ffn = c.ffn;
-  const size_t M1p = align_up((size_t)W * c.spec_cols, 128), Mp = align_up((size_t)W * c.enc_positions, 128);
-  const size_t R = (size_t)W * nb, Rp = align_up(R, 128);
+  const size_t M1p = align_up((size_t)W * c.spec_cols, 256), Mp = align_up((size_t)W * c.enc_positions, 256);
+  const size_t R = (size_t)W * nb, Rp = align_up(R, 256);
   char* cur = base;
   auto take = [&](size_t bytes) { char* q = cur; cur += align_up(bytes, 256); return q; };
   // encoder: a1 | h1 | a2 are dead once conv2 has run; hbuf reuses their space.
