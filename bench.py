@@ -125,7 +125,7 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     lib = _lib.load(require_device=True)
-    distributed = world > 1
+    distributed = world > 1 or torch.distributed.is_initialized()
 
     sr, sts = args.sr, args.spec_time_step
     win_len = int(1000 * sts * sr)

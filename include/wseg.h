@@ -80,6 +80,15 @@ int wseg_logmel_f32(const wseg_logmel_desc* d, const float* audio, int64_t n_aud
                     void* scratch, size_t scratch_bytes, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Rational polyphase resampler (audio ingest).
+ * Replaces the resampling half of `librosa.load(path, sr=target)` at reference scripts/segment.py:48,61 and
+ * evaluate.py:58.  y[m] = sum_k taps[(m + pre_remove) * down - pre_pad - k * up] * x[k], all device pointers.
+ * The Kaiser-windowed-sinc taps and the two alignment integers are produced by whisperseg_amd/resample.py.
+ * ---------------------------------------------------------------------------------------------- */
+int wseg_resample_f32(const float* x, int64_t n_in, const float* taps, int32_t n_taps, int32_t up, int32_t down,
+                      int32_t pre_pad, int32_t pre_remove, float* y, int64_t n_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Whisper encoder-decoder.
  * Replaces HF WhisperForConditionalGeneration as the reference drives it:
  *   construction  reference model.py:626-644 (WhisperSegmenter.__init__, from_pretrained)

@@ -55,9 +55,11 @@ def main(argv=None):
     if args.audio_path is None:
         assert args.audio_folder is not None, "Either audio_path or audio_folder needs to be specified!"
         columns, rows = ["filename", "onset", "offset", "cluster"], []
-        for path in glob.glob(args.audio_folder + "/*.wav") + glob.glob(args.audio_folder + "/*.WAV"):
-            audio, sr = load_wav(path)
-            res = segmenter.segment(audio, sr, **kwargs)
+        paths = glob.glob(args.audio_folder + "/*.wav") + glob.glob(args.audio_folder + "/*.WAV")
+        loaded = [load_wav(path) for path in paths]
+        # same rows as the reference's serial loop, but the windows of all files share decode batches
+        results = segmenter.segment_batch([a for a, _ in loaded], [sr for _, sr in loaded], **kwargs)
+        for path, res in zip(paths, results):
             name = os.path.basename(path)
             rows += [(name, on, off, c) for on, off, c in zip(res["onset"], res["offset"], res["cluster"])]
     else:

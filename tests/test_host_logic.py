@@ -103,3 +103,34 @@ def test_scoring_helpers():
     assert got == [695.0, 1400.0, 1395.0, 0.49642857142857144, 0.4982078853046595, 0.4973166368515206]
     got = [float(v) for v in seg.frame_score(copy.deepcopy(pred), copy.deepcopy(lab), target_cluster="b", time_per_frame_for_scoring=0.001)]
     assert got == [300.0, 500.0, 1000.0, 0.6, 0.3, 0.4]
+
+
+def test_evaluate_accumulates_like_reference(tmp_path):
+    """whisperseg_amd.evaluate.evaluate with a stub segmenter: pooled counts and F1 (reference evaluate.py:9-51)."""
+    import json as _json
+    from whisperseg_amd.evaluate import evaluate, get_audio_and_label_paths, read_label
+
+    class Stub(SegmenterBase):
+        def __init__(self, preds):
+            super().__init__()
+            self.preds = iter(preds)
+
+        def segment(self, audio, sr, **kw):
+            return next(self.preds)
+
+    labels = [{"onset": [0.1, 1.0], "offset": [0.5, 1.5], "cluster": ["a", "b"], "sr": 16000},
+              {"onset": [0.2], "offset": [0.9], "cluster": ["a"], "sr": 16000, "spec_time_step": 0.01}]
+    preds = [{"onset": [0.1, 1.2], "offset": [0.5, 1.5], "cluster": ["a", "b"]}, {"onset": [0.2], "offset": [0.9], "cluster": ["a"]}]
+    res = evaluate([np.zeros(10), np.zeros(10)], labels, Stub(preds), 8, 448, 1)
+    assert res["segment_wise"][:3] == [2, 3, 3] and abs(res["segment_wise"][5] - 2 / 3) < 1e-12
+    tp, n_pred, n_lab = res["frame_wise"][:3]
+    assert (tp, n_pred, n_lab) == (400 + 300 + 700, 400 + 300 + 700, 400 + 500 + 700)
+    (tmp_path / "x.wav").write_bytes(b"")
+    (tmp_path / "x.json").write_text(_json.dumps({"onset": [0], "offset": [1]}))
+    (tmp_path / "y.wav").write_bytes(b"")
+    (tmp_path / "y.csv").write_text("onset,offset,cluster\n0.5,0.75,3\n")
+    a, l = get_audio_and_label_paths(str(tmp_path))
+    assert sorted(os.path.basename(p) for p in l) == ["x.json", "y.csv"]
+    lab = read_label(str(tmp_path / "y.csv"))
+    assert lab["onset"] == [0.5] and lab["cluster"] == ["3"] and lab["species"] == "unknown"
+    assert read_label(str(tmp_path / "x.json"))["cluster"] == ["Vocal"]

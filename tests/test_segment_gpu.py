@@ -167,3 +167,15 @@ def test_determinism_and_batch_invariance(gpu_lib):
                 c, lc = seg.model.generate(feats[i:i + 1], TM.PROMPT, TM.EOT, TM.EOT, **args)
                 n = int(lc[0])
                 assert int(la[i]) == n and torch.equal(a[i, :n], c[0, :n]), i
+
+
+def test_segment_batch_pools_files(gpu_lib):
+    """Continuous batching across recordings: pooled decode == per-file segment() (exact in f32 mode)."""
+    from whisperseg_amd.model import WhisperSegmenter
+    seg = WhisperSegmenter(MODEL_DIR, device="cuda", device_ids=[0], dtype="f32")
+    audios = [GI.tiny_recording(100, 3), GI.tiny_recording(103, 1), np.zeros(0, np.float32), GI.tiny_recording(105, 2)]
+    for kw in (dict(batch_size=3), dict(batch_size=5, num_trials=3), dict(batch_size=2, num_beams=1)):
+        single = [seg.segment(a, TM.SR, **kw) for a in audios]
+        pooled = seg.segment_batch(audios, TM.SR, **kw)
+        assert pooled == single, kw
+    assert sum(len(p["onset"]) for p in pooled) > 5

@@ -34,6 +34,8 @@ SYMBOLS = {
     "wseg_logmel_scratch_bytes": (C.c_size_t, [C.POINTER(LogmelDesc), C.c_int32, C.c_int64]),
     "wseg_logmel_f32": (C.c_int, [C.POINTER(LogmelDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int64,
                                   C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "wseg_resample_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_void_p, C.c_int64, C.c_void_p]),
     "wseg_model_create": (C.c_int, [C.POINTER(ModelConfig), C.POINTER(C.c_void_p)]),
     "wseg_model_destroy": (None, [C.c_void_p]),
     "wseg_model_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),

@@ -23,15 +23,25 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("WSEG_FORCE_DIST") == "1"      # exercise the RCCL collectives even at world size 1
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+def _single():
+    """True when no collective is needed (WSEG_FORCE_DIST=1 keeps them on at world size 1, for validation)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size() == 1 and os.environ.get("WSEG_FORCE_DIST") != "1"
 
 
 def my_shard(n_items, rank, world):
@@ -42,7 +52,7 @@ def my_shard(n_items, rank, world):
 
 def broadcast_pcm(audio, device, src=0):
     """Rank `src` holds the recording (numpy float32); every rank returns it as a device tensor."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _single():
         return torch.as_tensor(np.ascontiguousarray(audio, dtype=np.float32)).to(device)
     n = torch.zeros(1, dtype=torch.int64, device=device)
     if dist.get_rank() == src:
@@ -60,7 +70,7 @@ def broadcast_pcm(audio, device, src=0):
 def broadcast_weights(weights, src=0):
     """In-place broadcast of a prepared weight dict (same keys/shapes on every rank) from rank `src`.
     large bf16 = 3.08 GB: one pipelined ring broadcast is bounded by a single xGMI link (~153 GB/s)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if not _single():
         for name in sorted(weights):
             dist.broadcast(weights[name], src)
     return weights
@@ -71,7 +81,7 @@ def gather_rows(tokens, lengths, n_total):
 
     tokens int32 [n_local, L], lengths int32 [n_local] for this rank's shard of n_total windows.
     Returns (tokens [n_total, L], lengths [n_total]) on every rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _single():
         return tokens, lengths
     world = dist.get_world_size()
     per = int(np.ceil(n_total / world)) if n_total > 0 else 0

@@ -70,7 +70,10 @@ class SegmenterBase:
         """-> list of (trial_id, offset_time, features, clip_seconds); `features` is a float32 [80, 1000]
         DEVICE tensor (a view into one batch tensor) instead of a numpy array."""
         device = self.device_list[0]
-        pcm = torch.as_tensor(np.ascontiguousarray(audio, dtype=np.float32)).to(device, non_blocking=True)
+        if torch.is_tensor(audio):      # already a tensor (e.g. straight out of whisperseg_amd.resample): no host round trip
+            pcm = audio.to(device=device, dtype=torch.float32).contiguous()
+        else:
+            pcm = torch.as_tensor(np.ascontiguousarray(audio, dtype=np.float32)).to(device, non_blocking=True)
         out = self.sliced_features_from_device_pcm(pcm, sr, min_frequency, spec_time_step, num_trials)
         return out["shard"]
 
@@ -215,6 +218,44 @@ class SegmenterBase:
                                            num_trials, eps, time_per_frame_for_voting, consolidation_method)
         prediction = postprocess.correct_fft_blur(prediction, get_n_fft_given_sr(sr), sr)
         return postprocess.drop_consecutive_duplicates(prediction)
+
+    # ---- many recordings at once (continuous batching across files) -----------------
+    @torch.no_grad()
+    def segment_batch(self, audios, srs, min_frequency=None, spec_time_step=None, min_segment_length=None, eps=None,
+                      time_per_frame_for_voting=None, consolidation_method="clustering", max_length=448, batch_size=4,
+                      num_trials=1, num_beams=4, top_k=1, top_p=1.0, length_penalty=1.0, status_monitor=None):
+        """segment() for a list of recordings with their windows POOLED into shared decode batches.
+
+        The reference batches only inside one file (model.py:653) and its folder mode is a serial loop
+        (scripts/segment.py:39-56), so short clips decode with 1-2 windows per launch.  Windows are independent, hence
+        pooling changes nothing but the batch a window is decoded in: the per-recording results equal segment()'s
+        (bit-identical in f32 mode).  `srs` is one int or a list.  Returns a list of prediction dicts."""
+        if isinstance(srs, (int, float)):
+            srs = [srs] * len(audios)
+        defaults = self.default_segmentation_config
+        if min_frequency is None:
+            min_frequency = defaults.get("min_frequency", 0)
+        if spec_time_step is None:
+            spec_time_step = defaults.get("spec_time_step", 0.0025)
+        if min_segment_length is None:
+            min_segment_length = spec_time_step * RATIO_DECODING_TIME_STEP_TO_SPEC_TIME_STEP
+        if eps is None:
+            eps = spec_time_step * RATIO_DECODING_TIME_STEP_TO_SPEC_TIME_STEP * 4
+        if time_per_frame_for_voting is None:
+            time_per_frame_for_voting = spec_time_step
+        per_file = [self.get_sliced_audios_features(a, sr, min_frequency, spec_time_step, num_trials) for a, sr in zip(audios, srs)]
+        pooled = [w for windows in per_file for w in windows]
+        texts = self.generate_segment_text(pooled, batch_size, max_length, num_beams, top_k, top_p, length_penalty,
+                                           status_monitor) if pooled else []
+        out, pos = [], 0
+        for audio, sr, windows in zip(audios, srs, per_file):
+            mine = texts[pos:pos + len(windows)]
+            pos += len(windows)
+            pred = self.parse_generation(mine, windows, min_segment_length, len(audio) / sr, spec_time_step, num_trials, eps,
+                                         time_per_frame_for_voting, consolidation_method)
+            pred = postprocess.correct_fft_blur(pred, get_n_fft_given_sr(sr), sr)
+            out.append(postprocess.drop_consecutive_duplicates(pred))
+        return out
 
     # ---- scoring helpers (reference model.py:474-569) --------------------------------------------
     def segment_score(self, prediction, label, target_cluster=None, tolerance=None):
