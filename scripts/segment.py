@@ -21,12 +21,11 @@ from whisperseg_amd.wavio import load_wav  # noqa: E402
 def build_parser():
     p = argparse.ArgumentParser()
     p.add_argument("--model_path")
-    p.add_argument("--audio_path", default=None, help="The file path to the audio .wav file ('-' reads stdin)")
-    p.add_argument("--audio_folder", default=None,
-                   help="Folder with .wav files; used when --audio_path is not given.")
+    p.add_argument("--audio_path", default=None, help="one .wav file, or '-' to read a wav from stdin")
+    p.add_argument("--audio_folder", default=None, help="directory of .wav/.WAV files (when --audio_path is absent)")
     p.add_argument("--csv_save_path")
-    p.add_argument("--device", help="cpu or cuda", default="cuda")
-    p.add_argument("--device_ids", help="a list of GPU ids", type=int, nargs="+", default=[0, ])
+    p.add_argument("--device", default="cuda", help="'cuda' (an MI355X is required; 'cpu' raises)")
+    p.add_argument("--device_ids", type=int, nargs="+", default=[0, ], help="GPU indices, one model replica each")
     p.add_argument("--batch_size", default=8, type=int)
     p.add_argument("--min_frequency", default=None, type=int)
     p.add_argument("--spec_time_step", default=None, type=float)

@@ -40,3 +40,20 @@ def test_product_fails_loudly_without_device():
     from whisperseg_amd.model import WhisperSegmenter
     with pytest.raises(_lib.WsegError):
         WhisperSegmenter(os.path.join(ROOT, "tests", "golden", "tiny_model"), device="cpu")
+
+
+def test_fast_class_rejects_ct2_directory(tmp_path):
+    """A CTranslate2-converted directory (hf_model/ with config + tokenizer but no HF weights) cannot be read; the
+    constructor raises so that scripts/segment.py's try-Fast-then-fallback idiom behaves as upstream."""
+    import json
+    import pytest
+    from whisperseg_amd.model import WhisperSegmenterFast, resolve_model_dir
+    hf = tmp_path / "hf_model"
+    hf.mkdir()
+    (hf / "config.json").write_text(json.dumps({"total_spec_columns": 1000}))
+    (tmp_path / "model.bin").write_bytes(b"ct2")
+    assert resolve_model_dir(str(tmp_path)) == str(hf)
+    with pytest.raises(FileNotFoundError):
+        WhisperSegmenterFast(str(tmp_path), device="cuda")
+    with pytest.raises(FileNotFoundError):
+        resolve_model_dir(str(tmp_path / "nope"))

@@ -179,3 +179,26 @@ def test_segment_batch_pools_files(gpu_lib):
         pooled = seg.segment_batch(audios, TM.SR, **kw)
         assert pooled == single, kw
     assert sum(len(p["onset"]) for p in pooled) > 5
+
+
+def test_for_eval_accepts_in_memory_hf_style_model(gpu_lib, runs):
+    """reference model.py:573-601: WhisperSegmenterForEval(model=..., tokenizer=...) with an object exposing
+    .state_dict() / .config / .generation_config (what train.py hands over) — weights are converted on the fly."""
+    import types
+    import torch
+    from safetensors.torch import load_file
+    from whisperseg_amd.model import WhisperSegmenterForEval
+    from whisperseg_amd.tokenizer import WhisperSegTokenizer
+    with open(os.path.join(MODEL_DIR, "config.json")) as f:
+        cfg = json.load(f)
+    sd = load_file(os.path.join(MODEL_DIR, "model.safetensors"))
+    fake = types.SimpleNamespace(state_dict=lambda: {k: torch.nn.Parameter(v.float(), requires_grad=False) for k, v in sd.items()},
+                                 config=cfg, generation_config=types.SimpleNamespace(suppress_tokens=TM.SUPPRESS,
+                                                                                     begin_suppress_tokens=TM.BEGIN_SUPPRESS))
+    seg = WhisperSegmenterForEval(model=fake, tokenizer=WhisperSegTokenizer.from_pretrained(MODEL_DIR), dtype="f32")
+    run = runs[1]
+    got = seg.segment(GI.tiny_recording(run["seed"], run["n_windows"]), TM.SR, **run["kwargs"])
+    assert got == run["expected"]
+    seg.update_cluster_codebook({"x": 0, "y": 1, "z": 2})
+    renamed = seg.segment(GI.tiny_recording(run["seed"], run["n_windows"]), TM.SR, **run["kwargs"])
+    assert renamed["cluster"] == [{"a": "x", "b": "y", "c": "z"}[c] for c in got["cluster"]]

@@ -69,6 +69,21 @@ __global__ void advance_kernel(DecodeState st) {
 // Self-attention, one wave per (row, head).  8 lanes cover one 128-byte K/V row, so one wave instruction
 // gathers 8 cache rows (each found through the ancestry table) and 4 instructions are in flight per lane.
 // ------------------------------------------------------------------------------------------------
+// streaming variant: cross-attention K/V (82 MB per window per step) are read exactly once per step by one workgroup, far more
+// than L2 + Infinity Cache hold, so the loads are marked non-temporal.
+template <typename T> __device__ __forceinline__ void load8_nt(const T* p, float v[8]);
+template <> __device__ __forceinline__ void load8_nt<float>(const float* p, float v[8]) {
+  typedef float nt_f4 __attribute__((ext_vector_type(4)));
+  const nt_f4 a = __builtin_nontemporal_load((const nt_f4*)p), b = __builtin_nontemporal_load((const nt_f4*)p + 1);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+template <> __device__ __forceinline__ void load8_nt<bf16_t>(const bf16_t* p, float v[8]) {
+  typedef unsigned int nt_u4 __attribute__((ext_vector_type(4)));
+  const nt_u4 t = __builtin_nontemporal_load((const nt_u4*)p);
+  const uint32_t w[4] = {t[0], t[1], t[2], t[3]};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+}
 template <typename T> __device__ __forceinline__ void load8(const T* p, float v[8]);
 template <> __device__ __forceinline__ void load8<float>(const float* p, float v[8]) {
   const float4 a = ((const float4*)p)[0], b = ((const float4*)p)[1];
@@ -260,7 +275,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(DecodeState st, con
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int t = t0 + u * 32 + wave * 8 + rowl;
-      if (t < Tk) load8<T>(Kb + (size_t)t * 64 + sub * 8, kv[u]);
+      if (t < Tk) load8_nt<T>(Kb + (size_t)t * 64 + sub * 8, kv[u]);
       else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) kv[u][e] = 0.f;
@@ -302,7 +317,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(DecodeState st, con
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int t = t0 + u * 32 + wave * 8 + rowl;
-      if (t < Tk) load8<T>(Vb + (size_t)t * 64 + sub * 8, vv[u]);
+      if (t < Tk) load8_nt<T>(Vb + (size_t)t * 64 + sub * 8, vv[u]);
       else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) vv[u][e] = 0.f;
