@@ -192,11 +192,23 @@ def main():
         step()
         fl, ms, n = C.c_double(), C.c_double(), C.c_int64()
         _lib.check(lib.wseg_profile_end(C.byref(fl), C.byref(ms), C.byref(n)))
+        traffic, traffic_note = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
+        if os.path.exists(tpath) and args.model == "large" and W == 120:
+            # PMC counters cannot be collected live next to the timing (separate rocprofv3 passes): use the committed
+            # pass over the same GEMM shapes (tools/pmc_traffic.sh), averaged over the four per-layer encoder GEMMs.
+            with open(tpath) as f:
+                pl = json.load(f)["per_launch"]
+            keys = [k for k in ("qkv", "o-proj", "fc1", "fc2") if k in pl]
+            traffic = sum(pl[k]["hbm_bytes"] for k in keys) / len(keys)
+            traffic_note = ("bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, committed pass "
+                            "profiles/r01_gemm_hbm_traffic.json; algorithmic bytes per launch %.3g"
+                            % (sum(pl[k]["algorithmic_bytes"] for k in keys) / len(keys)))
         if n.value:
             achieved = fl.value / (ms.value * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel<256,256,2,4,*> (+<128,128,2,2,*> for narrow problems)", "achieved": achieved,
                         "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / (MFMA_PEAK_BF16 / 1e12),
-                        "traffic": None, "launches_per_step": int(n.value),
+                        "traffic": traffic, "traffic_note": traffic_note, "launches_per_step": int(n.value),
                         "avg_launch_us": ms.value * 1e3 / n.value, "flops_per_step": fl.value,
                         "end_to_end_frac": windows_per_s / world * (enc_f + ckv_f + dec_f) / MFMA_PEAK_BF16}
     cpu = None

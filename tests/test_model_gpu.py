@@ -114,3 +114,24 @@ def test_real_vocab_logits_bf16(gpu_lib):
     assert (got - want).abs().max().item() <= 8e-2 * max(scale, 1.0)
     # beams of one window are identical at the first step
     assert torch.equal(got[0], got[1])
+
+
+def test_base_geometry_bf16(gpu_lib):
+    """BASELINE config[1] geometry (whisperseg-base: d 512, 8 heads, 6+6 layers, ffn 2048, vocab 51865), seeded random
+    weights, bf16: encoder output and first-step logits vs the oracle; beams of a window agree at the first step."""
+    cfg = hf_cfg(d=512, heads=8, layers=6, ffn=2048, vocab=51865)
+    rc, sd, eng = make(cfg, "bf16", seed=11)
+    x = feats(2, seed=13)
+    want_enc = R.encoder_forward(sd, rc, x)
+    got_enc = eng.encode(x.cuda()).float().cpu()
+    assert (got_enc - want_enc).abs().max().item() <= 0.1 * max(1.0, want_enc.abs().max().item())
+    prompt, eos = [50258, 50259, 50363], 50257
+    gp = R.GenParams(prompt=prompt, eos_token_id=eos, pad_token_id=eos, max_length=5, num_beams=4)
+    _, want = R.generate(sd, rc, x, gp, return_first_logits=True)
+    toks, lens, got = eng.generate(x.cuda(), prompt, eos, eos, max_length=5, num_beams=4, return_first_logits=True)
+    got = got.cpu()
+    assert (got - want).abs().max().item() <= 0.1 * max(1.0, want.abs().max().item())
+    # cosine similarity of the logit rows: a transposed / mis-indexed head would destroy it
+    cos = torch.nn.functional.cosine_similarity(got, want, dim=1)
+    assert cos.min().item() > 0.999
+    assert lens.tolist() == [5, 5]

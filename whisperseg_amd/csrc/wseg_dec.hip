@@ -103,9 +103,22 @@ __device__ __forceinline__ void reduce8(const PartialInfo& pi, int row, int col,
   for (int e = 0; e < 8; ++e) v[e] = 0.f;
   const float* pp = pi.part + (size_t)row * pi.n + col;
   const size_t zs = (size_t)pi.m_pad * pi.n;
-  for (int z = 0; z < pi.splits; ++z) {
-    const float4 a = *(const float4*)(pp + z * zs), b = *(const float4*)(pp + z * zs + 4);
-    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+  // two splits (4 independent 16-byte loads) in flight at a time; loads are unconditional (clamped), the adds are masked
+  for (int z0 = 0; z0 < pi.splits; z0 += 2) {
+    float4 a[2], b[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int zc = min(z0 + u, pi.splits - 1);
+      a[u] = *(const float4*)(pp + zc * zs);
+      b[u] = *(const float4*)(pp + zc * zs + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (z0 + u < pi.splits) {
+        v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w;
+        v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
+      }
+    }
   }
   if (bias) {
     float bb[8];
@@ -168,14 +181,13 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
     float kv[4][8];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
+      // unconditional clamped loads (see the cross-attention kernel); the fused step's own key is patched in after
       const int t = t0 + u * 8 + rowl;
+      const int tl = min(t, fused ? max(n - 2, 0) : n - 1);
+      load8<T>(kc + (((size_t)srow[tl] * H + h) * L + tl) * 64 + sub * 8, kv[u]);
       if (fused && t == n - 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) kv[u][e] = snk[sub * 8 + e];
-      } else if (t < n) load8<T>(kc + (((size_t)srow[t] * H + h) * L + t) * 64 + sub * 8, kv[u]);
-      else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) kv[u][e] = 0.f;
       }
     }
 #pragma unroll
@@ -204,13 +216,11 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int t = t0 + u * 8 + rowl;
+      const int tl = min(t, fused ? max(n - 2, 0) : n - 1);
+      load8<T>(vc + (((size_t)srow[tl] * H + h) * L + tl) * 64 + sub * 8, vv[u]);
       if (fused && t == n - 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) vv[u][e] = snv[sub * 8 + e];
-      } else if (t < n) load8<T>(vc + (((size_t)srow[t] * H + h) * L + t) * 64 + sub * 8, vv[u]);
-      else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) vv[u][e] = 0.f;
       }
     }
 #pragma unroll
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
 // reads 8 consecutive rows = 1 KiB fully coalesced per instruction and 4 rows are in flight per lane.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int NB>
-__global__ __launch_bounds__(256) void dec_cross_attn_kernel(DecodeState st, const T* __restrict__ q, const T* __restrict__ ck,
+__global__ __launch_bounds__(256, 5) void dec_cross_attn_kernel(DecodeState st, const T* __restrict__ q, const T* __restrict__ ck,
                                                              const T* __restrict__ cv, T* __restrict__ out, int H, int Tk, int d,
                                                              PartialInfo pi, const T* __restrict__ q_bias, float scale) {
   __shared__ float sc[NB][512];
@@ -256,17 +266,16 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(DecodeState st, con
   const T* Vb = cv + ((size_t)w * H + h) * Tk * 64;
   // this lane's 8-dim slice of every beam's (pre-scaled) query
   float qv[NB][8];
+  if (pi.part != nullptr) {
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    if (j < nb && pi.part != nullptr) {
-      reduce8<T>(pi, w * nb + j, h * 64 + sub * 8, q_bias, qv[j]);
+    for (int j = 0; j < NB; ++j) {
+      reduce8<T>(pi, w * nb + min(j, nb - 1), h * 64 + sub * 8, q_bias, qv[j]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) qv[j][e] = El<T>::rnd(qv[j][e] * scale);
-    } else if (j < nb) load8<T>(q + (size_t)(w * nb + j) * d + h * 64 + sub * 8, qv[j]);
-    else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) qv[j][e] = 0.f;
     }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) load8<T>(q + (size_t)(w * nb + min(j, nb - 1)) * d + h * 64 + sub * 8, qv[j]);
   }
   // scores: rows t = it*32 + wave*8 + rowl
   constexpr int U = 4;                                  // K/V rows in flight per lane (8 costs occupancy: measured 1.6x slower)
@@ -274,12 +283,10 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(DecodeState st, con
     float kv[U][8];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int t = t0 + u * 32 + wave * 8 + rowl;
-      if (t < Tk) load8_nt<T>(Kb + (size_t)t * 64 + sub * 8, kv[u]);
-      else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) kv[u][e] = 0.f;
-      }
+      // unconditional (clamped) loads: a branch around each load makes the compiler wait vmcnt(0) per load and
+      // serialises the U rows that are meant to be in flight together; out-of-range rows are discarded below
+      const int t = min(t0 + u * 32 + wave * 8 + rowl, Tk - 1);
+      load8_nt<T>(Kb + (size_t)t * 64 + sub * 8, kv[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -316,23 +323,19 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(DecodeState st, con
     float vv[U][8];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int t = t0 + u * 32 + wave * 8 + rowl;
-      if (t < Tk) load8_nt<T>(Vb + (size_t)t * 64 + sub * 8, vv[u]);
-      else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) vv[u][e] = 0.f;
-      }
+      const int t = min(t0 + u * 32 + wave * 8 + rowl, Tk - 1);
+      load8_nt<T>(Vb + (size_t)t * 64 + sub * 8, vv[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int t = t0 + u * 32 + wave * 8 + rowl;
-      if (t < Tk) {
+      const bool ok = t < Tk;
+      const int tc = ok ? t : Tk - 1;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          const float p = j < nb ? sc[j][t] : 0.f;
+      for (int j = 0; j < NB; ++j) {
+        const float p = (ok && j < nb) ? sc[j][tc] : 0.f;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[j][e] = fmaf(p, vv[u][e], acc[j][e]);
-        }
+        for (int e = 0; e < 8; ++e) acc[j][e] = fmaf(p, vv[u][e], acc[j][e]);
       }
     }
   }

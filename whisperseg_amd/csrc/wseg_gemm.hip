@@ -367,7 +367,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const bf16_t* _
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_persist_kernel(const bf16_t* __restrict__ A, int lda,
                                                                          const bf16_t* __restrict__ W, int ldw, int M, int N,
-                                                                         int K, EpiParams ep, int ntm) {
+                                                                         int K, EpiParams ep, int ntm, int GM) {
   constexpr int BK = 64;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 16, NI = TN / 16;
@@ -388,7 +388,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_persist_kernel(const b
   const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   const int count = q + (xcd < r ? 1 : 0);
   auto tile_coords = [&](int swz, int& m0, int& n0) {
-    constexpr int GM = 8;
     const int per_group = GM * ntn, grp = swz / per_group, rem = swz - grp * per_group;
     const int gm = min(GM, ntm - grp * GM);
     m0 = (grp * GM + rem % gm) * BM;
@@ -711,6 +710,11 @@ static int launch_bf16(const GemmArgs& g, hipStream_t s) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g_prof.on) { e0 = g_prof.get(); e1 = g_prof.get(); g_prof.flops.push_back(2.0 * g.M * g.N * g.K); (void)hipEventRecord(e0, s); }
     static const bool persist = getenv("WSEG_GEMM_NO_PERSIST") == nullptr;
+    // m-tiles per tile group of the persistent order.  The weight matrix of these GEMMs is small (<= 13 MB) next to the
+    // activations (154 MB at 120 windows): with 2-row groups the 32 tiles in flight on one XCD span ~2 activation
+    // tiles x many weight tiles, so every activation tile crosses the fabric once and only the weights are re-streamed
+    // (PMC FETCH_SIZE: see profiles/).
+    static const int group_m = getenv("WSEG_GEMM_GROUP_M") ? atoi(getenv("WSEG_GEMM_GROUP_M")) : 2;
     static int n_cu = 0;
     if (n_cu == 0) {
       int dev = 0; hipDeviceProp_t prop;
@@ -723,7 +727,7 @@ static int launch_bf16(const GemmArgs& g, hipStream_t s) {
         int grid = ntiles < n_cu ? ntiles : n_cu;
         grid &= ~7;
         hipLaunchKernelGGL((gemm_bf16_persist_kernel<256, 256, 2, 4, EPI>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
-                           g.K, g.ep, ntm);
+                           g.K, g.ep, ntm, group_m);
       } else {
         hipLaunchKernelGGL((gemm_bf16_kernel<256, 256, 2, 4, EPI, false>), dim3(ntiles), dim3(512), 0, s, A, g.lda, W, g.ldw,
                            g.M, g.N, g.K, g.ep, (float*)nullptr, 0, ntm);
@@ -734,7 +738,7 @@ static int launch_bf16(const GemmArgs& g, hipStream_t s) {
         int grid = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;
         grid &= ~7;
         hipLaunchKernelGGL((gemm_bf16_persist_kernel<128, 128, 2, 2, EPI>), dim3(grid), dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
-                           g.K, g.ep, ntm);
+                           g.K, g.ep, ntm, group_m);
       } else {
         dim3 grid(g.N / 128, ntm, 1);
         if (!no_swz) grid = dim3(ntiles, 1, 1);
