@@ -21,13 +21,19 @@ struct DecLayer {
       *ln3_g, *ln3_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
 };
 
-struct Plan {   // workspace carve-up (all offsets 256-byte aligned)
-  size_t total = 0;
-  char *a1, *h1, *a2, *x, *y, *q, *k, *vt, *hbuf, *enc_out;
+struct DecPlan {   // decoder-side buffers of one cohort of windows
+  int W = 0, w0 = 0;           // windows in the cohort, index of its first window
   char *ck, *cv, *sk, *sv, *dx, *dy, *dq, *dattn, *dh, *logits, *first_logits, *splitk, *mask;
   char *tk_val, *tk_idx, *tk_stat;
   size_t splitk_bytes;
   DecodeState st;
+};
+
+struct Plan {   // workspace carve-up (all offsets 256-byte aligned)
+  size_t total = 0;
+  char *a1, *h1, *a2, *x, *y, *q, *k, *vt, *hbuf, *enc_out;
+  int n_coh = 1;               // the windows of a call are decoded as 1 or 2 independent cohorts (see wseg_generate)
+  DecPlan dec[2];
 };
 
 }  // namespace
@@ -51,6 +57,8 @@ struct wseg_model {
   // decode-step graph (hipGraph): captured once per (workspace, geometry, parameters), replayed per step
   hipGraphExec_t step_graph = nullptr;
   hipStream_t cap_stream = nullptr;   // capture happens on a private stream (the legacy NULL stream cannot capture)
+  hipStream_t cap_stream2 = nullptr;  // second branch of the step graph (two cohorts)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::vector<unsigned char> step_graph_key;
 };
 
@@ -67,7 +75,6 @@ void make_plan(const wseg_model* m, int W, int nb, int L, char* base, Plan& p) {
   const size_t es = m->es;
   const size_t d = c.d_model, H = c.n_heads, ffn = c.ffn;
   const size_t M1p = align_up((size_t)W * c.spec_cols, 256), Mp = align_up((size_t)W * c.enc_positions, 256);
-  const size_t R = (size_t)W * nb, Rp = align_up(R, 256);
   char* cur = base;
   auto take = [&](size_t bytes) { char* q = cur; cur += align_up(bytes, 256); return q; };
   // encoder: a1 | h1 | a2 are dead once conv2 has run; hbuf reuses their space.
@@ -84,44 +91,57 @@ void make_plan(const wseg_model* m, int W, int nb, int L, char* base, Plan& p) {
   p.k = take((size_t)W * H * m->tp * 64 * es);
   p.vt = take((size_t)W * H * m->tp * 64 * es);
   p.enc_out = take(Mp * d * es);
-  // decoder
+  // decoder: one cohort by default.  WSEG_TWO_COHORTS=1 splits the windows into two independent decode chains captured
+  // as parallel branches of the step graph (windows never interact).  Measured on MI355X (large, 120 windows): the
+  // branches do run concurrently, but 8.19 ms per step against 6.60 ms for one chain — the two chains compete for the
+  // same CUs / LDS-DMA path instead of filling each other's gaps — so it stays an experiment.
+  static const bool two_cohorts = getenv("WSEG_TWO_COHORTS") != nullptr;
+  p.n_coh = (W >= 16 && two_cohorts) ? 2 : 1;
   const size_t Ld = c.dec_layers, Tk = c.enc_positions;
-  p.ck = take(Ld * W * H * Tk * 64 * es);
-  p.cv = take(Ld * W * H * Tk * 64 * es);
-  p.sk = take(Ld * R * H * (size_t)L * 64 * es);
-  p.sv = take(Ld * R * H * (size_t)L * 64 * es);
-  p.dx = take(Rp * d * es);
-  p.dy = take(Rp * d * es);
-  p.dq = take(Rp * d * es);
-  p.dattn = take(Rp * d * es);
-  p.dh = take(Rp * ffn * es);
-  p.logits = take(Rp * (size_t)m->vp * 4);
-  p.first_logits = take(R * (size_t)m->vp * 4);
   const size_t maxn = 3 * d > ffn ? 3 * d : ffn;
-  p.splitk_bytes = (size_t)8 * Rp * maxn * 4;   // fp32 partials of the decoder-step GEMMs
-  p.splitk = take(p.splitk_bytes);
-  p.mask = take(align_up((size_t)c.vocab, 4));
-  p.tk_val = take(R * 256 * 4);
-  p.tk_idx = take(R * 256 * 4);
-  p.tk_stat = take(R * 16 * 2 * 4);
-  DecodeState& st = p.st;
-  st.W = W; st.nb = nb; st.L = L; st.V = c.vocab; st.ldv = m->vp;
-  st.pos = (int*)take(256);
-  st.tokens_in = (int*)take(R * 4);
-  st.run_seq = (int*)take(R * L * 4);
-  st.fin_seq = (int*)take(R * L * 4);
-  st.run_score = (float*)take(R * 4);
-  st.fin_score = (float*)take(R * 4);
-  st.fin_flag = (int*)take(R * 4);
-  st.fin_len = (int*)take(R * 4);
-  st.unsat = (int*)take((size_t)W * 4);
-  st.anc = (unsigned char*)take(R * L);
-  st.cand_val = (float*)take(R * MAX_CAND * 4);
-  st.cand_tok = (int*)take(R * MAX_CAND * 4);
-  st.active = (int*)take((size_t)L * 4);
-  st.flags = (int*)take((size_t)L * 4);
-  st.epoch = 0;
-  st.sup_mask = (const unsigned char*)p.mask;
+  int w0 = 0;
+  for (int ci = 0; ci < p.n_coh; ++ci) {
+    DecPlan& q = p.dec[ci];
+    q.W = p.n_coh == 1 ? W : (ci == 0 ? (W + 1) / 2 : W / 2);
+    q.w0 = w0;
+    w0 += q.W;
+    const size_t Wc = q.W, R = Wc * nb, Rp = align_up(R, 256);
+    q.ck = take(Ld * Wc * H * Tk * 64 * es);
+    q.cv = take(Ld * Wc * H * Tk * 64 * es);
+    q.sk = take(Ld * R * H * (size_t)L * 64 * es);
+    q.sv = take(Ld * R * H * (size_t)L * 64 * es);
+    q.dx = take(Rp * d * es);
+    q.dy = take(Rp * d * es);
+    q.dq = take(Rp * d * es);
+    q.dattn = take(Rp * d * es);
+    q.dh = take(Rp * ffn * es);
+    q.logits = take(Rp * (size_t)m->vp * 4);
+    q.first_logits = take(R * (size_t)m->vp * 4);
+    q.splitk_bytes = (size_t)8 * Rp * maxn * 4;   // fp32 partials of the decoder-step GEMMs
+    q.splitk = take(q.splitk_bytes);
+    q.mask = take(align_up((size_t)c.vocab, 4));
+    q.tk_val = take(R * 256 * 4);
+    q.tk_idx = take(R * 256 * 4);
+    q.tk_stat = take(R * 16 * 2 * 4);
+    DecodeState& st = q.st;
+    st.W = (int)Wc; st.nb = nb; st.L = L; st.V = c.vocab; st.ldv = m->vp;
+    st.pos = (int*)take(256);
+    st.tokens_in = (int*)take(R * 4);
+    st.run_seq = (int*)take(R * L * 4);
+    st.fin_seq = (int*)take(R * L * 4);
+    st.run_score = (float*)take(R * 4);
+    st.fin_score = (float*)take(R * 4);
+    st.fin_flag = (int*)take(R * 4);
+    st.fin_len = (int*)take(R * 4);
+    st.unsat = (int*)take(Wc * 4);
+    st.anc = (unsigned char*)take(R * L);
+    st.cand_val = (float*)take(R * MAX_CAND * 4);
+    st.cand_tok = (int*)take(R * MAX_CAND * 4);
+    st.active = (int*)take((size_t)L * 4);
+    st.flags = (int*)take((size_t)L * 4);
+    st.epoch = 0;
+    st.sup_mask = (const unsigned char*)q.mask;
+  }
   p.total = (size_t)(cur - base);
 }
 
@@ -139,7 +159,7 @@ int check_geometry(const wseg_model_config& c) {
 #define WSEG_TRY(expr) do { int _s = (expr); if (_s != WSEG_OK) return _s; } while (0)
 
 int gemm(const wseg_model* m, EpiKind epi, const void* A, int lda, const void* Wt, int ldw, int M, int N, int K,
-         const EpiParams& ep, const Plan* p, hipStream_t s) {
+         const EpiParams& ep, const DecPlan* p, hipStream_t s) {
   GemmArgs g;
   g.A = A; g.lda = lda; g.W = Wt; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.ep = ep;
   if (p) { g.splitk_ws = (float*)p->splitk; g.splitk_ws_bytes = p->splitk_bytes; }
@@ -186,7 +206,7 @@ int run_encoder(wseg_model* m, const float* feats, int W, Plan& p, void* enc_out
 }
 
 // One decoder step for all R rows at position *st.pos.  want_logits: run final LN + LM head.
-int run_decoder_step(wseg_model* m, Plan& p, bool want_logits, hipStream_t s) {
+int run_decoder_step(wseg_model* m, DecPlan& p, bool want_logits, hipStream_t s) {
   const wseg_model_config& c = m->cfg;
   const int dt = c.dtype, d = c.d_model, H = c.n_heads, ffn = c.ffn, Tk = c.enc_positions;
   const DecodeState& st = p.st;
@@ -313,6 +333,9 @@ extern "C" void wseg_model_destroy(wseg_model* m) {
   if (m->ev_ok) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(m->ev[i]);
   if (m->step_graph) (void)hipGraphExecDestroy(m->step_graph);
   if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
+  if (m->cap_stream2) (void)hipStreamDestroy(m->cap_stream2);
+  if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+  if (m->ev_join) (void)hipEventDestroy(m->ev_join);
   if (m->poll) (void)hipHostFree(m->poll);
   delete m;
 }
@@ -380,77 +403,110 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
     for (int i = 0; i < 4; ++i) WSEG_HIP_CHECK(hipEventCreate(&m->ev[i]));
     m->ev_ok = true;
   }
-  if (!m->poll) WSEG_HIP_CHECK(hipHostMalloc((void**)&m->poll, 512 * sizeof(int), hipHostMallocDefault));
-  DecodeState& st = p.st;
-  st.P = P; st.eos = gp->eos_token_id; st.pad = gp->pad_token_id; st.max_length = L; st.length_penalty = gp->length_penalty;
-  for (int i = 0; i < 8; ++i) st.prompt[i] = i < P ? gp->prompt[i] : 0;
+  if (!m->poll) WSEG_HIP_CHECK(hipHostMalloc((void**)&m->poll, 2 * 512 * sizeof(int), hipHostMallocDefault));
   m->epoch = (m->epoch % 100000000) + 1;
-  st.epoch = m->epoch;
+  for (int ci = 0; ci < p.n_coh; ++ci) {
+    DecodeState& st = p.dec[ci].st;
+    st.P = P; st.eos = gp->eos_token_id; st.pad = gp->pad_token_id; st.max_length = L; st.length_penalty = gp->length_penalty;
+    for (int i = 0; i < 8; ++i) st.prompt[i] = i < P ? gp->prompt[i] : 0;
+    st.epoch = m->epoch;
+  }
 
   m->timing_valid = false;
   WSEG_HIP_CHECK(hipEventRecord(m->ev[0], s));
   WSEG_TRY(run_encoder(m, feats, n_windows, p, p.enc_out, s));
   WSEG_HIP_CHECK(hipEventRecord(m->ev[1], s));
-  // cross-attention K/V of every decoder layer, once per window (shared by its beams)
-  {
-    const int d = c.d_model, H = c.n_heads, Tk = c.enc_positions, M = n_windows * Tk;
-    const size_t cross_stride = (size_t)n_windows * H * Tk * 64 * m->es;
+  // cross-attention K/V of every decoder layer, once per window (shared by its beams), per cohort
+  for (int ci = 0; ci < p.n_coh; ++ci) {
+    DecPlan& q = p.dec[ci];
+    const int d = c.d_model, H = c.n_heads, Tk = c.enc_positions, M = q.W * Tk;
+    const size_t cross_stride = (size_t)q.W * H * Tk * 64 * m->es;
+    const char* enc_rows = p.enc_out + (size_t)q.w0 * Tk * d * m->es;
     for (int l = 0; l < c.dec_layers; ++l) {
       EpiParams e;
-      e.bias = m->dec[l].ckv_b; e.k = p.ck + l * cross_stride; e.v = p.cv + l * cross_stride;
+      e.bias = m->dec[l].ckv_b; e.k = q.ck + l * cross_stride; e.v = q.cv + l * cross_stride;
       e.d_model = d; e.t_len = Tk; e.n_heads = H;
-      WSEG_TRY(gemm(m, EPI_KV_CROSS, p.enc_out, d, m->dec[l].ckv_w, d, M, 2 * d, d, e, nullptr, s));
+      WSEG_TRY(gemm(m, EPI_KV_CROSS, enc_rows, d, m->dec[l].ckv_w, d, M, 2 * d, d, e, nullptr, s));
     }
   }
   WSEG_HIP_CHECK(hipEventRecord(m->ev[2], s));
-  WSEG_TRY(launch_build_suppress_mask((unsigned char*)p.mask, c.vocab, gp->suppress_tokens, gp->n_suppress,
-                                      gp->begin_suppress_tokens, gp->n_begin_suppress, s));
-  WSEG_TRY(launch_decode_init(st, s));
+  for (int ci = 0; ci < p.n_coh; ++ci) {
+    WSEG_TRY(launch_build_suppress_mask((unsigned char*)p.dec[ci].mask, c.vocab, gp->suppress_tokens, gp->n_suppress,
+                                        gp->begin_suppress_tokens, gp->n_begin_suppress, s));
+    WSEG_TRY(launch_decode_init(p.dec[ci].st, s));
+  }
 
-  // One generated-token step: decoder layers, LM head, candidates, bookkeeping, verdict mirror, advance.
-  auto enqueue_gen_step = [&](bool snapshot_logits, hipStream_t q) -> int {
-    WSEG_TRY(run_decoder_step(m, p, true, q));
+  // One generated-token step of one cohort: decoder layers, LM head, candidates, bookkeeping, advance, verdict mirror.
+  auto enqueue_gen_step = [&](int ci, bool snapshot_logits, hipStream_t qs) -> int {
+    DecPlan& q = p.dec[ci];
+    WSEG_TRY(run_decoder_step(m, q, true, qs));
     if (snapshot_logits)
-      WSEG_HIP_CHECK(hipMemcpyAsync(p.first_logits, p.logits, (size_t)n_windows * nb * m->vp * 4, hipMemcpyDeviceToDevice, q));
-    WSEG_TRY(launch_row_topk(st, (const float*)p.logits, (float*)p.tk_val, (int*)p.tk_idx, (float*)p.tk_stat, q));
-    if (nb == 1) WSEG_TRY(launch_greedy_step(st, q));
-    else WSEG_TRY(launch_beam_step(st, q));
-    WSEG_TRY(launch_advance(st, q));
-    WSEG_HIP_CHECK(hipMemcpyAsync(m->poll, st.flags, (size_t)L * sizeof(int), hipMemcpyDeviceToHost, q));
+      WSEG_HIP_CHECK(hipMemcpyAsync(q.first_logits, q.logits, (size_t)q.W * nb * m->vp * 4, hipMemcpyDeviceToDevice, qs));
+    WSEG_TRY(launch_row_topk(q.st, (const float*)q.logits, (float*)q.tk_val, (int*)q.tk_idx, (float*)q.tk_stat, qs));
+    if (nb == 1) WSEG_TRY(launch_greedy_step(q.st, qs));
+    else WSEG_TRY(launch_beam_step(q.st, qs));
+    WSEG_TRY(launch_advance(q.st, qs));
+    WSEG_HIP_CHECK(hipMemcpyAsync(m->poll + ci * 512, q.st.flags, (size_t)L * sizeof(int), hipMemcpyDeviceToHost, qs));
     return WSEG_OK;
   };
-  // The step reads every step-dependent value (position, tokens, ancestry) from device memory, so ONE captured
-  // graph serves all steps: replay costs ~1.6 us per kernel instead of ~5 us per eager launch.
+  // The step reads every step-dependent value (position, tokens, ancestry, epoch) from device memory, so ONE captured
+  // graph serves all steps and later calls: replay costs ~1.6 us per kernel instead of ~5 us per eager launch.  With two
+  // cohorts the graph has two parallel branches (fork / join through events on two capture streams).
   static const bool use_graph = getenv("WSEG_NO_GRAPH") == nullptr;
   std::vector<unsigned char> key;
   {
     auto put = [&](const void* ptr, size_t n) { const unsigned char* b = (const unsigned char*)ptr; key.insert(key.end(), b, b + n); };
     void* base = aligned_base(workspace);
-    put(&base, sizeof(base)); put(&n_windows, 4); put(&nb, 4); put(&L, 4);
+    const DecodeState& st = p.dec[0].st;
+    put(&base, sizeof(base)); put(&n_windows, 4); put(&nb, 4); put(&L, 4); put(&p.n_coh, 4);
     put(&st.P, 4); put(&st.eos, 4); put(&st.pad, 4); put(&st.length_penalty, 4); put(st.prompt, sizeof(st.prompt));
   }
   int steps = 0;
   bool stop = false;
   auto check_stop = [&](int upto) {
-    for (int t = P - 1; t < upto && !stop; ++t)
-      if (((volatile int*)m->poll)[t] == st.epoch * 4 + 2) stop = true;
+    int done = 0;
+    for (int ci = 0; ci < p.n_coh; ++ci) {
+      const volatile int* pl = (const volatile int*)(m->poll + ci * 512);
+      for (int t = P - 1; t < upto; ++t)
+        if (pl[t] == m->epoch * 4 + 2) { ++done; break; }
+    }
+    if (done == p.n_coh) stop = true;
   };
   for (int t = 0; t < L - 1 && !stop; ++t) {
     if (t < P - 1) {
-      WSEG_TRY(run_decoder_step(m, p, false, s));
-      WSEG_TRY(launch_prompt_feed(st, s));
-      WSEG_TRY(launch_advance(st, s));
+      for (int ci = 0; ci < p.n_coh; ++ci) {
+        WSEG_TRY(run_decoder_step(m, p.dec[ci], false, s));
+        WSEG_TRY(launch_prompt_feed(p.dec[ci].st, s));
+        WSEG_TRY(launch_advance(p.dec[ci].st, s));
+      }
     } else if (t == P - 1 || !use_graph) {
-      WSEG_TRY(enqueue_gen_step(t == P - 1, s));
+      for (int ci = 0; ci < p.n_coh; ++ci) WSEG_TRY(enqueue_gen_step(ci, t == P - 1, s));
     } else {
       if (!m->step_graph || m->step_graph_key != key) {
         if (m->step_graph) { (void)hipGraphExecDestroy(m->step_graph); m->step_graph = nullptr; }
         hipGraph_t graph = nullptr;
         if (!m->cap_stream) WSEG_HIP_CHECK(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+        if (!m->cap_stream2) {
+          WSEG_HIP_CHECK(hipStreamCreateWithFlags(&m->cap_stream2, hipStreamNonBlocking));
+          WSEG_HIP_CHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+          WSEG_HIP_CHECK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+        }
         WSEG_HIP_CHECK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
-        const int rc = enqueue_gen_step(false, m->cap_stream);
+        int rc = WSEG_OK;
+        if (p.n_coh == 2) {
+          hipError_t e1 = hipEventRecord(m->ev_fork, m->cap_stream);
+          hipError_t e2 = hipStreamWaitEvent(m->cap_stream2, m->ev_fork, 0);
+          if (e1 != hipSuccess || e2 != hipSuccess) rc = WSEG_ERR_HIP;
+          if (rc == WSEG_OK) rc = enqueue_gen_step(1, false, m->cap_stream2);
+          if (rc == WSEG_OK) rc = enqueue_gen_step(0, false, m->cap_stream);
+          e1 = hipEventRecord(m->ev_join, m->cap_stream2);
+          e2 = hipStreamWaitEvent(m->cap_stream, m->ev_join, 0);
+          if (rc == WSEG_OK && (e1 != hipSuccess || e2 != hipSuccess)) rc = WSEG_ERR_HIP;
+        } else {
+          rc = enqueue_gen_step(0, false, m->cap_stream);
+        }
         const hipError_t ec = hipStreamEndCapture(m->cap_stream, &graph);
-        if (rc != WSEG_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (rc != WSEG_OK) { if (graph) (void)hipGraphDestroy(graph); if (rc == WSEG_ERR_HIP) set_error("graph capture fork/join failed"); return rc; }
         if (ec != hipSuccess) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ec)); return WSEG_ERR_HIP; }
         WSEG_HIP_CHECK(hipGraphInstantiate(&m->step_graph, graph, nullptr, nullptr, 0));
         (void)hipGraphDestroy(graph);
@@ -459,11 +515,12 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
       WSEG_HIP_CHECK(hipGraphLaunch(m->step_graph, s));
     }
     ++steps;
-    // lagged, non-blocking poll of the pinned verdict mirror: stop enqueueing once a finished step reported that
-    // no window can still improve (steps already enqueued are harmless: finished beams are frozen)
+    // lagged, non-blocking poll of the pinned verdict mirror: stop enqueueing once a finished step of EVERY cohort reported
+    // that no window can still improve (steps already enqueued are harmless: finished beams are frozen)
     check_stop(t);
   }
-  WSEG_TRY(launch_finalize(st, out_tokens, out_lengths, s));
+  for (int ci = 0; ci < p.n_coh; ++ci)
+    WSEG_TRY(launch_finalize(p.dec[ci].st, out_tokens + (size_t)p.dec[ci].w0 * L, out_lengths + p.dec[ci].w0, s));
   WSEG_HIP_CHECK(hipEventRecord(m->ev[3], s));
   m->last_steps = steps;
   m->last_W = n_windows; m->last_nb = nb; m->last_L = L;
@@ -477,8 +534,15 @@ extern "C" int wseg_debug_first_logits(wseg_model* m, void* workspace, float* ou
   if (m->last_W <= 0 || n_rows > m->last_W * m->last_nb) { set_error("no matching wseg_generate call"); return WSEG_ERR_STATE; }
   Plan p;
   make_plan(m, m->last_W, m->last_nb, m->last_L, aligned_base(workspace), p);
-  WSEG_HIP_CHECK(hipMemcpy2DAsync(out, (size_t)m->cfg.vocab * 4, p.first_logits, (size_t)m->vp * 4, (size_t)m->cfg.vocab * 4,
-                                  (size_t)n_rows, hipMemcpyDeviceToDevice, s));
+  for (int ci = 0; ci < p.n_coh; ++ci) {
+    const DecPlan& q = p.dec[ci];
+    const int r0 = q.w0 * m->last_nb;
+    int rows = q.W * m->last_nb;
+    if (r0 >= n_rows) break;
+    if (r0 + rows > n_rows) rows = n_rows - r0;
+    WSEG_HIP_CHECK(hipMemcpy2DAsync(out + (size_t)r0 * m->cfg.vocab, (size_t)m->cfg.vocab * 4, q.first_logits, (size_t)m->vp * 4,
+                                    (size_t)m->cfg.vocab * 4, (size_t)rows, hipMemcpyDeviceToDevice, s));
+  }
   return WSEG_OK;
 }
 
