@@ -9,15 +9,19 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--windows", type=int, default=32)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--encoder-only", action="store_true")
+ap.add_argument("--decoder-only", action="store_true")
 a = ap.parse_args()
 lib = _lib.load(require_device=True)
 d, f = 1280, 5120
 M = a.windows * 500
 shapes = [("qkv", M, 3 * d, d, 0), ("o-proj", M, d, d, 2), ("fc1", M, f, d, 1), ("fc2", M, d, f, 2), ("conv2", M, d, 3 * d, 1),
           ("4096^3", 4096, 4096, 4096, 0), ("dec fc1 R=128", 128, f, d, 1), ("dec fc2 R=128", 128, d, f, 2), ("dec o R=128", 128, d, d, 2),
+          ("dec fc1 R=480", 480, f, d, 1), ("dec fc2 R=480", 480, d, f, 2), ("dec o R=480", 480, d, d, 2), ("dec qkv R=480", 480, 3 * d, d, 0),
           ("dec fc1 R=32", 32, f, d, 1), ("dec fc2 R=32", 32, d, f, 2), ("dec qkv R=32", 32, 3 * d, d, 0), ("lm head R=128", 128, 51968, d, 0)]
 if a.encoder_only:
     shapes = shapes[:5]
+if a.decoder_only:
+    shapes = [sh for sh in shapes if sh[0].startswith('dec') or sh[0].startswith('lm')]
 ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
 for name, m, n, k, epi in shapes:
     mp = (m + 255) // 256 * 256

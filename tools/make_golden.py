@@ -63,10 +63,6 @@ def make_frontend(ref_audio, ref_model):
     np.savez_compressed(os.path.join(OUT, "logmel.npz"), **arrays)
 
 
-class _StubSegmenter:
-    pass
-
-
 def make_windows(ref_audio, ref_model):
     seg = ref_model.SegmenterBase()
     seg.total_spec_columns = 1000
@@ -270,7 +266,6 @@ def make_tiny(ref_audio, ref_model):
 
 
 def make_wav():
-    import shutil
     import struct
     src = "/root/reference/data/example_subset/Meerkat/test/VALP007_AL_6_15DEC2022_MF_ML.wav"
     with open(src, "rb") as f:
@@ -283,7 +278,6 @@ def make_wav():
         + b"data" + struct.pack("<I", len(data))
     with open(os.path.join(OUT, "meerkat_5s.wav"), "wb") as f:
         f.write(hdr + data)
-    del shutil
 
 
 def main():

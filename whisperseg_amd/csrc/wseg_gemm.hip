@@ -620,8 +620,11 @@ static int launch_skinny_partial(const GemmArgs& g, const SkinnyPlan& sp, hipStr
     return WSEG_ERR_STATE;
   }
   dim3 grid(g.N / 64, sp.mt, sp.splits);
+  // LDS ring depth: 2 stages.  Measured (large, 120 windows): 6-8 K tiles in flight with one workgroup per CU is 1.7x
+  // SLOWER than 3-4 stages at two workgroups per CU, and 2 stages (3-5 workgroups per CU) is another 2-3 % faster at every
+  // batch size — these kernels want co-resident workgroups to cover their barriers, not more bytes in flight each.
 #define WSEG_SKINNY_P(BM_, WM_, WN_)                                                                                     \
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM_, 64, WM_, WN_, EPI_STORE, true, (BM_ <= 64 ? 4 : 3)>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, \
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM_, 64, WM_, WN_, EPI_STORE, true, 2>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, \
                      g.N, sp.k_len, g.ep, g.splitk_ws, sp.m_pad, 0)
   if (sp.bm == 32) WSEG_SKINNY_P(32, 1, 4);
   else if (sp.bm == 64) WSEG_SKINNY_P(64, 1, 4);
@@ -703,8 +706,9 @@ static int launch_bf16(const GemmArgs& g, hipStream_t s) {
   const bf16_t* A = (const bf16_t*)g.A;
   const bf16_t* W = (const bf16_t*)g.W;
   if (g.K % 64 || g.N % 64) { set_error("gemm bf16: K %d / N %d not tile multiples", g.K, g.N); return WSEG_ERR_INVALID; }
+  static const long big_min = getenv("WSEG_BIG_MIN_BLOCKS") ? atol(getenv("WSEG_BIG_MIN_BLOCKS")) : 256;   // tuning knob
   const long big_blocks = (long)cdiv(g.M, 128) * (g.N / 128);
-  if (g.M > 128 && g.N % 128 == 0 && big_blocks >= 256) {
+  if (g.M > 128 && g.N % 128 == 0 && big_blocks >= big_min) {
     static const bool no_swz = getenv("WSEG_NO_XCD_SWIZZLE") != nullptr;
     static const bool big256 = getenv("WSEG_GEMM_128") == nullptr;   // 256x256 tiles by default where they fill the chip
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -754,7 +758,7 @@ static int launch_bf16(const GemmArgs& g, hipStream_t s) {
   if (sp.splits == 1) {
     dim3 grid(g.N / 64, sp.mt, 1);
 #define WSEG_SKINNY(BM_, WM_, WN_)                                                                                      \
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM_, 64, WM_, WN_, EPI, false, (BM_ <= 64 ? 4 : 3)>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, \
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM_, 64, WM_, WN_, EPI, false, 2>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, \
                      g.K, g.ep, (float*)nullptr, sp.m_pad, 0)
     if (sp.bm == 32) WSEG_SKINNY(32, 1, 4);
     else if (sp.bm == 64) WSEG_SKINNY(64, 1, 4);

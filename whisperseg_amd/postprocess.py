@@ -12,7 +12,6 @@ from .utils import RATIO_DECODING_TIME_STEP_TO_SPEC_TIME_STEP
 
 # onset token, cluster digits, offset token, adjacent with nothing between (reference model.py:120)
 SEGMENT_PATTERN = re.compile(r"<\|([0-9]+)\|>(\d+?)<\|([0-9]+)\|>")
-EMPTY = {"onset": [], "offset": [], "cluster": []}
 
 
 def _empty():
@@ -22,7 +21,6 @@ def _empty():
 def extract_segments(text, spec_time_step, cluster_codebook, matcher=SEGMENT_PATTERN):
     """model.py:191-207: [[onset_s, offset_s, cluster_name]] relative to the window start."""
     names = {v: k for k, v in cluster_codebook.items()}
-    unit = spec_time_step * RATIO_DECODING_TIME_STEP_TO_SPEC_TIME_STEP
     rows = []
     for on_txt, cid_txt, off_txt in matcher.findall(text):
         # NB: the reference multiplies int * spec_time_step first, then * RATIO (left to right)
@@ -32,7 +30,6 @@ def extract_segments(text, spec_time_step, cluster_codebook, matcher=SEGMENT_PAT
         if cid not in names or offset - onset <= 0:
             continue
         rows.append([onset, offset, names[cid]])
-    del unit
     return rows
 
 
