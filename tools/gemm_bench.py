@@ -10,6 +10,7 @@ ap.add_argument("--windows", type=int, default=32)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--encoder-only", action="store_true")
 ap.add_argument("--decoder-only", action="store_true")
+ap.add_argument("--shapes", default="", help="custom list 'M,N,K,epi;M,N,K,epi;...' (epi 0 bias, 1 bias+gelu, 2 bias+residual)")
 a = ap.parse_args()
 lib = _lib.load(require_device=True)
 d, f = 1280, 5120
@@ -22,6 +23,8 @@ if a.encoder_only:
     shapes = shapes[:5]
 if a.decoder_only:
     shapes = [sh for sh in shapes if sh[0].startswith('dec') or sh[0].startswith('lm')]
+if a.shapes:
+    shapes = [("custom",) + tuple(int(v) for v in item.split(",")) for item in a.shapes.split(";") if item]
 ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
 for name, m, n, k, epi in shapes:
     mp = (m + 255) // 256 * 256

@@ -35,12 +35,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);                                          // round to nearest even
-  return (bf16_t)(u >> 16);
+// float -> bf16, round to nearest even: gfx950's v_cvt_pk_bf16_f32 (the integer emulation is ~7 VALU per element,
+// which showed up as microseconds per 256x256 GEMM tile epilogue).
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  const hw_f32x2 v = {lo, hi};
+  const hw_bf16x2 b = __builtin_convertvector(v, hw_bf16x2);
+  return __builtin_bit_cast(uint32_t, b);
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 // Element-type traits: T = float (exact-parity mode) or bf16_t (production mode).
 template <typename T> struct El;
@@ -58,16 +62,30 @@ template <> struct El<bf16_t> {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // erf-GELU for the bf16 path: Abramowitz & Stegun 7.1.26 rational approximation of erf (|error| <= 1.5e-7, far
-// below the 2^-9 relative rounding of the bf16 result), ~14 VALU instructions instead of libm erff's ~50.
+// below the 2^-9 relative rounding of the bf16 result).  v_rcp_f32 / v_exp_f32 directly: `1.0f / x` and __frcp_rn
+// compile to the IEEE division sequence (v_div_scale x2, v_div_fmas, v_div_fixup + Newton steps), which made the
+// GELU of a 256x256 tile 3200 VALU instructions per wave.  12 VALU + 2 transcendental per element.
 __device__ __forceinline__ float gelu_erf_fast(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);
   p = fmaf(p, t, 0.254829592f);
-  const float e = 1.0f - p * t * __expf(-z * z);        // erf(|x| / sqrt 2)
-  return 0.5f * x * (1.0f + copysignf(e, x));
+  const float e2 = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170368f);   // exp(-x^2 / 2)
+  const float h = 0.5f * x;
+  return fmaf(fabsf(h), fmaf(-(p * t), e2, 1.0f), h);    // 0.5 x (1 + sign(x) erf(|x| / sqrt 2))
+}
+// Cheaper erf-GELU for MFMA epilogues (the GELU of a 256x256 tile is ~9 us of VALU work with the A&S form, beside a
+// ~30 us K loop): x * sigmoid(x (a1 + a3 x^2 + a5 x^4)), coefficients minimax-fitted to 0.5 x (1 + erf(x / sqrt 2)) on
+// [-9, 9]: max |error| 2.6e-5 (tools/gelu_fit.py) — the classic tanh form is 4.7e-4.  -log2(e) is folded into the
+// coefficients; x^2 is clamped at 64 because the quintic is monotone only up to |x| = 8.3 (sigmoid has saturated
+// by then).  5 VALU + v_exp_f32 + v_rcp_f32.
+__device__ __forceinline__ float gelu_sig5(float x) {
+  const float x2 = fminf(x * x, 64.0f);
+  float q = fmaf(x2, 0.0010142630198970437f, -0.10677572339773178f);
+  q = fmaf(q, x2, -2.301121234893799f);
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * q));
 }
 template <typename T> __device__ __forceinline__ float gelu_for(float x);
 template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }

@@ -136,7 +136,7 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float 
 template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float v[8]) {
   uint32_t w[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) w[j] = (uint32_t)f2bf(v[2 * j]) | ((uint32_t)f2bf(v[2 * j + 1]) << 16);
+  for (int j = 0; j < 4; ++j) w[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
   *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
 }
 

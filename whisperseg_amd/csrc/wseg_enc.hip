@@ -79,7 +79,7 @@ template <> struct VecIO<bf16_t> {
   static __device__ __forceinline__ void st(bf16_t* p, const float v[8]) {
     uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
     *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
   }
 };
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 // ------------------------------------------------------------------------------------------------
 // Encoder attention, bf16 MFMA.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return pack_bf16x2(a, b); }
 
 __global__ __launch_bounds__(256) void enc_attention_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ Vt, bf16_t* __restrict__ out,

@@ -35,8 +35,8 @@ template <> struct Vec4<bf16_t> {
   }
   static __device__ __forceinline__ void st(bf16_t* p, const float v[4]) {
     uint2 t;
-    t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-    t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    t.x = pack_bf16x2(v[0], v[1]);
+    t.y = pack_bf16x2(v[2], v[3]);
     *(uint2*)p = t;
   }
 };
@@ -117,7 +117,7 @@ __device__ __forceinline__ void ld8_bf16(const bf16_t* p, float v[8]) {
 __device__ __forceinline__ void st8_bf16(bf16_t* p, const float v[8]) {
   uint32_t w[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) w[j] = (uint32_t)f2bf(v[2 * j]) | ((uint32_t)f2bf(v[2 * j + 1]) << 16);
+  for (int j = 0; j < 4; ++j) w[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
   *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
@@ -482,10 +482,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_persist_kernel(const b
     }
     g += nk;
     {
-      // LDS-staged epilogue in the stage consumed last ((g-1)&1); the other stage is receiving the next tile
+      // LDS-staged epilogue in the stage consumed last ((g-1)&1); the other stage is receiving the next tile.
+      // Every global LOAD of the epilogue (bias, residual rows) is issued before its first STORE: vmcnt retires in
+      // order on gfx9, so a load issued after a store cannot be consumed before that store has completed — a bias
+      // load per output row made each of the 16 stores a full round trip (measured 16-42 % of the launch).
       constexpr int LDT = TN + 4;
       float* strip = (float*)(smem + ((g - 1) & 1) * STAGE) + (size_t)wave * 16 * LDT;
       const int rr = lane >> 3, cc = (lane & 7) * 8;
+      const int nc = n0 + wn * TN + cc, mb = m0 + wm * TM;
+      float bv[8];
+      if (ep.bias) ld8_bf16((const bf16_t*)ep.bias + nc, bv);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+      }
+      uint4 rraw[EPI == EPI_RESID ? MI * 2 : 1];
+      if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+        for (int t = 0; t < MI * 2; ++t) {
+          const int m = min(mb + t * 8 + rr, M - 1);
+          rraw[t] = *(const uint4*)((const bf16_t*)ep.resid + (size_t)m * ep.ldc + nc);
+        }
+      }
+      EpiParams ep2 = ep;
+      ep2.bias = nullptr;
 #pragma unroll
       for (int j = 0; j < MI; ++j) {
 #pragma unroll
@@ -495,9 +515,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_persist_kernel(const b
         for (int hh = 0; hh < 2; ++hh) {
           const int rw = hh * 8 + rr;
           const float4 a = *(const float4*)(strip + rw * LDT + cc), b = *(const float4*)(strip + rw * LDT + cc + 4);
-          float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-          const int m = m0 + wm * TM + j * 16 + rw;
-          if (m < M) epi_apply8<EPI>(ep, m, n0 + wn * TN + cc, v);
+          float v[8] = {a.x + bv[0], a.y + bv[1], a.z + bv[2], a.w + bv[3], b.x + bv[4], b.y + bv[5], b.z + bv[6], b.w + bv[7]};
+          const int m = mb + j * 16 + rw;
+          if constexpr (EPI == EPI_RESID) {
+            const uint4 t = rraw[j * 2 + hh];
+            const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[2 * e] = __uint_as_float(w4[e] << 16) + v[2 * e];
+              v[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u) + v[2 * e + 1];
+            }
+            if (m < M) st8_bf16((bf16_t*)ep.out + (size_t)m * ep.ldc + nc, v);
+          } else {
+            if (m < M) epi_apply8<EPI>(ep2, m, nc, v);
+          }
         }
       }
     }
@@ -695,7 +726,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_resid_ln_kernel(const float
     for (int j = 0; j < 4; ++j) {
       const float y0 = (v[2 * j] - mean) * rstd * __uint_as_float(wg[j] << 16) + __uint_as_float(wb[j] << 16);
       const float y1 = (v[2 * j + 1] - mean) * rstd * __uint_as_float(wg[j] & 0xffff0000u) + __uint_as_float(wb[j] & 0xffff0000u);
-      o[j] = (uint32_t)f2bf(y0) | ((uint32_t)f2bf(y1) << 16);
+      o[j] = pack_bf16x2(y0, y1);
     }
     *(uint4*)(y + (size_t)row * d + c) = make_uint4(o[0], o[1], o[2], o[3]);
   }
