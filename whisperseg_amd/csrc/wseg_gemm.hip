@@ -357,6 +357,65 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const bf16_t* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// Epilogue of the 8-wave MFMA kernels (wave tile MI*16 rows x 64 columns), staged through LDS: every wave
+// transposes one 16-row x 64-column strip at a time so that 8 lanes cover one 128-byte output row with 16-byte
+// accesses.  Every global LOAD (bias, residual rows) is issued before the first STORE: vmcnt retires in order on
+// gfx9, so a load issued after a store cannot be consumed before that store has completed — a bias load per
+// output row made each of the 16 stores a full round trip (measured 16-42 % of a launch).
+// ------------------------------------------------------------------------------------------------
+template <int EPI, int MI, int NI>
+__device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NI][MI], float* stage, const EpiParams& ep, int M, int mb,
+                                                int nb, int lane, int wave) {
+  static_assert(NI == 4, "64-column wave tiles");
+  constexpr int LDT = 64 + 4;
+  float* strip = stage + (size_t)wave * 16 * LDT;
+  const int fr = lane & 15, fg = lane >> 4, rr = lane >> 3, cc = (lane & 7) * 8;
+  const int nc = nb + cc;
+  float bv[8];
+  if (ep.bias) ld8_bf16((const bf16_t*)ep.bias + nc, bv);
+  else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+  }
+  uint4 rraw[EPI == EPI_RESID ? MI * 2 : 1];
+  if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+    for (int t = 0; t < MI * 2; ++t) {
+      const int m = min(mb + t * 8 + rr, M - 1);
+      rraw[t] = *(const uint4*)((const bf16_t*)ep.resid + (size_t)m * ep.ldc + nc);
+    }
+  }
+  EpiParams ep2 = ep;
+  ep2.bias = nullptr;
+#pragma unroll
+  for (int j = 0; j < MI; ++j) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      *(float4*)(strip + fr * LDT + i * 16 + fg * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    // same-wave LDS RAW: ds ops of one wave complete in order, the compiler waits lgkmcnt before the reads
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int rw = hh * 8 + rr;
+      const float4 a = *(const float4*)(strip + rw * LDT + cc), b = *(const float4*)(strip + rw * LDT + cc + 4);
+      float v[8] = {a.x + bv[0], a.y + bv[1], a.z + bv[2], a.w + bv[3], b.x + bv[4], b.y + bv[5], b.z + bv[6], b.w + bv[7]};
+      const int m = mb + j * 16 + rw;
+      if constexpr (EPI == EPI_RESID) {
+        const uint4 t = rraw[j * 2 + hh];
+        const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] = __uint_as_float(w4[e] << 16) + v[2 * e];
+          v[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u) + v[2 * e + 1];
+        }
+        if (m < M) st8_bf16((bf16_t*)ep.out + (size_t)m * ep.ldc + nc, v);
+      } else {
+        if (m < M) epi_apply8<EPI>(ep2, m, nc, v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Persistent variant for the large encoder GEMMs: the grid is one (256x256) or two (128x128) workgroups per CU and
 // every workgroup walks a strided sequence of tiles.  While the last K-tile of a tile is multiplied the first
 // K-tile of the NEXT tile is already streaming into the other LDS stage, and it keeps streaming under the LDS-staged
@@ -481,61 +540,196 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_persist_kernel(const b
       __builtin_amdgcn_s_barrier();
     }
     g += nk;
-    {
-      // LDS-staged epilogue in the stage consumed last ((g-1)&1); the other stage is receiving the next tile.
-      // Every global LOAD of the epilogue (bias, residual rows) is issued before its first STORE: vmcnt retires in
-      // order on gfx9, so a load issued after a store cannot be consumed before that store has completed — a bias
-      // load per output row made each of the 16 stores a full round trip (measured 16-42 % of the launch).
-      constexpr int LDT = TN + 4;
-      float* strip = (float*)(smem + ((g - 1) & 1) * STAGE) + (size_t)wave * 16 * LDT;
-      const int rr = lane >> 3, cc = (lane & 7) * 8;
-      const int nc = n0 + wn * TN + cc, mb = m0 + wm * TM;
-      float bv[8];
-      if (ep.bias) ld8_bf16((const bf16_t*)ep.bias + nc, bv);
-      else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-      }
-      uint4 rraw[EPI == EPI_RESID ? MI * 2 : 1];
-      if constexpr (EPI == EPI_RESID) {
-#pragma unroll
-        for (int t = 0; t < MI * 2; ++t) {
-          const int m = min(mb + t * 8 + rr, M - 1);
-          rraw[t] = *(const uint4*)((const bf16_t*)ep.resid + (size_t)m * ep.ldc + nc);
-        }
-      }
-      EpiParams ep2 = ep;
-      ep2.bias = nullptr;
-#pragma unroll
-      for (int j = 0; j < MI; ++j) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-          *(float4*)(strip + fr * LDT + i * 16 + fg * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const int rw = hh * 8 + rr;
-          const float4 a = *(const float4*)(strip + rw * LDT + cc), b = *(const float4*)(strip + rw * LDT + cc + 4);
-          float v[8] = {a.x + bv[0], a.y + bv[1], a.z + bv[2], a.w + bv[3], b.x + bv[4], b.y + bv[5], b.z + bv[6], b.w + bv[7]};
-          const int m = mb + j * 16 + rw;
-          if constexpr (EPI == EPI_RESID) {
-            const uint4 t = rraw[j * 2 + hh];
-            const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[2 * e] = __uint_as_float(w4[e] << 16) + v[2 * e];
-              v[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u) + v[2 * e + 1];
-            }
-            if (m < M) st8_bf16((bf16_t*)ep.out + (size_t)m * ep.ldc + nc, v);
-          } else {
-            if (m < M) epi_apply8<EPI>(ep2, m, nc, v);
-          }
-        }
-      }
-    }
+    // LDS-staged epilogue in the stage consumed last ((g-1)&1); the other stage is receiving the next tile
+    staged_epilogue<EPI, MI, NI>(acc, (float*)(smem + ((g - 1) & 1) * STAGE), ep, M, m0 + wm * TM, n0 + wn * TN, lane, wave);
     if (!has_next) break;
     __builtin_amdgcn_s_barrier();                   // every wave is done with its strip before the stage is refilled
     m0 = nm0; n0 = nn0; idx = nidx;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ping-pong persistent kernel for the large encoder GEMMs (256x256 tile, 8 waves = 2 row groups x 4 column waves,
+// wave tile 128x64, K tiles of 64, two 64-KB LDS buffers of four 16-KB half-tiles [A0 | A1 | B0 | B1]).
+//
+// A K tile is four phases, one 64x32 quadrant of the wave tile each (16 MFMAs).  A phase is
+//     L part: fragment ds_reads + LDS-DMA prefetch issue      | s_barrier |
+//     M part: 16 MFMAs at raised priority                     | s_barrier |
+// and row group 1 runs one barrier behind row group 0 (it takes one extra barrier at the start), so on every SIMD
+// one wave is in its M part while the other is in its L part: the matrix pipe is fed by one group while the other
+// issues its loads, instead of all 8 waves reading, then all 8 multiplying.
+//
+// Fragment reads of K tile g:  phase 0: b0, a0   phase 1: b1   phase 2: a1 (into a0's registers)   phase 3: none;
+// quadrants (a0,b0) (a0,b1) (a1,b1) (a1,b0).  Group x executes the L part of phase p in barrier interval 2p + x and
+// its reads are retired (lgkmcnt(0)) inside interval 2p + x + 1.  Hence, for the buffer of K tile g (p = 4g + i):
+//     B half-tiles (read by both groups in phases 0-1): free from interval 8g + 5
+//     A0 (read by group 0 only, phases 0 and 2):         free from interval 8g + 6
+//     A1 (read by group 1 only):                         free from interval 8g + 7
+// and the prefetch stream is      phase 3 of g: B0 B1 A0 of g+2, then s_waitcnt vmcnt(6);   phase 0 of g+1: A1 of g+2
+// (group 0 issues in intervals 8g + 6 and 8g + 8).  The counted wait retires K tile g+1 — its youngest half-tile
+// A1(g+1) was issued three phases earlier — in the L part of phase 3, i.e. two barriers before group 0 and three
+// before group 1 read it; the three half-tiles just issued stay in flight across the barrier.
+// The K-tile stream is continuous across the output tiles a workgroup owns.  The last K tile e of an output tile
+// leaves buffer e & 1 to the epilogue as its staging area: the half-tiles of K tile e+2 are held back and issued
+// together in phase 1 of K tile e+1 (interval >= 8e + 10, after group 1 has left its epilogue in interval 8e + 8).
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
+                                                          int ldw, int M, int N, int K, EpiParams ep, int ntm, int GM) {
+  constexpr int BM = 256, BN = 256, BK = 64, TM = 128, TN = 64, MI = 8, NI = 4;
+  constexpr int HT = 128 * BK;                      // elements per half-tile (16 KB)
+  constexpr int BUF = 4 * HT;                       // elements per K-tile buffer: [A0 | A1 | B0 | B1]
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int ntn = N / BN, ntiles = ntm * ntn, nk = K / BK;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int count = q + (xcd < r ? 1 : 0);
+  if (loc >= count) return;
+  const int T = ((count - loc + bpx - 1) / bpx) * nk;      // K tiles this workgroup consumes
+  auto tile_coords = [&](int swz, int& m0, int& n0) {
+    const int per_group = GM * ntn, grp = swz / per_group, rem = swz - grp * per_group;
+    const int gm = min(GM, ntm - grp * GM);
+    m0 = (grp * GM + rem % gm) * BM;
+    n0 = (rem / gm) * BN;
+  };
+
+  // ---- prefetch stream: one cursor per operand (tile sequence index, K tile, stream index, scalar row base) ----
+  // thread's piece of a half-tile: LDS 16-B slot p = it*512 + tid (it = 0, 1) holds row p >> 3, logical slot
+  // (p & 7) ^ (row & 7) (swizzle on the source side); piece 1 is 64 rows below piece 0, same slot.
+  const int prow = tid >> 3, pslot = (tid & 7) ^ (prow & 7);
+  const int a_lane = prow * lda + pslot * 8, w_lane = prow * ldw + pslot * 8;      // element offsets (< 2^31)
+  int ca_idx = loc, ca_kt = 0, ca_g = 0, cb_idx = loc, cb_kt = 0, cb_g = 0;
+  int tm, tn;
+  tile_coords(start + loc, tm, tn);
+  size_t ca_row = (size_t)tm * lda, cb_row = (size_t)tn * ldw;                    // scalar
+  auto issue_a = [&](int half) {                       // half-tile A<half> of K tile ca_g; the cursor advances after A1
+    bf16_t* dst = smem + (ca_g & 1) * BUF + half * HT + wave * 512;
+    const bf16_t* src = A + (ca_row + (size_t)(half * 128) * lda + ca_kt * BK) + a_lane;
+    WSEG_GLDS16(src, dst);
+    WSEG_GLDS16(src + (size_t)64 * lda, dst + 4096);
+    if (half == 1) {
+      ++ca_g;
+      if (++ca_kt == nk) {
+        ca_kt = 0;
+        ca_idx += bpx;
+        if (ca_idx < count) {
+          tile_coords(start + ca_idx, tm, tn);
+          ca_row = (size_t)tm * lda;
+        }
+      }
+    }
+  };
+  auto issue_b = [&](int half) {
+    bf16_t* dst = smem + (cb_g & 1) * BUF + (2 + half) * HT + wave * 512;
+    const bf16_t* src = W + (cb_row + (size_t)(half * 128) * ldw + cb_kt * BK) + w_lane;
+    WSEG_GLDS16(src, dst);
+    WSEG_GLDS16(src + (size_t)64 * ldw, dst + 4096);
+    if (half == 1) {
+      ++cb_g;
+      if (++cb_kt == nk) {
+        cb_kt = 0;
+        cb_idx += bpx;
+        if (cb_idx < count) {
+          tile_coords(start + cb_idx, tm, tn);
+          cb_row = (size_t)tn * ldw;
+        }
+      }
+    }
+  };
+
+  // prologue: K tile 0 complete, B0 B1 A0 of K tile 1 in flight
+  issue_b(0); issue_b(1); issue_a(0); issue_a(1);
+  if (T > 1) { issue_b(0); issue_b(1); issue_a(0); wait_vmcnt<6>(); }
+  else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();          // stagger: group 1 runs one barrier behind group 0
+
+  // fragment addressing: row j*16 + fr of a half-tile, 16-B slot (kk*4 + fg) ^ (fr & 7); kk = 1 is the kk = 0 address ^ 64 B
+  const int frag0 = fr * BK + ((fg ^ (fr & 7)) << 3);
+  const int fa0 = wr * HT + frag0, fa1 = fa0 ^ 32;
+  const int fb0 = (2 + (wc >> 1)) * HT + (wc & 1) * 64 * BK + frag0, fb1 = fb0 ^ 32;
+
+#define WSEG_PP_MFMA(JA, IB)                                                                                          \
+  do {                                                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                                    \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                                  \
+      _Pragma("unroll") for (int i = 2 * (IB); i < 2 * (IB) + 2; ++i)                                                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
+          acc[i][4 * (JA) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[i][kk], afr[j][kk], acc[i][4 * (JA) + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+  } while (0)
+
+  int g = 0;                                           // K tiles consumed so far
+  for (int idx = loc; idx < count; idx += bpx) {
+  int m0, n0;
+  tile_coords(start + idx, m0, n0);
+  f32x4 acc[NI][MI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma nounroll
+  for (int kt = 0; kt < nk; ++kt, ++g) {
+    const bool first = kt == 0 && g > 0, final = kt == nk - 1;
+    const bf16_t* cur = smem + (g & 1) * BUF;
+    bf16x8 afr[4][2], bfr[NI][2];
+    // ---- phase 0: b0, a0 -> quadrant (a0, b0) ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      bfr[i][0] = *(const bf16x8*)(cur + i * 16 * BK + fb0);
+      bfr[i][1] = *(const bf16x8*)(cur + i * 16 * BK + fb1);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      afr[j][0] = *(const bf16x8*)(cur + j * 16 * BK + fa0);
+      afr[j][1] = *(const bf16x8*)(cur + j * 16 * BK + fa1);
+    }
+    if (!first && g + 1 < T) issue_a(1);               // A1(g+1)
+    __builtin_amdgcn_sched_barrier(0);
+    WSEG_PP_MFMA(0, 0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 1: b1 -> quadrant (a0, b1) ----
+#pragma unroll
+    for (int i = 2; i < 4; ++i) {
+      bfr[i][0] = *(const bf16x8*)(cur + i * 16 * BK + fb0);
+      bfr[i][1] = *(const bf16x8*)(cur + i * 16 * BK + fb1);
+    }
+    if (first && g + 1 < T) { issue_b(0); issue_b(1); issue_a(0); issue_a(1); }     // K tile g+1, held back over the epilogue
+    __builtin_amdgcn_sched_barrier(0);
+    WSEG_PP_MFMA(0, 1);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: a1 -> quadrant (a1, b1) ----
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      afr[j][0] = *(const bf16x8*)(cur + (4 + j) * 16 * BK + fa0);
+      afr[j][1] = *(const bf16x8*)(cur + (4 + j) * 16 * BK + fa1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    WSEG_PP_MFMA(1, 1);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3: quadrant (a1, b0); prefetch B0 B1 A0 of K tile g+2, retire K tile g+1 ----
+    if (!final && g + 2 < T) { issue_b(0); issue_b(1); issue_a(0); wait_vmcnt<6>(); }
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    WSEG_PP_MFMA(1, 0);
+    if (!final) __builtin_amdgcn_s_barrier();
+  }
+  // epilogue inside the M part of the last phase: group 1 is in its (empty) L part meanwhile, then the roles swap
+  staged_epilogue<EPI, MI, NI>(acc, (float*)(smem + ((g - 1) & 1) * BUF), ep, M, m0 + wr * TM, n0 + wc * TN, lane, wave);
+  __builtin_amdgcn_s_barrier();
+  }
+#undef WSEG_PP_MFMA
+  if (wr == 0) __builtin_amdgcn_s_barrier();          // pair group 1's extra barrier
 }
 
 template <int EPI, typename T>
@@ -758,7 +952,13 @@ static int launch_bf16(const GemmArgs& g, hipStream_t s) {
     }
     if (big256 && g.N % 256 == 0 && (long)cdiv(g.M, 256) * (g.N / 256) >= 192) {
       const int ntm = cdiv(g.M, 256), ntiles = ntm * (g.N / 256);
-      if (persist) {
+      static const bool pingpong = getenv("WSEG_GEMM_NO_PP") == nullptr;   // ping-pong kernel by default (tuning knob)
+      if (pingpong && g.K >= 128) {
+        int grid = ntiles < n_cu ? ntiles : n_cu;
+        grid &= ~7;
+        hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K, g.ep, ntm,
+                           group_m);
+      } else if (persist) {
         int grid = ntiles < n_cu ? ntiles : n_cu;
         grid &= ~7;
         hipLaunchKernelGGL((gemm_bf16_persist_kernel<256, 256, 2, 4, EPI>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
