@@ -561,17 +561,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_persist_kernel(const b
 //
 // Fragment reads of K tile g:  phase 0: b0, a0   phase 1: b1   phase 2: a1 (into a0's registers)   phase 3: none;
 // quadrants (a0,b0) (a0,b1) (a1,b1) (a1,b0).  Group x executes the L part of phase p in barrier interval 2p + x and
-// its reads are retired (lgkmcnt(0)) inside interval 2p + x + 1.  Hence, for the buffer of K tile g (p = 4g + i):
-//     B half-tiles (read by both groups in phases 0-1): free from interval 8g + 5
-//     A0 (read by group 0 only, phases 0 and 2):         free from interval 8g + 6
-//     A1 (read by group 1 only):                         free from interval 8g + 7
-// and the prefetch stream is      phase 3 of g: B0 B1 A0 of g+2, then s_waitcnt vmcnt(6);   phase 0 of g+1: A1 of g+2
-// (group 0 issues in intervals 8g + 6 and 8g + 8).  The counted wait retires K tile g+1 — its youngest half-tile
-// A1(g+1) was issued three phases earlier — in the L part of phase 3, i.e. two barriers before group 0 and three
-// before group 1 read it; the three half-tiles just issued stay in flight across the barrier.
+// its reads are retired (lgkmcnt(0)) inside interval 2p + x + 1.  Hence, for the buffer of K tile g (p = 4g + i), the
+// half-tiles may be overwritten
+//     B0, B1 (read by both groups in phases 0-1): from interval 8g + 5
+//     A0 (read by group 0 only, phases 0 and 2):  from interval 8g + 6
+//     A1 (read by group 1 only):                  from interval 8g + 7
+// and the prefetch stream is      phase 3 of g: B pair of K tile g+2 (intervals 8g+6 / 8g+7), then s_waitcnt vmcnt(4)
+//                                 phase 1 of g: A pair of K tile g+1 (it overwrites K tile g-1: free since 8g - 1)
+// i.e. 4 LDS-DMA pieces in the phase that reads nothing and 4 in the phase that reads least (an LDS-DMA costs an L
+// part ~80 cycles; with 6 + 2 pieces in phases 3 + 0 the kernel was 3-5 % slower, with the pieces between the MFMAs
+// 7-9 % slower).  The counted wait in the L part of phase 3 retires K tile g+1 (A pair issued two phases, B pair four
+// phases earlier) and leaves the B pair of g+2 in flight across the barrier; it is two barriers before group 0 and
+// three before group 1 read K tile g+1.
 // The K-tile stream is continuous across the output tiles a workgroup owns.  The last K tile e of an output tile
-// leaves buffer e & 1 to the epilogue as its staging area: the half-tiles of K tile e+2 are held back and issued
-// together in phase 1 of K tile e+1 (interval >= 8e + 10, after group 1 has left its epilogue in interval 8e + 8).
+// leaves buffer e & 1 to the epilogue as its staging area: the B pair of K tile e+2 is held back to phase 1 of K tile
+// e+1 (interval >= 8e + 10, after group 1 has left its epilogue in interval 8e + 8).
 // ------------------------------------------------------------------------------------------------
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
@@ -643,9 +647,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
     }
   };
 
-  // prologue: K tile 0 complete, B0 B1 A0 of K tile 1 in flight
+  // prologue: K tile 0 complete, B pair of K tile 1 in flight
   issue_b(0); issue_b(1); issue_a(0); issue_a(1);
-  if (T > 1) { issue_b(0); issue_b(1); issue_a(0); wait_vmcnt<6>(); }
+  if (T > 1) { issue_b(0); issue_b(1); wait_vmcnt<4>(); }
   else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();          // stagger: group 1 runs one barrier behind group 0
@@ -694,7 +698,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
       afr[j][0] = *(const bf16x8*)(cur + j * 16 * BK + fa0);
       afr[j][1] = *(const bf16x8*)(cur + j * 16 * BK + fa1);
     }
-    if (!first && g + 1 < T) issue_a(1);               // A1(g+1)
     __builtin_amdgcn_sched_barrier(0);
     WSEG_PP_MFMA(0, 0);
     __builtin_amdgcn_s_barrier();
@@ -704,7 +707,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
       bfr[i][0] = *(const bf16x8*)(cur + i * 16 * BK + fb0);
       bfr[i][1] = *(const bf16x8*)(cur + i * 16 * BK + fb1);
     }
-    if (first && g + 1 < T) { issue_b(0); issue_b(1); issue_a(0); issue_a(1); }     // K tile g+1, held back over the epilogue
+    if (first && g + 1 < T) { issue_b(0); issue_b(1); }        // B pair of K tile g+1, held back over the epilogue
+    if (g + 1 < T) { issue_a(0); issue_a(1); }                 // A pair of K tile g+1
     __builtin_amdgcn_sched_barrier(0);
     WSEG_PP_MFMA(0, 1);
     __builtin_amdgcn_s_barrier();
@@ -718,7 +722,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
     WSEG_PP_MFMA(1, 1);
     __builtin_amdgcn_s_barrier();
     // ---- phase 3: quadrant (a1, b0); prefetch B0 B1 A0 of K tile g+2, retire K tile g+1 ----
-    if (!final && g + 2 < T) { issue_b(0); issue_b(1); issue_a(0); wait_vmcnt<6>(); }
+    if (!final && g + 2 < T) { issue_b(0); issue_b(1); wait_vmcnt<4>(); }      // B pair of K tile g+2
     else wait_vmcnt<0>();
     __builtin_amdgcn_sched_barrier(0);
     WSEG_PP_MFMA(1, 0);
