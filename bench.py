@@ -7,8 +7,10 @@ One "step" = one pass of the whole hot path over one batch of synthetic windows 
 resident in HBM -> log-mel kernels -> Whisper encoder -> cross-K/V -> beam-search decode (libwseg) ->
 token ids to the host -> detokenise + regex parse (the CPU epilogue).  Workload (BASELINE.json metric):
 whisperseg-large geometry (1550 M), bf16, 30 s windows (spec_time_step 0.03 @ 16 kHz, 480 000 samples,
-SURVEY §8d), by default 120 windows = one 1-hour recording per GPU per step (BASELINE.json configs[3], sharded
-weakly: every GPU gets its own hour), all 120 windows decoded as one batch, seeded random weights (no checkpoint exists offline), synthetic 16 kHz sine+noise, beams 4,
+SURVEY §8d), by default 256 concurrent windows (2 h 8 min of audio) per GPU per step — the concurrency of
+BASELINE.json configs[4], sharded weakly: every GPU gets its own 256 windows; `--windows 120` is the one-hour
+recording of configs[3] — all windows of a step decoded as one batch, seeded random weights (no checkpoint exists
+offline), synthetic 16 kHz sine+noise, beams 4,
 decode length pinned to --gen-tokens with EOS suppressed (random weights never emit a meaningful EOS).
 Windows are independent, so ranks shard them with no data-path collective ("weak" scaling: fixed
 windows per GPU); the only exchange is the all_gather of token ids to every rank.
@@ -102,8 +104,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="large", choices=sorted(GEOMETRY))
-    ap.add_argument("--windows", type=int, default=120,
-                    help="30 s windows per GPU per step (default 120 = one 1-hour recording per GPU, BASELINE config[3])")
+    ap.add_argument("--windows", type=int, default=256,
+                    help="30 s windows per GPU per step (default 256 concurrent windows, BASELINE configs[4]; 120 = one 1-hour "
+                         "recording, configs[3])")
     ap.add_argument("--batch", type=int, default=0, help="windows per generate call (0 = all windows of the step)")
     ap.add_argument("--gen-tokens", type=int, default=32)
     ap.add_argument("--beams", type=int, default=4)
@@ -193,20 +196,25 @@ def main():
         fl, ms, n = C.c_double(), C.c_double(), C.c_int64()
         _lib.check(lib.wseg_profile_end(C.byref(fl), C.byref(ms), C.byref(n)))
         traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
-        if os.path.exists(tpath) and args.model == "large" and W == 120:
-            # PMC counters cannot be collected live next to the timing (separate rocprofv3 passes): use the committed
-            # pass over the same GEMM shapes (tools/pmc_traffic.sh), averaged over the four per-layer encoder GEMMs.
+        # PMC counters cannot be collected live next to the timing (separate rocprofv3 passes): use the committed pass
+        # over the same GEMM shapes at the same window count (tools/pmc_traffic.sh), averaged over the four per-layer
+        # encoder GEMMs.
+        import glob
+        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_gemm_hbm_traffic.json")), reverse=True):
             with open(tpath) as f:
-                pl = json.load(f)["per_launch"]
+                tj = json.load(f)
+            if args.model != "large" or tj.get("windows", 120) != W:
+                continue
+            pl = tj["per_launch"]
             keys = [k for k in ("qkv", "o-proj", "fc1", "fc2") if k in pl]
             traffic = sum(pl[k]["hbm_bytes"] for k in keys) / len(keys)
             traffic_note = ("bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, committed pass "
-                            "profiles/r01_gemm_hbm_traffic.json; algorithmic bytes per launch %.3g"
-                            % (sum(pl[k]["algorithmic_bytes"] for k in keys) / len(keys)))
+                            "profiles/%s; algorithmic bytes per launch %.3g"
+                            % (os.path.basename(tpath), sum(pl[k]["algorithmic_bytes"] for k in keys) / len(keys)))
+            break
         if n.value:
             achieved = fl.value / (ms.value * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel<256,256,2,4,*> (+<128,128,2,2,*> for narrow problems)", "achieved": achieved,
+            roofline = {"bound": "mfma", "kernel": "gemm_bf16_pp_kernel<*> (256x256 ping-pong tiles; + the 128x128 persistent kernel for narrow problems)", "achieved": achieved,
                         "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / (MFMA_PEAK_BF16 / 1e12),
                         "traffic": traffic, "traffic_note": traffic_note, "launches_per_step": int(n.value),
                         "avg_launch_us": ms.value * 1e3 / n.value, "flops_per_step": fl.value,

@@ -10,6 +10,7 @@ ap.add_argument("--windows", type=int, default=32)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--encoder-only", action="store_true")
 ap.add_argument("--decoder-only", action="store_true")
+ap.add_argument("--rotate", type=int, default=1, help="cycle through this many weight copies (cold weights, as in a decode step)")
 ap.add_argument("--shapes", default="", help="custom list 'M,N,K,epi;M,N,K,epi;...' (epi 0 bias, 1 bias+gelu, 2 bias+residual)")
 a = ap.parse_args()
 lib = _lib.load(require_device=True)
@@ -30,14 +31,17 @@ for name, m, n, k, epi in shapes:
     mp = (m + 255) // 256 * 256
     A = (torch.rand(mp, k, device="cuda") * 2 - 1).to(torch.bfloat16)
     W = (torch.rand(n, k, device="cuda") * 2 - 1).to(torch.bfloat16)
+    Ws = [W] + [W.clone() for _ in range(a.rotate - 1)]
+    call = [0]
     bias = torch.rand(n, device="cuda").to(torch.bfloat16)
     res = torch.rand(mp, n, device="cuda").to(torch.bfloat16)
     out = torch.empty(mp, n, device="cuda", dtype=torch.bfloat16)
     st = _lib.stream_ptr()
 
     def run():
-        _lib.check(lib.wseg_debug_gemm(1, epi, m, n, k, A.data_ptr(), W.data_ptr(), bias.data_ptr(), res.data_ptr(), out.data_ptr(),
-                                       ws.data_ptr(), ws.numel(), st))
+        call[0] += 1
+        _lib.check(lib.wseg_debug_gemm(1, epi, m, n, k, A.data_ptr(), Ws[call[0] % len(Ws)].data_ptr(), bias.data_ptr(), res.data_ptr(),
+                                       out.data_ptr(), ws.data_ptr(), ws.numel(), st))
     for _ in range(3):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -943,11 +943,11 @@ static int launch_bf16(const GemmArgs& g, hipStream_t s) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g_prof.on) { e0 = g_prof.get(); e1 = g_prof.get(); g_prof.flops.push_back(2.0 * g.M * g.N * g.K); (void)hipEventRecord(e0, s); }
     static const bool persist = getenv("WSEG_GEMM_NO_PERSIST") == nullptr;
-    // m-tiles per tile group of the persistent order.  The weight matrix of these GEMMs is small (<= 13 MB) next to the
-    // activations (154 MB at 120 windows): with 2-row groups the 32 tiles in flight on one XCD span ~2 activation
-    // tiles x many weight tiles, so every activation tile crosses the fabric once and only the weights are re-streamed
-    // (PMC FETCH_SIZE: see profiles/).
-    static const int group_m = getenv("WSEG_GEMM_GROUP_M") ? atoi(getenv("WSEG_GEMM_GROUP_M")) : 2;
+    // m-tiles per tile group of the persistent order: the 32 tiles in flight on one XCD then span ~4 activation tiles x 8
+    // weight tiles, the smallest operand footprint for 32 tiles (a + b = 12 operand tiles; 2-row groups re-stream the
+    // whole weight matrix per tile pair: PMC FETCH_SIZE 2-3x the algorithmic bytes, profiles/).  Measured at 256
+    // windows: 4 beats 2 by 2-8 % on the K = 1280 shapes, 6 and 8 lose on K = 5120.
+    static const int group_m = getenv("WSEG_GEMM_GROUP_M") ? atoi(getenv("WSEG_GEMM_GROUP_M")) : 4;
     static int n_cu = 0;
     if (n_cu == 0) {
       int dev = 0; hipDeviceProp_t prop;
