@@ -389,8 +389,16 @@ __global__ __launch_bounds__(256) void row_topk_partial_kernel(DecodeState st, c
   const float* x = logits + (size_t)r * st.ldv;
   const int cur_len = *st.pos + 1;
   const unsigned char bits = 1 | ((cur_len == st.P) ? 2 : 0);
+  // the slice as [lo, a4) scalar head, [a4, b4) 16-byte groups (rows are 16-byte aligned: ldv % 4 == 0), [b4, hi) tail:
+  // a row is 200 KB of fp32, one dword per lane per load left the scan latency-bound (0.66 TB/s at 1024 rows)
+  const int a4 = min(hi, (lo + 3) & ~3), b4 = max(a4, hi & ~3);
   float mx = -3.0e38f;
-  for (int i = lo + tid; i < hi; i += 256) mx = fmaxf(mx, x[i]);
+  for (int i = lo + tid; i < a4; i += 256) mx = fmaxf(mx, x[i]);
+  for (int i = a4 + tid * 4; i < b4; i += 1024) {
+    const float4 v = *(const float4*)(x + i);
+    mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+  }
+  for (int i = b4 + tid; i < hi; i += 256) mx = fmaxf(mx, x[i]);
   mx = wave_max(mx);
   if (lane == 0) s_red[wave] = mx;
   __syncthreads();
@@ -401,10 +409,9 @@ __global__ __launch_bounds__(256) void row_topk_partial_kernel(DecodeState st, c
   int ti[KC];
 #pragma unroll
   for (int j = 0; j < KC; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
-  for (int i = lo + tid; i < hi; i += 256) {
-    float v = x[i];
+  auto visit = [&](float v, int i, unsigned char sup) {
     sum += expf(v - mx);
-    if (st.sup_mask[i] & bits) v = -INFINITY;
+    if (sup & bits) v = -INFINITY;
     if (better(v, i, tv[KC - 1], ti[KC - 1])) {
 #pragma unroll
       for (int j = KC - 1; j >= 0; --j) {
@@ -414,7 +421,17 @@ __global__ __launch_bounds__(256) void row_topk_partial_kernel(DecodeState st, c
         else if (gt_cur) { tv[j] = v; ti[j] = i; }
       }
     }
+  };
+  for (int i = lo + tid; i < a4; i += 256) visit(x[i], i, st.sup_mask[i]);
+  for (int i = a4 + tid * 4; i < b4; i += 1024) {
+    const float4 v = *(const float4*)(x + i);
+    const uchar4 m4 = *(const uchar4*)(st.sup_mask + i);      // the mask buffer is 4-byte aligned and padded (align_up(V, 4))
+    visit(v.x, i, m4.x);
+    visit(v.y, i + 1, m4.y);
+    visit(v.z, i + 2, m4.z);
+    visit(v.w, i + 3, m4.w);
   }
+  for (int i = b4 + tid; i < hi; i += 256) visit(x[i], i, st.sup_mask[i]);
   sum = wave_sum(sum);
   if (lane == 0) s_red[wave] = sum;
   __syncthreads();
