@@ -38,3 +38,43 @@ def test_gemm_matches_torch(gpu_lib, M, N, K, epi, dtype):
     tol = 2e-2 if dtype == "bf16" else 2e-5          # bf16 output rounding (2^-8) dominates; f32 is accumulation order only
     assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
     assert torch.isnan(out[M:]).all() or M == Mp      # rows beyond M are never written
+
+
+# Shapes that reach the 256x256 ping-pong kernel (N % 256 == 0, >= 192 tiles): fewer tiles than workgroups x 2,
+# several tiles per workgroup (the K-tile stream crosses output tiles and holds the prefetch back over the epilogue),
+# the minimum K (2 K tiles), an odd number of K tiles, M not a tile multiple, and the bench's own row count.
+PP_SHAPES = [(12800, 1280, 1280), (8192, 2560, 128), (10000, 3840, 192), (66000, 1280, 320), (128000, 1280, 1280),
+             (30000, 5120, 1280), (25000, 2560, 5120)]
+
+
+@pytest.mark.parametrize("M,N,K", PP_SHAPES)
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_pingpong_gemm_matches_torch(gpu_lib, M, N, K, epi):
+    from whisperseg_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(M + N * 3 + K * 5 + epi)
+    Mp = (M + 255) // 256 * 256
+    A = (torch.rand(Mp, K, device="cuda", generator=g) * 2 - 1).to(torch.bfloat16)
+    W = ((torch.rand(N, K, device="cuda", generator=g) * 2 - 1) * K ** -0.5).to(torch.bfloat16)
+    bias = (torch.rand(N, device="cuda", generator=g) - 0.5).to(torch.bfloat16)
+    res = (torch.rand(Mp, N, device="cuda", generator=g) - 0.5).to(torch.bfloat16)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    outs = []
+    for rep in range(3):          # race screen: a mis-ordered LDS-DMA / ds_read shows up as run-to-run differences
+        out = torch.full((Mp, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        _lib.check(gpu_lib.wseg_debug_gemm(1, epi, M, N, K, A.data_ptr(), W.data_ptr(), bias.data_ptr(), res.data_ptr(),
+                                           out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0][:M].view(torch.int16), outs[1][:M].view(torch.int16))
+    assert torch.equal(outs[0][:M].view(torch.int16), outs[2][:M].view(torch.int16))
+    assert torch.isnan(outs[0][M:]).all()                      # rows past M are never written
+    worst = 0.0
+    for lo in range(0, M, 16384):                              # reference in row blocks (fp32 128000 x 5120 would be 2.6 GB)
+        hi = min(M, lo + 16384)
+        ref = A[lo:hi].float() @ W.float().T + bias.float()
+        if epi == 1:
+            ref = torch.nn.functional.gelu(ref)
+        if epi == 2:
+            ref = ref + res[lo:hi].float()
+        worst = max(worst, (outs[0][lo:hi].float() - ref).abs().max().item())
+    assert worst <= 2e-2, worst                                # O(1) outputs rounded to bf16 (2^-9 relative)

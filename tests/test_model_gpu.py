@@ -135,3 +135,30 @@ def test_base_geometry_bf16(gpu_lib):
     cos = torch.nn.functional.cosine_similarity(got, want, dim=1)
     assert cos.min().item() > 0.999
     assert lens.tolist() == [5, 5]
+
+
+def test_pingpong_gemm_epilogues_in_the_model_bf16(gpu_lib):
+    """50 windows at d=512 / 8 heads / ffn 2048 (2+2 layers): every large GEMM of the path has >= 192 tiles of 256x256, so
+    conv2 (+pos-emb), the QKV head split incl. V^T, o-proj / fc2 (residual), fc1 (GELU) and the cross-K/V head split all
+    run in the ping-pong kernel — encoder output and first-step logits vs the oracle, plus the size-independent
+    properties: beams of a window agree at the first step, and a permutation of the windows permutes the results."""
+    cfg = hf_cfg(d=512, heads=8, layers=2, ffn=2048, vocab=1280)
+    rc, sd, eng = make(cfg, "bf16", seed=21)
+    x = feats(50, seed=23)
+    want_enc = R.encoder_forward(sd, rc, x)
+    got_enc = eng.encode(x.cuda()).float().cpu()
+    assert (got_enc - want_enc).abs().max().item() <= 8e-2 * max(1.0, want_enc.abs().max().item())
+    gp = gen_params(4, 6)
+    _, want = R.generate(sd, rc, x, gp, return_first_logits=True)
+    toks, lens, got = eng.generate(x.cuda(), PROMPT, EOS, EOS, max_length=6, num_beams=4, suppress_tokens=gp.suppress_tokens,
+                                   begin_suppress_tokens=gp.begin_suppress_tokens, return_first_logits=True)
+    got = got.cpu()
+    assert (got - want).abs().max().item() <= 0.1 * max(1.0, want.abs().max().item())
+    assert torch.nn.functional.cosine_similarity(got, want, dim=1).min().item() > 0.999
+    assert torch.equal(got[0::4], got[1::4])
+    perm = torch.randperm(50, generator=torch.Generator().manual_seed(1))
+    toks_p, lens_p, got_p = eng.generate(x[perm].cuda(), PROMPT, EOS, EOS, max_length=6, num_beams=4,
+                                         suppress_tokens=gp.suppress_tokens, begin_suppress_tokens=gp.begin_suppress_tokens,
+                                         return_first_logits=True)
+    assert torch.equal(got_p.cpu()[0::4], got[0::4][perm])          # bit-identical rows: no dependence on the batch slot
+    assert torch.equal(toks_p.cpu(), toks.cpu()[perm]) and torch.equal(lens_p.cpu(), lens.cpu()[perm])
