@@ -721,7 +721,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
     __builtin_amdgcn_sched_barrier(0);
     WSEG_PP_MFMA(1, 1);
     __builtin_amdgcn_s_barrier();
-    // ---- phase 3: quadrant (a1, b0); prefetch B0 B1 A0 of K tile g+2, retire K tile g+1 ----
+    // ---- phase 3: quadrant (a1, b0); B pair of K tile g+2, retire K tile g+1 ----
     if (!final && g + 2 < T) { issue_b(0); issue_b(1); wait_vmcnt<4>(); }      // B pair of K tile g+2
     else wait_vmcnt<0>();
     __builtin_amdgcn_sched_barrier(0);
