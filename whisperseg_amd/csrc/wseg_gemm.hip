@@ -930,14 +930,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_resid_ln_kernel(const float
   }
 }
 
+// Large-tile kernels (128x128 / 256x256 output tiles, no split-K) or the weight-stream family (64-column tiles, split-K)?
+// Decoder-step GEMMs sit at the border.  Measured on the whole decode step (large, 4 beams): at 1024 rows fc1 (N = 5120,
+// 320 blocks of 128x128) is better in the stream family (decode step 10.71 -> 10.23 ms); at 1536 rows q|k|v (360 blocks)
+// and fc1 (480) are better on large tiles (13.50 vs 13.70 ms).
+static bool big_tile_path(const GemmArgs& g) {
+  static const long big_min = getenv("WSEG_BIG_MIN_BLOCKS") ? atol(getenv("WSEG_BIG_MIN_BLOCKS")) : 340;   // tuning knob
+  return g.M > 128 && g.N % 128 == 0 && (long)cdiv(g.M, 128) * (g.N / 128) >= big_min;
+}
+
 template <int EPI>
 static int launch_bf16(const GemmArgs& g, hipStream_t s) {
   const bf16_t* A = (const bf16_t*)g.A;
   const bf16_t* W = (const bf16_t*)g.W;
   if (g.K % 64 || g.N % 64) { set_error("gemm bf16: K %d / N %d not tile multiples", g.K, g.N); return WSEG_ERR_INVALID; }
-  static const long big_min = getenv("WSEG_BIG_MIN_BLOCKS") ? atol(getenv("WSEG_BIG_MIN_BLOCKS")) : 256;   // tuning knob
-  const long big_blocks = (long)cdiv(g.M, 128) * (g.N / 128);
-  if (g.M > 128 && g.N % 128 == 0 && big_blocks >= big_min) {
+  if (big_tile_path(g)) {
     static const bool no_swz = getenv("WSEG_NO_XCD_SWIZZLE") != nullptr;
     static const bool big256 = getenv("WSEG_GEMM_128") == nullptr;   // 256x256 tiles by default where they fill the chip
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1025,8 +1032,7 @@ static int launch_any(int dtype, const GemmArgs& g, hipStream_t s) {
 
 int launch_gemm_partial(int dtype, const GemmArgs& g, PartialInfo* info, bool* ok, hipStream_t s) {
   *ok = false;
-  const long big_blocks = (long)cdiv(g.M, 128) * (g.N / 128);
-  const bool big = g.M > 128 && g.N % 128 == 0 && big_blocks >= 256;
+  const bool big = big_tile_path(g);
   if (dtype != WSEG_BF16 || big || !g.splitk_ws || g.K % 64 || g.N % 64) return WSEG_OK;
   SkinnyPlan sp = plan_skinny(g);
   if ((size_t)sp.splits * sp.m_pad * g.N * sizeof(float) > g.splitk_ws_bytes) return WSEG_OK;
@@ -1041,8 +1047,7 @@ int launch_gemm_partial(int dtype, const GemmArgs& g, PartialInfo* info, bool* o
 int launch_gemm_resid_ln(int dtype, const GemmArgs& g0, const void* gamma, const void* beta, void* y, hipStream_t s) {
   GemmArgs g = g0;
   const int d = g.N;
-  const long big_blocks = (long)cdiv(g.M, 128) * (g.N / 128);
-  const bool big = g.M > 128 && g.N % 128 == 0 && big_blocks >= 256;
+  const bool big = big_tile_path(g);
   if (dtype == WSEG_BF16 && !big && g.splitk_ws && d % 8 == 0 && d <= 2048 && g.ep.bias && g.ep.resid == g.ep.out && g.ep.ldc == d &&
       g.K % 64 == 0 && g.N % 64 == 0) {
     SkinnyPlan sp = plan_skinny(g);
