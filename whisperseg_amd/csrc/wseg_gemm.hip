@@ -830,7 +830,8 @@ static SkinnyPlan plan_skinny(const GemmArgs& g) {
   if (g.splitk_ws) {
     // split K (in whole 64-wide tiles, >= 2 tiles per split) until ~256 workgroups stream the weights
     const int nk = g.K / 64;
-    for (int cand = 2; cand <= 16 && blocks * sp.splits < 256; ++cand) {
+    static const int target = getenv("WSEG_SKINNY_TARGET") ? atoi(getenv("WSEG_SKINNY_TARGET")) : 256;   // tuning knob
+    for (int cand = 2; cand <= 16 && blocks * sp.splits < target; ++cand) {
       if (nk % cand || nk / cand < 2) continue;
       if ((size_t)cand * sp.m_pad * g.N * sizeof(float) > g.splitk_ws_bytes) break;
       sp.splits = cand;
