@@ -158,20 +158,30 @@ __global__ __launch_bounds__(256) void enc_attention_bf16_kernel(const bf16_t* _
   float m_run = -1.0e30f, l_run = 0.f;
 
   const int n_tiles = (T + 63) / 64;
-  for (int kt = 0; kt < n_tiles; ++kt) {
-    __syncthreads();
-    // stage K tile and V^T tile (each 8 KiB): 512 16-byte chunks per tile, 2 per thread.
+  // K tile and V^T tile (each 8 KiB): 512 16-byte chunks per tile, 2 per thread; the NEXT tile's chunks are loaded into
+  // registers while the current tile is multiplied (rows are padded to Tp, so a tile is always readable)
+  uint4 kreg[2], vreg[2];
+  auto fetch = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = tid + i * 256, row = c >> 3, sl = c & 7;
-      const uint4 kv = *(const uint4*)(Kb + (size_t)(kt * 64 + row) * 64 + sl * 8);
-      *(uint4*)(sK + row * 64 + ((sl ^ (row & 7)) << 3)) = kv;
-      const uint4 vv = *(const uint4*)(Vb + (size_t)row * Tp + kt * 64 + sl * 8);
+      kreg[i] = *(const uint4*)(Kb + (size_t)(kt * 64 + row) * 64 + sl * 8);
+      vreg[i] = *(const uint4*)(Vb + (size_t)row * Tp + kt * 64 + sl * 8);
+    }
+  };
+  fetch(0);
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 256, row = c >> 3, sl = c & 7;
+      *(uint4*)(sK + row * 64 + ((sl ^ (row & 7)) << 3)) = kreg[i];
       const int sw = (row >> 1) & 15;
-      *(uint2*)(sV + row * 64 + (((2 * sl) ^ sw) << 2)) = make_uint2(vv.x, vv.y);
-      *(uint2*)(sV + row * 64 + (((2 * sl + 1) ^ sw) << 2)) = make_uint2(vv.z, vv.w);
+      *(uint2*)(sV + row * 64 + (((2 * sl) ^ sw) << 2)) = make_uint2(vreg[i].x, vreg[i].y);
+      *(uint2*)(sV + row * 64 + (((2 * sl + 1) ^ sw) << 2)) = make_uint2(vreg[i].z, vreg[i].w);
     }
     __syncthreads();
+    if (kt + 1 < n_tiles) fetch(kt + 1);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       const int key_base = kt * 64 + sub * 32;
@@ -205,8 +215,10 @@ __global__ __launch_bounds__(256) void enc_attention_bf16_kernel(const bf16_t* _
       ps += __shfl_xor(ps, 32, 64);
       l_run = l_run * alpha + ps;
       m_run = m_new;
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {      // no query of this wave raised its maximum: 32 multiplies by 1.0 saved
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      }
       // O^T[hd][q] += V^T[hd][key] P^T[key][q]; contraction slots of lane-half g2, MFMA mm:
       // keys 16*mm + 4*g2 + {0,1,2,3, 8,9,10,11}  == registers 8*mm .. 8*mm+7 of s.
 #pragma unroll
