@@ -177,6 +177,14 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
   const unsigned char* anc = st.anc + (size_t)r * L;
   for (int t = lane; t < n; t += 64) srow[t] = w * st.nb + (t == n - 1 ? (r - w * st.nb) : (int)anc[t]);
   __syncthreads();
+  // The V rows of the first 32 positions are requested together with the K rows (both depend only on the ancestry
+  // table): a wave is one chain of dependent HBM round trips, and this removes one of them for sequences <= 32.
+  float vfirst[4][8];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int tl = min(u * 8 + rowl, fused ? max(n - 2, 0) : n - 1);
+    load8<T>(vc + (((size_t)srow[tl] * H + h) * L + tl) * 64 + sub * 8, vfirst[u]);
+  }
   for (int t0 = 0; t0 < n; t0 += 32) {
     float kv[4][8];
 #pragma unroll
@@ -217,7 +225,12 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
     for (int u = 0; u < 4; ++u) {
       const int t = t0 + u * 8 + rowl;
       const int tl = min(t, fused ? max(n - 2, 0) : n - 1);
-      load8<T>(vc + (((size_t)srow[tl] * H + h) * L + tl) * 64 + sub * 8, vv[u]);
+      if (t0 == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vv[u][e] = vfirst[u][e];
+      } else {
+        load8<T>(vc + (((size_t)srow[tl] * H + h) * L + tl) * 64 + sub * 8, vv[u]);
+      }
       if (fused && t == n - 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) vv[u][e] = snv[sub * 8 + e];
@@ -394,7 +407,8 @@ __global__ __launch_bounds__(256) void row_topk_partial_kernel(DecodeState st, c
   const int a4 = min(hi, (lo + 3) & ~3), b4 = max(a4, hi & ~3);
   float mx = -3.0e38f;
   for (int i = lo + tid; i < a4; i += 256) mx = fmaxf(mx, x[i]);
-  for (int i = a4 + tid * 4; i < b4; i += 1024) {
+#pragma unroll 8
+  for (int i = a4 + tid * 4; i < b4; i += 1024) {          // unrolled: 8 independent 16-byte loads in flight per lane
     const float4 v = *(const float4*)(x + i);
     mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
   }
@@ -423,6 +437,7 @@ __global__ __launch_bounds__(256) void row_topk_partial_kernel(DecodeState st, c
     }
   };
   for (int i = lo + tid; i < a4; i += 256) visit(x[i], i, st.sup_mask[i]);
+#pragma unroll 4
   for (int i = a4 + tid * 4; i < b4; i += 1024) {
     const float4 v = *(const float4*)(x + i);
     const uchar4 m4 = *(const uchar4*)(st.sup_mask + i);      // the mask buffer is 4-byte aligned and padded (align_up(V, 4))
