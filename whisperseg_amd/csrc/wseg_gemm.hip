@@ -575,7 +575,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_persist_kernel(const b
 // three before group 1 read K tile g+1.
 // The K-tile stream is continuous across the output tiles a workgroup owns.  The last K tile e of an output tile
 // leaves buffer e & 1 to the epilogue as its staging area: the B pair of K tile e+2 is held back to phase 1 of K tile
-// e+1 (interval >= 8e + 10, after group 1 has left its epilogue in interval 8e + 8).
+// e+1, which both groups reach only after the barrier that closes the (shared) epilogue interval.
 // ------------------------------------------------------------------------------------------------
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
@@ -728,9 +728,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
     WSEG_PP_MFMA(1, 0);
     if (!final) __builtin_amdgcn_s_barrier();
   }
-  // epilogue inside the M part of the last phase: group 1 is in its (empty) L part meanwhile, then the roles swap
+  // Epilogue: group 0 gives up its one-barrier lead (it idles while group 1 finishes its last 16 MFMAs), both groups run
+  // their epilogues in the SAME interval — back to back they cost two epilogue times with the matrix pipe idle, side by
+  // side the loads / stores of 8 waves overlap (o-proj 459 -> 441 us, fc1 1653 -> 1598 us at 256 windows) — and group 1
+  // then drops one barrier behind again.  Every wave stages in its own strip of the buffer the last K tile left; nothing
+  // is prefetched into that buffer before phase 1 of the next K tile, which both groups reach only after the barrier
+  // below.  (Requesting group 0's residual rows before its idle interval measured no further gain.)
+  if (wr == 0) __builtin_amdgcn_s_barrier();
   staged_epilogue<EPI, MI, NI>(acc, (float*)(smem + ((g - 1) & 1) * BUF), ep, M, m0 + wr * TM, n0 + wc * TN, lane, wave);
   __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();
   }
 #undef WSEG_PP_MFMA
   if (wr == 0) __builtin_amdgcn_s_barrier();          // pair group 1's extra barrier
