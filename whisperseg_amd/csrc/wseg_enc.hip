@@ -138,7 +138,10 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return pack_bf
 __global__ __launch_bounds__(256) void enc_attention_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ Vt, bf16_t* __restrict__ out,
                                                                  int H, int T, int Tp, int d) {
-  __shared__ __attribute__((aligned(16))) bf16_t sK[64 * 64];   // [key][64 hd], 16-B slots XOR (key & 7)
+  // [key][64 hd], 16-B slots XOR ((key >> 1) & 7): a 32-row MFMA fragment read (lane = row + 32*half) is serviced in the
+  // lane groups {0-3,12-15,20-27}, ... and needs 16 distinct (row & 1, slot) pairs per group — XOR (key & 7), right for
+  // 16-row fragments, was 2-way conflicted here (SQ_LDS_BANK_CONFLICT 44 % of LDS cycles)
+  __shared__ __attribute__((aligned(16))) bf16_t sK[64 * 64];
   __shared__ __attribute__((aligned(16))) bf16_t sV[64 * 64];   // [hd][64 keys], 8-B granules XOR ((hd >> 1) & 15)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void enc_attention_bf16_kernel(const bf16_t* _
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = tid + i * 256, row = c >> 3, sl = c & 7;
-      *(uint4*)(sK + row * 64 + ((sl ^ (row & 7)) << 3)) = kreg[i];
+      *(uint4*)(sK + row * 64 + ((sl ^ ((row >> 1) & 7)) << 3)) = kreg[i];
       const int sw = (row >> 1) & 15;
       *(uint2*)(sV + row * 64 + (((2 * sl) ^ sw) << 2)) = make_uint2(vreg[i].x, vreg[i].y);
       *(uint2*)(sV + row * 64 + (((2 * sl + 1) ^ sw) << 2)) = make_uint2(vreg[i].z, vreg[i].w);
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(256) void enc_attention_bf16_kernel(const bf16_t* _
       const int krow = sub * 32 + qi;
 #pragma unroll
       for (int hs = 0; hs < 4; ++hs) {
-        const bf16x8 kf = *(const bf16x8*)(sK + krow * 64 + (((hs * 2 + g2) ^ (krow & 7)) << 3));
+        const bf16x8 kf = *(const bf16x8*)(sK + krow * 64 + (((hs * 2 + g2) ^ ((krow >> 1) & 7)) << 3));
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[hs], s, 0, 0, 0);
       }
       if (key_base + 32 > T) {
