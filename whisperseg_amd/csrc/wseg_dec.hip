@@ -378,6 +378,195 @@ __global__ __launch_bounds__(256, 5) void dec_cross_attn_kernel(DecodeState st, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 cross-attention with packed arithmetic — the SAME arithmetic in the same order as the kernel above (bit-equal
+// results), at about half the VALU instructions.  The kernel above spends ~120 VALU instructions per 8 K/V rows (8 FMAs
+// per beam and row slice, lane reductions through ds_bpermute) and that time (~65 us of a 145-160-us launch at 256
+// windows) does not hide under the loads: a plain streaming probe (tools/probes/stream_probe.hip) reads HBM at
+// 6.9-7.1 TB/s on this part, the kernel above at 4.1-4.5.  Here: two beams per v_pk_fma_f32 in the score chain and in
+// the probability-weighted sum, the 8-lane row sums by DPP adds (quad_perm, quad_perm, row_half_mirror: no LDS), one
+// predicated score store per row, rows kept raw (4 VGPRs) until used so that 8 per lane are in flight.
+// (v_dot2c_f32_bf16 scores are 8 instructions per row shorter still, but sum in another order — one boundary of the
+// tiny-model parity test moved by two mel frames — so the FMA chain stays.)
+// ------------------------------------------------------------------------------------------------
+// Sum over the 8 lanes that share a K/V row (lanes 8k .. 8k+7), result in all of them, with DPP adds (no LDS traffic:
+// __shfl_xor compiles to ds_bpermute_b32 + s_waitcnt).  Same pairing as xor 1, 2, 4: bit-equal.
+__device__ __forceinline__ float row8_sum(float a) {
+  a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  return a;
+}
+
+template <int NB>
+__global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState st, const bf16_t* __restrict__ q,
+                                                                   const bf16_t* __restrict__ ck, const bf16_t* __restrict__ cv,
+                                                                   bf16_t* __restrict__ out, int H, int Tk, int d, PartialInfo pi,
+                                                                   const bf16_t* __restrict__ q_bias, float scale) {
+  typedef unsigned int raw16 __attribute__((ext_vector_type(4)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  constexpr int U = 8;                                  // K/V rows in flight per lane
+  __shared__ float sc[NB][512];
+  __shared__ float red[4][NB][64];
+  __shared__ float sinv[NB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int w = blockIdx.x / H, h = blockIdx.x - w * H;
+  const int nb = st.nb;
+  const int sub = lane & 7, rowl = lane >> 3;
+  const bf16_t* Kb = ck + ((size_t)w * H + h) * Tk * 64;
+  const bf16_t* Vb = cv + ((size_t)w * H + h) * Tk * 64;
+  // this lane's 8-dim slice of every beam's (pre-scaled) query, fp32, beams paired for v_pk_fma_f32: qq[e][j2] holds
+  // dim e of beams 2*j2 and 2*j2+1
+  constexpr int NP = (NB + 1) / 2;
+  f2 qq[8][NP];
+  {
+    float qv[8];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if (pi.part != nullptr) {
+        reduce8<bf16_t>(pi, w * nb + min(j, nb - 1), h * 64 + sub * 8, q_bias, qv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] = El<bf16_t>::rnd(qv[e] * scale);
+      } else {
+        load8<bf16_t>(q + (size_t)(w * nb + min(j, nb - 1)) * d + h * 64 + sub * 8, qv);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qq[e][j >> 1][j & 1] = qv[e];
+    }
+    if constexpr (NB == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qq[e][0][1] = 0.f;
+    }
+  }
+  for (int t0 = 0; t0 < Tk; t0 += 32 * U) {
+    raw16 kr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = min(t0 + u * 32 + wave * 8 + rowl, Tk - 1);      // clamped: out-of-range rows are discarded below
+      kr[u] = __builtin_nontemporal_load((const raw16*)(Kb + (size_t)t * 64 + sub * 8));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + u * 32 + wave * 8 + rowl;
+      // scores: the fp32 FMA chain over the 8 dims of the kernel above (bit-equal), two beams per v_pk_fma_f32
+      float kv[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { kv[2 * e] = __uint_as_float(kr[u][e] << 16); kv[2 * e + 1] = __uint_as_float(kr[u][e] & 0xffff0000u); }
+      float a[NB];
+#ifdef WSEG_DBG_SCALAR_K
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        float t2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t2 = fmaf(qq[e][j >> 1][j & 1], kv[e], t2);
+        a[j] = t2;
+      }
+#else
+      f2 a2[NP];
+#pragma unroll
+      for (int j2 = 0; j2 < NP; ++j2) a2[j2] = (f2){0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const f2 kk = {kv[e], kv[e]};
+#pragma unroll
+        for (int j2 = 0; j2 < NP; ++j2) a2[j2] = __builtin_elementwise_fma(qq[e][j2], kk, a2[j2]);
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) a[j] = a2[j >> 1][j & 1];
+#endif
+      // the three DPP steps beam-interleaved: a DPP read needs wait states after the write of its source
+#pragma unroll
+      for (int j = 0; j < NB; ++j) a[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[j]), 0xB1, 0xF, 0xF, true));
+#pragma unroll
+      for (int j = 0; j < NB; ++j) a[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[j]), 0x4E, 0xF, 0xF, true));
+#pragma unroll
+      for (int j = 0; j < NB; ++j) a[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[j]), 0x141, 0xF, 0xF, true));
+      // lane `sub` of the row stores beam `sub`: one predicated store per row instead of one per beam
+#ifdef WSEG_DBG_SCALAR_K
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        if (sub == 0 && t < Tk && j < nb) sc[j][t] = a[j];
+#else
+      float mine = a[0];
+#pragma unroll
+      for (int j = 1; j < NB; ++j) mine = sub == j ? a[j] : mine;
+      if (sub < nb && t < Tk) sc[sub][t] = mine;
+#endif
+    }
+  }
+  __syncthreads();
+  for (int j = wave; j < nb; j += 4) {
+    float mx = -3.0e38f;
+    for (int t = lane; t < Tk; t += 64) mx = fmaxf(mx, sc[j][t]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int t = lane; t < Tk; t += 64) { const float p = expf(sc[j][t] - mx); sc[j][t] = p; sum += p; }
+    sum = wave_sum(sum);
+    if (lane == 0) sinv[j] = 1.0f / sum;
+  }
+  __syncthreads();
+  static_assert(NB == 1 || NB == 2 || NB == 4, "beam tiles");
+  const unsigned sc_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&sc[0][0];
+  f2 acc[NB][4];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[j][e] = (f2){0.f, 0.f};
+  for (int t0 = 0; t0 < Tk; t0 += 32 * U) {
+    raw16 vr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = min(t0 + u * 32 + wave * 8 + rowl, Tk - 1);
+      vr[u] = __builtin_nontemporal_load((const raw16*)(Vb + (size_t)t * 64 + sub * 8));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + u * 32 + wave * 8 + rowl;
+      const bool ok = t < Tk;
+      const int tc = ok ? t : Tk - 1;
+      f2 vv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vv[e] = (f2){__uint_as_float(vr[u][e] << 16), __uint_as_float(vr[u][e] & 0xffff0000u)};
+      // probabilities of this row through opaque ds_reads: as C++ loads the compiler gathers all U x NB of them in front
+      // of the loop and spills the rows that are in flight (reading the next row's ahead of time costs more registers
+      // than it hides: measured slower).  Early-clobber outputs: a result register must not be the address register —
+      // other waves issue between these instructions, so an earlier read can land before a later one is issued.
+      float pr[NB];
+      const unsigned pa = sc_base + (unsigned)tc * 4u;
+      if constexpr (NB == 1) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(pr[0]) : "v"(pa) : "memory");
+      else if constexpr (NB == 2)
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:2048\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pr[0]), "=&v"(pr[1]) : "v"(pa) : "memory");
+      else
+        asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:2048\n\tds_read_b32 %2, %4 offset:4096\n\tds_read_b32 %3, %4 offset:6144\n\t"
+                     "s_waitcnt lgkmcnt(0)" : "=&v"(pr[0]), "=&v"(pr[1]), "=&v"(pr[2]), "=&v"(pr[3]) : "v"(pa) : "memory");
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const float p = (ok && j < nb) ? pr[j] : 0.f;
+        const f2 pp = {p, p};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][e] = __builtin_elementwise_fma(pp, vv[e], acc[j][e]);
+      }
+    }
+  }
+  // reduce over the 8 row-lanes of the wave (lanes with equal `sub`), then over the 4 waves through LDS
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = acc[j][e >> 1][e & 1];
+      a += __shfl_xor(a, 8, 64);
+      a += __shfl_xor(a, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      if (rowl == 0) red[wave][j][sub * 8 + e] = a;
+    }
+  __syncthreads();
+  for (int i = tid; i < nb * 64; i += 256) {
+    const int j = i >> 6, e = i & 63;
+    const float o = ((red[0][j][e] + red[1][j][e]) + red[2][j][e]) + red[3][j][e];
+    El<bf16_t>::st(out + (size_t)(w * nb + j) * d + h * 64 + e, o * sinv[j]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Per-row candidates: log_softmax (fp32) -> suppress -> + running beam score -> top-Kc.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool better(float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); }
@@ -718,7 +907,14 @@ int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const
   if (Tk > 512) { set_error("cross-attention: %d encoder positions > 512", Tk); return WSEG_ERR_INVALID; }
   PartialInfo pi;
   if (q_part) pi = *q_part;
-  if (dtype == WSEG_BF16) launch_cross_t<bf16_t>(st, (const bf16_t*)q, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)out, H, Tk, d, pi, (const bf16_t*)q_bias, scale, s);
+  static const bool deep = getenv("WSEG_CROSS_NO_PK") == nullptr;         // tuning knob: fp32-FMA kernel
+  if (dtype == WSEG_BF16 && deep && Tk <= 512 && st.nb <= 4) {
+    dim3 grid(st.W * H), block(256);
+    const bf16_t *qb = (const bf16_t*)q, *kb = (const bf16_t*)ck, *vb = (const bf16_t*)cv, *bb = (const bf16_t*)q_bias;
+    if (st.nb <= 1) hipLaunchKernelGGL((dec_cross_attn_pk_kernel<1>), grid, block, 0, s, st, qb, kb, vb, (bf16_t*)out, H, Tk, d, pi, bb, scale);
+    else if (st.nb <= 2) hipLaunchKernelGGL((dec_cross_attn_pk_kernel<2>), grid, block, 0, s, st, qb, kb, vb, (bf16_t*)out, H, Tk, d, pi, bb, scale);
+    else hipLaunchKernelGGL((dec_cross_attn_pk_kernel<4>), grid, block, 0, s, st, qb, kb, vb, (bf16_t*)out, H, Tk, d, pi, bb, scale);
+  } else if (dtype == WSEG_BF16) launch_cross_t<bf16_t>(st, (const bf16_t*)q, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)out, H, Tk, d, pi, (const bf16_t*)q_bias, scale, s);
   else launch_cross_t<float>(st, (const float*)q, (const float*)ck, (const float*)cv, (float*)out, H, Tk, d, pi, (const float*)q_bias, scale, s);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
