@@ -140,6 +140,15 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const floa
   *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// Sum over the 8 lanes that share a K/V row (lanes 8k .. 8k+7), result in all of them, with DPP adds (no LDS traffic:
+// __shfl_xor compiles to ds_bpermute_b32 + s_waitcnt).  Same pairing as xor 1, 2, 4: bit-equal.
+__device__ __forceinline__ float row8_sum(float a) {
+  a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  return a;
+}
+
 template <typename T>
 __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const T* __restrict__ q, T* __restrict__ kc,
                                                            T* __restrict__ vc, T* __restrict__ out, int H, int d,
@@ -204,9 +213,7 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
       float s = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) s = fmaf(qv[e], kv[u][e], s);
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
+      s = row8_sum(s);
       if (sub == 0 && t < n) sp[t] = s;
     }
   }
@@ -309,9 +316,7 @@ __global__ __launch_bounds__(256, 5) void dec_cross_attn_kernel(DecodeState st, 
         float s = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) s = fmaf(qv[j][e], kv[u][e], s);
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
+        s = row8_sum(s);
         if (sub == 0 && t < Tk && j < nb) sc[j][t] = s;
       }
     }
@@ -388,15 +393,6 @@ __global__ __launch_bounds__(256, 5) void dec_cross_attn_kernel(DecodeState st, 
 // (v_dot2c_f32_bf16 scores are 8 instructions per row shorter still, but sum in another order — one boundary of the
 // tiny-model parity test moved by two mel frames — so the FMA chain stays.)
 // ------------------------------------------------------------------------------------------------
-// Sum over the 8 lanes that share a K/V row (lanes 8k .. 8k+7), result in all of them, with DPP adds (no LDS traffic:
-// __shfl_xor compiles to ds_bpermute_b32 + s_waitcnt).  Same pairing as xor 1, 2, 4: bit-equal.
-__device__ __forceinline__ float row8_sum(float a) {
-  a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-  a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-  a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x141, 0xF, 0xF, true));   // row_half_mirror
-  return a;
-}
-
 template <int NB>
 __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState st, const bf16_t* __restrict__ q,
                                                                    const bf16_t* __restrict__ ck, const bf16_t* __restrict__ cv,
