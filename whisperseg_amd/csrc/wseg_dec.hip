@@ -447,16 +447,6 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
       float kv[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { kv[2 * e] = __uint_as_float(kr[u][e] << 16); kv[2 * e + 1] = __uint_as_float(kr[u][e] & 0xffff0000u); }
-      float a[NB];
-#ifdef WSEG_DBG_SCALAR_K
-#pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        float t2 = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) t2 = fmaf(qq[e][j >> 1][j & 1], kv[e], t2);
-        a[j] = t2;
-      }
-#else
       f2 a2[NP];
 #pragma unroll
       for (int j2 = 0; j2 < NP; ++j2) a2[j2] = (f2){0.f, 0.f};
@@ -466,9 +456,9 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
 #pragma unroll
         for (int j2 = 0; j2 < NP; ++j2) a2[j2] = __builtin_elementwise_fma(qq[e][j2], kk, a2[j2]);
       }
+      float a[NB];
 #pragma unroll
       for (int j = 0; j < NB; ++j) a[j] = a2[j >> 1][j & 1];
-#endif
       // the three DPP steps beam-interleaved: a DPP read needs wait states after the write of its source
 #pragma unroll
       for (int j = 0; j < NB; ++j) a[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[j]), 0xB1, 0xF, 0xF, true));
@@ -477,16 +467,10 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
 #pragma unroll
       for (int j = 0; j < NB; ++j) a[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[j]), 0x141, 0xF, 0xF, true));
       // lane `sub` of the row stores beam `sub`: one predicated store per row instead of one per beam
-#ifdef WSEG_DBG_SCALAR_K
-#pragma unroll
-      for (int j = 0; j < NB; ++j)
-        if (sub == 0 && t < Tk && j < nb) sc[j][t] = a[j];
-#else
       float mine = a[0];
 #pragma unroll
       for (int j = 1; j < NB; ++j) mine = sub == j ? a[j] : mine;
       if (sub < nb && t < Tk) sc[sub][t] = mine;
-#endif
     }
   }
   __syncthreads();
