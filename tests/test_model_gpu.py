@@ -162,3 +162,33 @@ def test_pingpong_gemm_epilogues_in_the_model_bf16(gpu_lib):
                                          return_first_logits=True)
     assert torch.equal(got_p.cpu()[0::4], got[0::4][perm])          # bit-identical rows: no dependence on the batch slot
     assert torch.equal(toks_p.cpu(), toks.cpu()[perm]) and torch.equal(lens_p.cpu(), lens.cpu()[perm])
+
+
+def test_packed_cross_attention_is_bit_equal_to_the_fma_kernel(gpu_lib):
+    """dec_cross_attn_pk_kernel (v_pk_fma_f32 over beam pairs, DPP row sums) against dec_cross_attn_kernel (WSEG_CROSS_NO_PK=1,
+    a process-wide switch read once: two child processes): first-step logits and tokens identical for 1, 2, 3 and 4 beams."""
+    import os, subprocess, sys, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[2])
+from whisperseg_amd.engine import Engine
+cfg = dict(d_model=512, encoder_attention_heads=8, decoder_attention_heads=8, encoder_layers=1, decoder_layers=3,
+           encoder_ffn_dim=1024, decoder_ffn_dim=1024, vocab_size=1280, num_mel_bins=80, max_source_positions=500, max_target_positions=448)
+eng = Engine.random(cfg, "cuda:0", "bf16", seed=3)
+x = torch.randn(10, 80, 1000, generator=torch.Generator().manual_seed(5)) * 0.5
+out = {}
+for nb in (1, 2, 3, 4):
+    t, l, fl = eng.generate(x.cuda(), [1100, 1102, 1103], 1101, 1101, max_length=14, num_beams=nb, return_first_logits=True)
+    out[nb] = (t.cpu(), l.cpu(), fl.cpu())
+torch.save(out, sys.argv[1])
+'''
+    with tempfile.TemporaryDirectory() as tmp:
+        res = {}
+        for tag, env in (("pk", {}), ("fma", {"WSEG_CROSS_NO_PK": "1"})):
+            path = os.path.join(tmp, tag + ".pt")
+            subprocess.check_call([sys.executable, "-c", code, path, root], env={**os.environ, **env})
+            res[tag] = torch.load(path)
+    for nb in (1, 2, 3, 4):
+        for got, want in zip(res["pk"][nb], res["fma"][nb]):
+            assert torch.equal(got, want), nb
