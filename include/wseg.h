@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define WSEG_ABI_VERSION 1
+#define WSEG_ABI_VERSION 2
 
 typedef enum {
   WSEG_OK = 0,
@@ -116,7 +116,7 @@ int wseg_model_set_tensor(wseg_model* m, const char* name, const void* dev_ptr, 
 /* 0 when every tensor the geometry needs has been attached. */
 int wseg_model_ready(const wseg_model* m);
 
-/* Workspace (device bytes) needed for up to max_windows windows per call. */
+/* Workspace (device bytes) for max_windows window slots (= windows per encoder pass and windows decoded concurrently). */
 size_t wseg_workspace_bytes(const wseg_model* m, int32_t max_windows, int32_t num_beams, int32_t max_length);
 
 /*
@@ -137,6 +137,13 @@ typedef struct {
   int32_t n_suppress;
   const int32_t* begin_suppress_tokens; /* device [n_begin_suppress] applied at the first generated position */
   int32_t n_begin_suppress;
+  /* In-flight batching (the reference decodes batch by batch, model.py:653, one file at a time,
+   * scripts/segment.py:39-56).  0 selects the default of each. */
+  int32_t n_slots;                /* window slots decoded concurrently; 0 or >= n_windows: one slot per window          */
+  int32_t refill_min;             /* admit queued windows once this many slots are free; 0: n_slots / 8 (min 1)         */
+  int32_t lookahead;              /* decode steps the host may run ahead of the device; 0: 2                            */
+  const int32_t* window_max_length; /* device [n_windows] per-window cap on the total length (clamped to max_length), or
+                                     NULL: every window may run to max_length                                           */
 } wseg_generate_params;
 
 /*
@@ -144,18 +151,33 @@ typedef struct {
  * (generation/utils.py:3208-3510), entirely on device.
  *   out_tokens  device int32 [n_windows][max_length]  best sequence INCLUDING the prompt, pad-filled
  *   out_lengths device int32 [n_windows]              number of valid tokens (prompt + generated)
- * The call is asynchronous with respect to the host except for a small per-step "all finished" poll.
+ * The windows are decoded through n_slots window slots: a slot whose window has finished (EOS / early-stop heuristic /
+ * max_length) is retired and re-used for the next queued window while the other slots keep decoding, every slot at its
+ * own position.  Idle slots are skipped by every per-step kernel.  The workspace is sized by
+ * wseg_workspace_bytes(m, n_slots, ...): it does not grow with n_windows.  The host stays `lookahead` steps ahead of
+ * the device and otherwise only waits on the small per-step status mirror.
  */
 int wseg_generate(wseg_model* m, const float* feats, int32_t n_windows, const wseg_generate_params* p,
                   void* workspace, size_t workspace_bytes,
                   int32_t* out_tokens, int32_t* out_lengths, void* stream);
+
+/* Scheduler statistics of the last wseg_generate call on this model. */
+typedef struct {
+  int32_t n_windows, n_slots;
+  int32_t n_steps;                /* decode steps launched (each steps every active slot once)                          */
+  int32_t n_admissions;           /* encoder + cross-K/V passes (groups of windows admitted into free slots)            */
+  int64_t slot_steps_active;      /* sum over steps of slots that were decoding a window                                */
+  int64_t slot_steps_total;       /* n_steps * n_slots                                                                  */
+} wseg_generate_stats;
+int wseg_last_stats(const wseg_model* m, wseg_generate_stats* out);
 
 /* Debug/parity taps (used by tests): first-step logits fp32 [n_windows*num_beams][vocab] of the last
  * wseg_generate call are kept in the workspace; this copies them out (device to device). */
 int wseg_debug_first_logits(wseg_model* m, void* workspace, float* out, int32_t n_rows, void* stream);
 
 /* Per-stage device time (ms) of the last wseg_generate call on this model, measured with HIP events
- * on the call's stream: [0]=encoder, [1]=cross-K/V, [2]=decode loop, [3]=number of decode steps. */
+ * on the call's stream: [0]=encoder passes, [1]=cross-K/V passes, [2]=everything else (the decode steps),
+ * [3]=number of decode steps. */
 int wseg_last_timing(const wseg_model* m, float out[4]);
 
 /* Test / tuning tap: out[M][N] = epilogue(A[M][K] * W[N][K]^T + bias) with the library's GEMM of the given dtype.
@@ -164,7 +186,7 @@ int wseg_last_timing(const wseg_model* m, float out[4]);
 int wseg_debug_gemm(int32_t dtype, int32_t epi, int32_t M, int32_t N, int32_t K, const void* A, const void* W,
                     const void* bias, const void* resid, void* out, void* splitk_ws, size_t splitk_ws_bytes, void* stream);
 
-/* Live per-launch timing of the dominant kernel (the 128x128 bf16 MFMA GEMM) with HIP events recorded on
+/* Live per-launch timing of the dominant kernel (the 256x256 ping-pong bf16 MFMA GEMM; 128x128 persistent for narrow problems) with HIP events recorded on
  * the launching stream.  Between begin and end every launch of that kernel is bracketed by two events;
  * end synchronises and returns the sums: algorithmic FLOPs (2*M*N*K of the real, un-padded problem),
  * kernel milliseconds and the number of launches.  Process-wide; intended for bench.py's roofline leg. */

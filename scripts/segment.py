@@ -55,9 +55,9 @@ def main(argv=None):
         assert args.audio_folder is not None, "Either audio_path or audio_folder needs to be specified!"
         columns, rows = ["filename", "onset", "offset", "cluster"], []
         paths = glob.glob(args.audio_folder + "/*.wav") + glob.glob(args.audio_folder + "/*.WAV")
-        loaded = [load_wav(path) for path in paths]
-        # same rows as the reference's serial loop, but the windows of all files share decode batches
-        results = segmenter.segment_batch([a for a, _ in loaded], [sr for _, sr in loaded], **kwargs)
+        # same rows as the reference's serial loop, but the windows of many files share the engine's decode slots; files
+        # are read lazily, group by group, so a large folder needs no more memory than a small one
+        results = segmenter.segment_batch((load_wav(path) for path in paths), **kwargs)
         for path, res in zip(paths, results):
             name = os.path.basename(path)
             rows += [(name, on, off, c) for on, off, c in zip(res["onset"], res["offset"], res["cluster"])]

@@ -22,15 +22,33 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     assert set(names) == set(_lib.SYMBOLS), set(names) ^ set(_lib.SYMBOLS)
     bound = _lib.load()
-    assert bound.wseg_abi_version() == 1
+    assert bound.wseg_abi_version() == 2
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """ctypes mirrors == what a C compiler makes of include/wseg.h (sizes and every field offset)."""
+    import subprocess
     from whisperseg_amd import _lib
-    assert ctypes.sizeof(_lib.ModelConfig) == 11 * 4
-    assert ctypes.sizeof(_lib.LogmelDesc) == 4 * 4 + 6 * 8
-    # prompt[8] + 6 ints/floats, two (pointer, int) pairs with natural alignment
-    assert ctypes.sizeof(_lib.GenerateParams) == 8 * 4 + 6 * 4 + 8 + 8 + 8 + 8
+    structs = {"wseg_model_config": _lib.ModelConfig, "wseg_logmel_desc": _lib.LogmelDesc,
+               "wseg_generate_params": _lib.GenerateParams, "wseg_generate_stats": _lib.GenerateStats}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "wseg.h"', "int main(void) {"]
+    for cname, ct in structs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = {}
+    for line in subprocess.check_output([str(exe)], text=True).splitlines():
+        cname, field, val = line.split()
+        got[(cname, field)] = int(val)
+    for cname, ct in structs.items():
+        assert got[(cname, "size")] == ctypes.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert got[(cname, fname)] == getattr(ct, fname).offset, (cname, fname)
 
 
 def test_product_fails_loudly_without_device():

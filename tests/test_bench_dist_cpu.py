@@ -1,0 +1,53 @@
+"""bench.py's launch + distributed path on CPU (gloo, world size 2) with a stub engine (tests/bench_stub_driver.py):
+`--gpus 2` outside torchrun starts two ranks itself; the JSON line reports the real world size and one entry per rank;
+rank 0's weights reach every rank; a WORLD_SIZE / --gpus mismatch is an error, not a warning."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+DRIVER = os.path.join(ROOT, "tests", "bench_stub_driver.py")
+ARGS = ["--device", "cpu", "--steps", "2", "--warmup", "1", "--windows", "5", "--model", "tiny", "--gen-tokens", "5",
+        "--sr", "16000", "--spec-time-step", "0.001", "--no-cpu-baseline"]
+
+
+def clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    return env
+
+
+def last_json(text):
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    assert lines, text[-2000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.timeout(300)
+def test_gpus_2_self_launches_two_ranks():
+    res = subprocess.run([sys.executable, DRIVER, "--gpus", "2"] + ARGS, env=clean_env(), capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = last_json(res.stdout)
+    assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["scaling"] == "weak"
+    assert sorted(r["rank"] for r in out["ranks"]) == [0, 1]
+    assert len({r["pid"] for r in out["ranks"]}) == 2
+    assert out["collectives"] == "gloo"
+    # whole-job value: 2 ranks x 5 windows x 1 s per step
+    assert out["value"] == pytest.approx(2 * 5 * 1.0 * 2 / (out["ms_per_step"] * 2 / 1e3), rel=1e-6)
+    assert out["config"]["windows_per_gpu"] == 5
+
+
+@pytest.mark.timeout(300)
+def test_single_process_default_and_mismatch():
+    res = subprocess.run([sys.executable, DRIVER] + ARGS, env=clean_env(), capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = last_json(res.stdout)
+    assert out["n_gpus"] == 1 and out["world_size"] == 1 and len(out["ranks"]) == 1
+    env = clean_env()
+    env.update(RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    res = subprocess.run([sys.executable, DRIVER, "--gpus", "1"] + ARGS, env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 2 and "WORLD_SIZE" in res.stderr

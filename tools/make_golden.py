@@ -116,6 +116,10 @@ PARSE_CASES = [
     dict(name="three_trials_voting", sr=16000, sts=0.01, n=16000 * 12,
          kwargs={"num_trials": 3, "consolidation_method": "voting"}, texts=None),
     dict(name="two_trials_eps", sr=32000, sts=0.0025, n=32000 * 4, kwargs={"num_trials": 2, "eps": 0.004}, texts=None),
+    # the same recording with a radius that lets the two trials agree (the case above consolidates to nothing)
+    dict(name="two_trials_eps_wide", sr=32000, sts=0.0025, n=32000 * 4, kwargs={"num_trials": 2, "eps": 0.03}, texts=None),
+    dict(name="five_trials_voting", sr=16000, sts=0.01, n=16000 * 14, kwargs={"num_trials": 5, "consolidation_method": "voting"},
+         texts=None),
 ]
 
 
@@ -249,6 +253,37 @@ def make_tiny(ref_audio, ref_model):
         ids = [c.tolist() for c in captured]
         meta.append(dict(seed=seed, n_windows=nw, kwargs=kw, expected=res, token_batches=ids))
         print("run", ridx, kw, "->", len(res["onset"]), "segments; batches", [len(b) for b in ids])
+    # Multi-trial runs whose consolidated output is NOT empty (runs 5 and 6 above consolidate to nothing: the tiny model
+    # disagrees with itself on shifted windows of those recordings; they stay as the empty-result cases).  The first seed
+    # >= 110 that yields at least 3 rows is recorded for every specification.
+    for kw in (dict(num_beams=4, num_trials=3, batch_size=8, consolidation_method="voting"),
+               dict(num_beams=4, num_trials=3, batch_size=3),
+               dict(num_beams=1, num_trials=3, batch_size=8),
+               dict(num_beams=4, num_trials=2, batch_size=8, eps=0.08),
+               dict(num_beams=2, num_trials=3, batch_size=2, consolidation_method="voting")):
+        for seed in range(110, 200):
+            nw = 2 + seed % 2
+            captured.clear()
+            res = segm.segment(GI.tiny_recording(seed, nw), TM.SR, **kw)
+            if len(res["onset"]) >= 3:
+                meta.append(dict(seed=seed, n_windows=nw, kwargs=kw, expected=res, token_batches=[c.tolist() for c in captured]))
+                print("multi-trial run", kw, "seed", seed, "->", len(res["onset"]), "segments")
+                break
+        else:
+            raise RuntimeError("no seed gives a non-empty multi-trial result for %r" % (kw,))
+    # G8 parity sweep: 200 recordings (50 seeds x trials {1, 3} x beams {1, 4}) through the reference's segment(); only the
+    # final rows are kept.  The GPU bf16 path is scored against these (tests/test_parity_sweep_gpu.py, tools/parity_sweep.py).
+    sweep = []
+    for seed in range(1000, 1050):
+        nw = 1 + seed % 3
+        audio = GI.tiny_recording(seed, nw)
+        for trials in (1, 3):
+            for beams in (1, 4):
+                kw = dict(num_beams=beams, num_trials=trials, batch_size=8)
+                sweep.append(dict(seed=seed, n_windows=nw, kwargs=kw, expected=segm.segment(audio, TM.SR, **kw)))
+        print("sweep seed", seed, [len(r["expected"]["onset"]) for r in sweep[-4:]])
+    with open(os.path.join(OUT, "tiny_sweep.json"), "w") as f:
+        json.dump(sweep, f)
     # G6: encoder output + first-step logits for 3 windows of run 0's recording
     audio = GI.tiny_recording(100, 3)
     sliced = segm.get_sliced_audios_features(audio, TM.SR, 0, TM.STS, 1)

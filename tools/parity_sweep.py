@@ -1,0 +1,77 @@
+"""bf16 (and f32) parity of WhisperSegmenter.segment() against the reference's own rows over tests/golden/tiny_sweep.json:
+200 recordings (50 seeds x trials {1, 3} x beams {1, 4}) of the tiny trained model, expected rows recorded by driving HF fp32
+through the reference's WhisperSegmenterForEval (tools/make_golden.py, G8).
+
+    python tools/parity_sweep.py [out.json]          (needs the GPU)
+
+Per dtype: runs whose rows have the same count and clusters as the reference's ("structure"), the histogram of boundary
+deviations in mel frames (spec_time_step units) over all rows of those runs, and the list of runs outside the north-star
+tolerance (clusters exact, boundaries within +-1 frame)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import golden_inputs as GI  # noqa: E402
+from tools import tiny_model as TM  # noqa: E402
+
+MODEL_DIR = os.path.join(ROOT, "tests", "golden", "tiny_model")
+
+
+def score(seg, sweep):
+    hist = {"0": 0, "<=0.5": 0, "<=1": 0, "<=2": 0, ">2": 0}
+    out = dict(runs=len(sweep), rows_expected=0, rows_compared=0, exact_runs=0, within_tolerance_runs=0,
+               structure_mismatch_runs=[], beyond_one_frame_runs=[], cluster_mismatch_rows=0, frame_hist=hist, max_dev_frames=0.0)
+    audio_cache = {}
+    for idx, run in enumerate(sweep):
+        key = (run["seed"], run["n_windows"])
+        if key not in audio_cache:
+            audio_cache[key] = GI.tiny_recording(*key)
+        got = seg.segment(audio_cache[key], TM.SR, **run["kwargs"])
+        want = run["expected"]
+        out["rows_expected"] += len(want["onset"])
+        if got == want:
+            out["exact_runs"] += 1
+        if len(got["onset"]) != len(want["onset"]) or got["cluster"] != want["cluster"]:
+            out["structure_mismatch_runs"].append(dict(index=idx, seed=run["seed"], kwargs=run["kwargs"], got_rows=len(got["onset"]),
+                                                       want_rows=len(want["onset"])))
+            if len(got["onset"]) == len(want["onset"]):
+                out["cluster_mismatch_rows"] += sum(a != b for a, b in zip(got["cluster"], want["cluster"]))
+            continue
+        dev = np.abs(np.array(got["onset"] + got["offset"]) - np.array(want["onset"] + want["offset"])) / TM.STS
+        out["rows_compared"] += len(want["onset"])
+        for d in dev:
+            k = "0" if d < 1e-6 else ("<=0.5" if d <= 0.5 + 1e-6 else ("<=1" if d <= 1 + 1e-6 else ("<=2" if d <= 2 + 1e-6 else ">2")))
+            hist[k] += 1
+        mx = float(dev.max()) if len(dev) else 0.0
+        out["max_dev_frames"] = max(out["max_dev_frames"], mx)
+        if mx <= 1 + 1e-6:
+            out["within_tolerance_runs"] += 1
+        else:
+            out["beyond_one_frame_runs"].append(dict(index=idx, seed=run["seed"], kwargs=run["kwargs"], max_dev_frames=mx))
+    return out
+
+
+def main():
+    from whisperseg_amd.model import WhisperSegmenter
+    with open(os.path.join(ROOT, "tests", "golden", "tiny_sweep.json")) as f:
+        sweep = json.load(f)
+    res = {}
+    for dtype in ("f32", "bf16"):
+        seg = WhisperSegmenter(MODEL_DIR, device="cuda", device_ids=[0], dtype=dtype)
+        res[dtype] = score(seg, sweep)
+        r = res[dtype]
+        print(dtype, "runs", r["runs"], "exact", r["exact_runs"], "within +-1 frame", r["within_tolerance_runs"], "structure mismatches",
+              len(r["structure_mismatch_runs"]), "hist", r["frame_hist"], "max", r["max_dev_frames"], flush=True)
+    dest = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "parity_sweep.json")
+    os.makedirs(os.path.dirname(dest), exist_ok=True)
+    with open(dest, "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

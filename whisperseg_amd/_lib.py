@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwseg.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class LogmelDesc(C.Structure):
@@ -23,7 +23,14 @@ class GenerateParams(C.Structure):
     _fields_ = [("prompt", C.c_int32 * 8), ("prompt_len", C.c_int32), ("eos_token_id", C.c_int32),
                 ("pad_token_id", C.c_int32), ("max_length", C.c_int32), ("num_beams", C.c_int32),
                 ("length_penalty", C.c_float), ("suppress_tokens", C.c_void_p), ("n_suppress", C.c_int32),
-                ("begin_suppress_tokens", C.c_void_p), ("n_begin_suppress", C.c_int32)]
+                ("begin_suppress_tokens", C.c_void_p), ("n_begin_suppress", C.c_int32),
+                ("n_slots", C.c_int32), ("refill_min", C.c_int32), ("lookahead", C.c_int32),
+                ("window_max_length", C.c_void_p)]
+
+
+class GenerateStats(C.Structure):
+    _fields_ = [("n_windows", C.c_int32), ("n_slots", C.c_int32), ("n_steps", C.c_int32), ("n_admissions", C.c_int32),
+                ("slot_steps_active", C.c_int64), ("slot_steps_total", C.c_int64)]
 
 
 # name -> (restype, argtypes); every symbol include/wseg.h declares.
@@ -46,6 +53,7 @@ SYMBOLS = {
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "wseg_debug_first_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "wseg_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 4)]),
+    "wseg_last_stats": (C.c_int, [C.c_void_p, C.POINTER(GenerateStats)]),
     "wseg_debug_gemm": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "wseg_profile_begin": (C.c_int, []),

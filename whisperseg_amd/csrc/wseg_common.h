@@ -76,17 +76,6 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   const float h = 0.5f * x;
   return fmaf(fabsf(h), fmaf(-(p * t), e2, 1.0f), h);    // 0.5 x (1 + sign(x) erf(|x| / sqrt 2))
 }
-// Cheaper erf-GELU for MFMA epilogues (the GELU of a 256x256 tile is ~9 us of VALU work with the A&S form, beside a
-// ~30 us K loop): x * sigmoid(x (a1 + a3 x^2 + a5 x^4)), coefficients minimax-fitted to 0.5 x (1 + erf(x / sqrt 2)) on
-// [-9, 9]: max |error| 2.6e-5 (tools/gelu_fit.py) — the classic tanh form is 4.7e-4.  -log2(e) is folded into the
-// coefficients; x^2 is clamped at 64 because the quintic is monotone only up to |x| = 8.3 (sigmoid has saturated
-// by then).  5 VALU + v_exp_f32 + v_rcp_f32.
-__device__ __forceinline__ float gelu_sig5(float x) {
-  const float x2 = fminf(x * x, 64.0f);
-  float q = fmaf(x2, 0.0010142630198970437f, -0.10677572339773178f);
-  q = fmaf(q, x2, -2.301121234893799f);
-  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * q));
-}
 template <typename T> __device__ __forceinline__ float gelu_for(float x);
 template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }
 template <> __device__ __forceinline__ float gelu_for<uint16_t>(float x) { return gelu_erf_fast(x); }

@@ -7,15 +7,21 @@ namespace wseg {
 constexpr int MAX_BEAMS = 8;
 constexpr int MAX_CAND = 2 * MAX_BEAMS;
 
-// Everything the decode loop needs lives on the device; the host only enqueues kernels and polls
-// `active[step]`.  W windows, nb beams, R = W * nb rows, L = max_length (cache capacity).
+// Everything the decode loop needs lives on the device; the host only enqueues kernels and reads a small
+// per-step status mirror.  W window SLOTS, nb beams, R = W * nb rows, L = max_length (cache capacity).
+// Slots are independent: every slot has its own decode position, so a finished window's slot can be
+// re-used for the next queued window while its neighbours keep decoding (wseg_generate's scheduler).
 struct DecodeState {
   int W, nb, L, V, ldv;            // ldv: leading dimension of the logits buffer (vocab padded)
   int P;                           // prompt length
   int eos, pad, max_length;
   float length_penalty;
   int prompt[8];
-  int* pos;                        // [1]   position of the token being fed this step
+  int* pos;                        // [W]   position of the token each slot feeds this step
+  int* done;                       // [W]   1 = slot idle (free, or finished and waiting to be retired): every kernel skips it
+  int* win;                        // [W]   index of the window decoded in the slot (row of the output arrays)
+  int* wmax;                       // [W]   total-length cap of the slot's window (<= max_length)
+  const int* win_max_length;       // [n_windows] per-window caps (device) or null
   int* tokens_in;                  // [R]   token fed at this step
   int* run_seq;                    // [W][nb][L]
   int* fin_seq;                    // [W][nb][L]
@@ -27,19 +33,16 @@ struct DecodeState {
   unsigned char* anc;              // [W][nb][L] cache slot (beam index) that holds position p of this row's history
   float* cand_val;                 // [R][Kc]
   int* cand_tok;                   // [R][Kc]
-  int* active;                     // [L]      number of windows still improvable after each step
-  int* flags;                      // [L]      per step: epoch*4 + (1 = some window still improvable, 2 = none); 0 = not run yet
-  int epoch;                       // per-call tag so that late copies of an earlier call are never misread
   const unsigned char* sup_mask;   // [V] bit0: always suppressed, bit1: suppressed at the first generated position
 };
 
-int launch_decode_init(const DecodeState& st, hipStream_t s);
+// all slots idle (start of a wseg_generate call)
+int launch_decode_reset(const DecodeState& st, hipStream_t s);
+// slots[i] starts decoding window wins[i] at position 0 (device arrays of n entries)
+int launch_decode_admit(const DecodeState& st, const int* slots, const int* wins, int n, hipStream_t s);
 int launch_build_suppress_mask(unsigned char* mask, int V, const int* sup, int n_sup, const int* bsup, int n_bsup, hipStream_t s);
-// x[r][:] = tok_emb[tokens_in[r]][:] + pos_emb[*pos][:]
+// x[r][:] = tok_emb[tokens_in[r]][:] + pos_emb[pos[slot of r]][:]
 int launch_embed(int dtype, const DecodeState& st, const void* tok_emb, const void* pos_emb, void* x, int d, hipStream_t s);
-// prompt phase: tokens_in <- prompt[*pos + 1], anc[..][*pos] = own slot
-int launch_prompt_feed(const DecodeState& st, hipStream_t s);
-int launch_advance(const DecodeState& st, hipStream_t s);
 // decoder self-attention over the KV cache [R][H][L][64] with per-position ancestry
 // qkv_part != nullptr: q/k/v of this step arrive as split-K partials [z][m_pad][3d] (+ qkv_bias); the kernel finishes the
 // reduction, appends k/v to the cache and uses them (saves the separate reduction launch).
@@ -54,6 +57,7 @@ int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const
 int launch_row_topk(const DecodeState& st, const float* logits, float* part_val, int* part_idx, float* part_stat, hipStream_t s);
 int launch_beam_step(const DecodeState& st, hipStream_t s);
 int launch_greedy_step(const DecodeState& st, hipStream_t s);
-int launch_finalize(const DecodeState& st, int* out_tokens, int* out_lengths, hipStream_t s);
+// retire: best sequence of slots[i] -> out_tokens[win[slots[i]]][:], out_lengths[win[slots[i]]]
+int launch_finalize(const DecodeState& st, const int* slots, int n, int* out_tokens, int* out_lengths, hipStream_t s);
 
 }  // namespace wseg

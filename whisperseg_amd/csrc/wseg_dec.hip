@@ -10,27 +10,36 @@
 namespace wseg {
 
 // ------------------------------------------------------------------------------------------------
-__global__ void decode_init_kernel(DecodeState st) {
-  const int W = st.W, nb = st.nb, L = st.L;
-  const int total = W * nb * L;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const int p = i % L, j = (i / L) % nb;
+__global__ void decode_reset_kernel(DecodeState st) {
+  for (int w = blockIdx.x * 256 + threadIdx.x; w < st.W; w += gridDim.x * 256) { st.pos[w] = 0; st.done[w] = 1; st.win[w] = -1; st.unsat[w] = 0; st.wmax[w] = st.max_length; }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < st.W * st.nb; i += gridDim.x * 256) st.tokens_in[i] = st.prompt[0];
+}
+
+// One workgroup per admitted slot: fresh sequences / scores / ancestry, position 0, not done.
+__global__ __launch_bounds__(256) void decode_admit_kernel(DecodeState st, const int* __restrict__ slots, const int* __restrict__ wins) {
+  const int w = slots[blockIdx.x];
+  const int nb = st.nb, L = st.L;
+  for (int i = threadIdx.x; i < nb * L; i += 256) {
+    const int p = i % L, j = i / L;
     const int v = p < st.P ? st.prompt[p] : st.pad;
-    st.run_seq[i] = v;
-    st.fin_seq[i] = v;
-    st.anc[i] = (unsigned char)j;
+    st.run_seq[(size_t)w * nb * L + i] = v;
+    st.fin_seq[(size_t)w * nb * L + i] = v;
+    st.anc[(size_t)w * nb * L + i] = (unsigned char)j;
   }
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < W * nb; i += gridDim.x * 256) {
-    const int j = i % nb;
+  if (threadIdx.x < nb) {
+    const int j = threadIdx.x, i = w * nb + j;
     st.run_score[i] = j == 0 ? 0.0f : -1.0e9f;
     st.fin_score[i] = -1.0e9f;
     st.fin_flag[i] = 0;
     st.fin_len[i] = 0;
     st.tokens_in[i] = st.prompt[0];
   }
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < W; i += gridDim.x * 256) st.unsat[i] = 1;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < L; i += gridDim.x * 256) { st.active[i] = 0; st.flags[i] = 0; }
-  if (blockIdx.x == 0 && threadIdx.x == 0) { st.pos[0] = 0; st.pos[1] = st.epoch; }   // epoch lives in device memory: the step graph is reused across calls
+  if (threadIdx.x == 0) {
+    const int win = wins[blockIdx.x];
+    int cap = st.max_length;
+    if (st.win_max_length) cap = max(st.P + 1, min(cap, st.win_max_length[win]));
+    st.unsat[w] = 1; st.pos[w] = 0; st.win[w] = win; st.wmax[w] = cap; st.done[w] = 0;
+  }
 }
 
 __global__ void suppress_mask_kernel(unsigned char* mask, int V, const int* sup, int n_sup, const int* bsup, int n_bsup) {
@@ -46,23 +55,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void embed_kernel(DecodeState st, const T* __restrict__ tok_emb, const T* __restrict__ pos_emb,
                                                     T* __restrict__ x, int d) {
   const int r = blockIdx.x;
-  const int tok = st.tokens_in[r], pos = *st.pos;
+  const int tok = st.tokens_in[r], pos = st.pos[r / st.nb];
   for (int c = threadIdx.x; c < d; c += 256)
     El<T>::st(x + (size_t)r * d + c, El<T>::ld(tok_emb + (size_t)tok * d + c) + El<T>::ld(pos_emb + (size_t)pos * d + c));
-}
-
-__global__ void prompt_feed_kernel(DecodeState st) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= st.W * st.nb) return;
-  const int pos = *st.pos;
-  st.tokens_in[i] = st.prompt[pos + 1 < st.P ? pos + 1 : st.P - 1];
-}
-
-// Last kernel of every step (single thread): publish the step's verdict for the host poll, then move on.
-__global__ void advance_kernel(DecodeState st) {
-  const int pos = *st.pos;
-  if (pos >= st.P - 1) st.flags[pos] = st.pos[1] * 4 + (st.active[pos] == 0 ? 2 : 1);
-  *st.pos = pos + 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -159,8 +154,9 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
   const int lane = threadIdx.x, sub = lane & 7, rowl = lane >> 3;
   const int r = blockIdx.x / H, h = blockIdx.x - r * H;
   const int w = r / st.nb;
+  if (st.done[w]) return;                         // idle slot: nothing to read, nothing to append
   const int L = st.L;
-  const int n = *st.pos + 1;                      // keys 0 .. pos (the current token's K/V were just appended)
+  const int n = st.pos[w] + 1;                    // keys 0 .. pos (the current token's K/V were just appended)
   float qv[8];
   const bool fused = pi.part != nullptr;
   if (fused) {
@@ -280,6 +276,7 @@ __global__ __launch_bounds__(256, 5) void dec_cross_attn_kernel(DecodeState st, 
   __shared__ float sinv[NB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = blockIdx.x / H, h = blockIdx.x - w * H;
+  if (st.done[w]) return;                              // idle slot: its 128 KiB of K/V are not streamed
   const int nb = st.nb;
   const int sub = lane & 7, rowl = lane >> 3;          // 8 lanes per row, 8 rows per wave-instruction
   const T* Kb = ck + ((size_t)w * H + h) * Tk * 64;
@@ -406,6 +403,7 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
   __shared__ float sinv[NB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = blockIdx.x / H, h = blockIdx.x - w * H;
+  if (st.done[w]) return;                              // idle slot: its 128 KiB of K/V are not streamed
   const int nb = st.nb;
   const int sub = lane & 7, rowl = lane >> 3;
   const bf16_t* Kb = ck + ((size_t)w * H + h) * Tk * 64;
@@ -565,11 +563,12 @@ __global__ __launch_bounds__(256) void row_topk_partial_kernel(DecodeState st, c
   __shared__ int s_bt[4];
   __shared__ int s_winner;
   const int seg = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (st.done[r / st.nb]) return;
   const int V = st.V;
   const int per = (V + nseg - 1) / nseg;
   const int lo = seg * per, hi = min(V, lo + per);
   const float* x = logits + (size_t)r * st.ldv;
-  const int cur_len = *st.pos + 1;
+  const int cur_len = st.pos[r / st.nb] + 1;
   const unsigned char bits = 1 | ((cur_len == st.P) ? 2 : 0);
   // the slice as [lo, a4) scalar head, [a4, b4) 16-byte groups (rows are 16-byte aligned: ldv % 4 == 0), [b4, hi) tail:
   // a row is 200 KB of fp32, one dword per lane per load left the scan latency-bound (0.66 TB/s at 1024 rows)
@@ -657,6 +656,7 @@ template <int KC>
 __global__ __launch_bounds__(64) void row_topk_merge_kernel(DecodeState st, int nseg, const float* __restrict__ part_val,
                                                             const int* __restrict__ part_idx, const float* __restrict__ part_stat) {
   const int r = blockIdx.x, lane = threadIdx.x;
+  if (st.done[r / st.nb]) return;
   const bool greedy = st.nb == 1;
   const int Kc = greedy ? 1 : 2 * st.nb;
   float mx = -3.0e38f;
@@ -712,8 +712,15 @@ __global__ __launch_bounds__(64) void beam_step_kernel(DecodeState st) {
   __shared__ int n_fin_flag[MAX_BEAMS], n_fin_len[MAX_BEAMS];
   __shared__ int head[MAX_BEAMS];
   const int w = blockIdx.x, lane = threadIdx.x;
+  if (st.done[w]) return;               // idle slot
   const int nb = st.nb, Kc = 2 * nb, L = st.L, P = st.P;
-  const int cur_len = *st.pos + 1;      // tokens present before this step's choice
+  const int pos = st.pos[w];
+  const int cur_len = pos + 1;          // tokens present before this step's choice
+  if (cur_len < P) {                    // prompt phase: the next token is forced, nothing else changes
+    if (lane < nb) st.tokens_in[w * nb + lane] = st.prompt[cur_len];
+    if (lane == 0) st.pos[w] = pos + 1;
+    return;
+  }
   if (lane == 0) {
     // c. top-Kc continuations over nb*V accumulated log-probs (each row's list is already sorted)
     for (int j = 0; j < nb; ++j) head[j] = 0;
@@ -729,7 +736,7 @@ __global__ __launch_bounds__(64) void beam_step_kernel(DecodeState st) {
       head[bj]++;
       c_val[k] = bv; c_beam[k] = bj; c_tok[k] = bt;
       // d. stopping criteria: EOS or max_length reached
-      c_hit[k] = (bt == st.eos) || (cur_len + 1 >= st.max_length);
+      c_hit[k] = (bt == st.eos) || (cur_len + 1 >= st.wmax[w]);
     }
     // e. running beams for the next iteration
     for (int k = 0; k < Kc; ++k) run_val[k] = c_val[k] + (c_hit[k] ? 1.0f : 0.0f) * -1.0e9f;
@@ -773,7 +780,10 @@ __global__ __launch_bounds__(64) void beam_step_kernel(DecodeState st) {
     for (int i = 0; i < nb; ++i) { const float worst = n_fin_flag[i] ? mn : -1.0e9f; if (best_running > worst) improve = 1; }
     const int un_new = un && improve;
     st.unsat[w] = un_new;
-    if (un_new) atomicAdd(&st.active[cur_len - 1], 1);
+    // the slot is finished once no running beam can still beat the finished ones (HF stops stepping a batch when this
+    // holds for all of its items; until then the item's result is frozen) or max_length is reached
+    if (!un_new || cur_len + 1 >= st.wmax[w]) st.done[w] = 1;
+    else st.pos[w] = pos + 1;
     for (int i = 0; i < nb; ++i) {
       st.run_score[w * nb + i] = n_run_score[i];
       st.fin_score[w * nb + i] = n_fin_score[i];
@@ -809,34 +819,48 @@ __global__ __launch_bounds__(64) void beam_step_kernel(DecodeState st) {
 
 __global__ void greedy_step_kernel(DecodeState st) {
   const int w = blockIdx.x * 64 + threadIdx.x;
-  if (w >= st.W) return;
+  if (w >= st.W || st.done[w]) return;
   const int L = st.L;
-  const int cur_len = *st.pos + 1;
-  int unfinished = st.unsat[w];
-  int tok = st.cand_tok[w];
-  if (!unfinished) tok = st.pad;
+  const int pos = st.pos[w];
+  const int cur_len = pos + 1;
+  if (cur_len < st.P) {                 // prompt phase
+    st.tokens_in[w] = st.prompt[cur_len];
+    st.pos[w] = pos + 1;
+    return;
+  }
+  const int tok = st.cand_tok[w];
   st.run_seq[(size_t)w * L + cur_len] = tok;
   st.anc[(size_t)w * L + cur_len] = 0;
   st.tokens_in[w] = tok;
-  if (unfinished && (tok == st.eos || cur_len + 1 >= st.max_length)) {
-    unfinished = 0;
+  if (tok == st.eos || cur_len + 1 >= st.wmax[w]) {
+    st.unsat[w] = 0;
     st.fin_len[w] = cur_len + 1 - st.P;
+    st.done[w] = 1;
+  } else {
+    st.pos[w] = pos + 1;
   }
-  st.unsat[w] = unfinished;
-  if (unfinished) atomicAdd(&st.active[cur_len - 1], 1);
 }
 
-__global__ void finalize_kernel(DecodeState st, int* out_tokens, int* out_lengths) {
-  const int w = blockIdx.x, L = st.L;
+// One workgroup per retired slot.
+__global__ void finalize_kernel(DecodeState st, const int* __restrict__ slots, int* out_tokens, int* out_lengths) {
+  const int w = slots[blockIdx.x], L = st.L;
+  const int row = st.win[w];
+  if (row < 0) return;
   const int* src = (st.nb == 1 ? st.run_seq : st.fin_seq) + (size_t)w * st.nb * L;
   const int len = st.P + st.fin_len[w * st.nb];
-  for (int p = threadIdx.x; p < L; p += blockDim.x) out_tokens[(size_t)w * L + p] = p < len ? src[p] : st.pad;
-  if (threadIdx.x == 0) out_lengths[w] = len;
+  for (int p = threadIdx.x; p < L; p += blockDim.x) out_tokens[(size_t)row * L + p] = p < len ? src[p] : st.pad;
+  if (threadIdx.x == 0) out_lengths[row] = len;
 }
 
 // ------------------------------------------------------------------------------------------------
-int launch_decode_init(const DecodeState& st, hipStream_t s) {
-  hipLaunchKernelGGL(decode_init_kernel, dim3(64), dim3(256), 0, s, st);
+int launch_decode_reset(const DecodeState& st, hipStream_t s) {
+  hipLaunchKernelGGL(decode_reset_kernel, dim3(cdiv(st.W * st.nb, 256)), dim3(256), 0, s, st);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+int launch_decode_admit(const DecodeState& st, const int* slots, const int* wins, int n, hipStream_t s) {
+  if (n <= 0) return WSEG_OK;
+  hipLaunchKernelGGL(decode_admit_kernel, dim3(n), dim3(256), 0, s, st, slots, wins);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
@@ -849,16 +873,6 @@ int launch_embed(int dtype, const DecodeState& st, const void* tok_emb, const vo
   const int R = st.W * st.nb;
   if (dtype == WSEG_BF16) hipLaunchKernelGGL((embed_kernel<bf16_t>), dim3(R), dim3(256), 0, s, st, (const bf16_t*)tok_emb, (const bf16_t*)pos_emb, (bf16_t*)x, d);
   else hipLaunchKernelGGL((embed_kernel<float>), dim3(R), dim3(256), 0, s, st, (const float*)tok_emb, (const float*)pos_emb, (float*)x, d);
-  WSEG_LAUNCH_CHECK();
-  return WSEG_OK;
-}
-int launch_prompt_feed(const DecodeState& st, hipStream_t s) {
-  hipLaunchKernelGGL(prompt_feed_kernel, dim3(cdiv(st.W * st.nb, 256)), dim3(256), 0, s, st);
-  WSEG_LAUNCH_CHECK();
-  return WSEG_OK;
-}
-int launch_advance(const DecodeState& st, hipStream_t s) {
-  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, st);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
@@ -928,8 +942,9 @@ int launch_greedy_step(const DecodeState& st, hipStream_t s) {
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
-int launch_finalize(const DecodeState& st, int* out_tokens, int* out_lengths, hipStream_t s) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(st.W), dim3(256), 0, s, st, out_tokens, out_lengths);
+int launch_finalize(const DecodeState& st, const int* slots, int n, int* out_tokens, int* out_lengths, hipStream_t s) {
+  if (n <= 0) return WSEG_OK;
+  hipLaunchKernelGGL(finalize_kernel, dim3(n), dim3(256), 0, s, st, slots, out_tokens, out_lengths);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }

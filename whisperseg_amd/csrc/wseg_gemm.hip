@@ -12,6 +12,7 @@
 //
 // Both paths share one epilogue (epi_apply), also used by the split-K reduction kernel.
 #include <stdlib.h>
+#include <mutex>
 #include <vector>
 #include "wseg_kernels.h"
 
@@ -85,7 +86,8 @@ __device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, fl
   } else if constexpr (EPI == EPI_KV_CROSS) {
     const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
     const int b = m / ep.t_len, t = m - b * ep.t_len;
-    T* dst = (T*)(sec == 0 ? ep.k : ep.v) + (((size_t)b * ep.n_heads + h) * ep.t_len + t) * 64 + e;
+    const int bs = ep.slot_map ? ep.slot_map[b] : b;
+    T* dst = (T*)(sec == 0 ? ep.k : ep.v) + (((size_t)bs * ep.n_heads + h) * ep.t_len + t) * 64 + e;
     Vec4<T>::st(dst, v);
   } else if constexpr (EPI == EPI_F32) {
     *(float4*)(ep.out_f32 + (size_t)m * ep.ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
@@ -96,7 +98,7 @@ __device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, fl
       for (int i = 0; i < 4; ++i) v[i] *= ep.scale;
       Vec4<T>::st((T*)ep.q + (size_t)m * d + nn, v);
     } else {
-      const int pos = *ep.pos_ptr;
+      const int pos = ep.pos_ptr[m / ep.pos_div];
       T* dst = (T*)(sec == 1 ? ep.k : ep.v) + (((size_t)m * ep.n_heads + h) * ep.t_pad + pos) * 64 + e;
       Vec4<T>::st(dst, v);
     }
@@ -166,7 +168,8 @@ __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, f
   } else if constexpr (EPI == EPI_KV_CROSS) {
     const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
     const int b = m / ep.t_len, t = m - b * ep.t_len;
-    T* dst = (T*)(sec == 0 ? ep.k : ep.v) + (((size_t)b * ep.n_heads + h) * ep.t_len + t) * 64 + e;
+    const int bs = ep.slot_map ? ep.slot_map[b] : b;
+    T* dst = (T*)(sec == 0 ? ep.k : ep.v) + (((size_t)bs * ep.n_heads + h) * ep.t_len + t) * 64 + e;
     st8_bf16(dst, v);
   } else if constexpr (EPI == EPI_F32) {
     float* o = ep.out_f32 + (size_t)m * ep.ldc + n0;
@@ -387,6 +390,18 @@ __device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NI][MI], floa
   }
   EpiParams ep2 = ep;
   ep2.bias = nullptr;
+  // cross-K/V into window slots: the (at most two: 16 * MI <= t_len rows) windows this wave tile touches are looked up here,
+  // before the first store (see above), and rows are re-based so that the identity mapping lands in the slot
+  int kv_b0 = 0, kv_s0 = 0, kv_s1 = 0;
+  if constexpr (EPI == EPI_KV_CROSS) {
+    if (ep.slot_map) {
+      const int nwin = (M + ep.t_len - 1) / ep.t_len;
+      kv_b0 = min(mb, M - 1) / ep.t_len;
+      kv_s0 = ep.slot_map[kv_b0];
+      kv_s1 = ep.slot_map[min(kv_b0 + 1, nwin - 1)];
+      ep2.slot_map = nullptr;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < MI; ++j) {
 #pragma unroll
@@ -408,6 +423,10 @@ __device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NI][MI], floa
           v[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u) + v[2 * e + 1];
         }
         if (m < M) st8_bf16((bf16_t*)ep.out + (size_t)m * ep.ldc + nc, v);
+      } else if constexpr (EPI == EPI_KV_CROSS) {
+        int mm = m;
+        if (ep.slot_map) { const int b = m / ep.t_len; mm = (b == kv_b0 ? kv_s0 : kv_s1) * ep.t_len + (m - b * ep.t_len); }
+        if (m < M) epi_apply8<EPI>(ep2, mm, nc, v);
       } else {
         if (m < M) epi_apply8<EPI>(ep2, m, nc, v);
       }
@@ -798,7 +817,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------------
 // Live profiler of the dominant kernel (wseg_profile_begin / wseg_profile_end)
 // ------------------------------------------------------------------------------------------------
+// Process-wide and meant for ONE measuring thread (bench.py's roofline leg); a mutex keeps concurrent device threads from
+// corrupting the event pool if a profile is requested while several devices run.
 struct GemmProfiler {
+  std::mutex mu;
   bool on = false;
   std::vector<hipEvent_t> pool;
   size_t used = 0;
@@ -813,6 +835,19 @@ static GemmProfiler g_prof;
 // ------------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------------
+// CU count of the CURRENT device, cached per device (thread-per-device mode drives several devices from one process).
+static int device_cu_count() {
+  static int cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 #define WSEG_TRY_(expr) do { int _s = (expr); if (_s != WSEG_OK) return _s; } while (0)
 
 // skinny family (decoder steps, small encoders): BN = 64, BM in {32, 64, 128}; K is split across workgroups until
@@ -956,19 +991,17 @@ static int launch_bf16(const GemmArgs& g, hipStream_t s) {
     static const bool no_swz = getenv("WSEG_NO_XCD_SWIZZLE") != nullptr;
     static const bool big256 = getenv("WSEG_GEMM_128") == nullptr;   // 256x256 tiles by default where they fill the chip
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (g_prof.on) { e0 = g_prof.get(); e1 = g_prof.get(); g_prof.flops.push_back(2.0 * g.M * g.N * g.K); (void)hipEventRecord(e0, s); }
+    if (g_prof.on) {
+      std::lock_guard<std::mutex> lk(g_prof.mu);
+      e0 = g_prof.get(); e1 = g_prof.get(); g_prof.flops.push_back(2.0 * g.M * g.N * g.K); (void)hipEventRecord(e0, s);
+    }
     static const bool persist = getenv("WSEG_GEMM_NO_PERSIST") == nullptr;
     // m-tiles per tile group of the persistent order: the 32 tiles in flight on one XCD then span ~4 activation tiles x 8
     // weight tiles, the smallest operand footprint for 32 tiles (a + b = 12 operand tiles; 2-row groups re-stream the
     // whole weight matrix per tile pair: PMC FETCH_SIZE 2-3x the algorithmic bytes, profiles/).  Measured at 256
     // windows: 4 beats 2 by 2-8 % on the K = 1280 shapes, 6 and 8 lose on K = 5120.
     static const int group_m = getenv("WSEG_GEMM_GROUP_M") ? atoi(getenv("WSEG_GEMM_GROUP_M")) : 4;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-      int dev = 0; hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-      if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = device_cu_count();
     if (big256 && g.N % 256 == 0 && (long)cdiv(g.M, 256) * (g.N / 256) >= 192) {
       const int ntm = cdiv(g.M, 256), ntiles = ntm * (g.N / 256);
       static const bool pingpong = getenv("WSEG_GEMM_NO_PP") == nullptr;   // ping-pong kernel by default (tuning knob)
@@ -1000,7 +1033,7 @@ static int launch_bf16(const GemmArgs& g, hipStream_t s) {
                            g.K, g.ep, (float*)nullptr, 0, no_swz ? 0 : ntm);
       }
     }
-    if (g_prof.on) (void)hipEventRecord(e1, s);
+    if (e1) (void)hipEventRecord(e1, s);
     WSEG_LAUNCH_CHECK();
     return WSEG_OK;
   }

@@ -36,7 +36,9 @@ struct EpiParams {
   int t_len = 1;               // rows per window (500)
   int t_pad = 1;               // padded rows per (b,h) slab (512) / cache capacity for EPI_QKV_DEC
   int n_heads = 1;
-  const int* pos_ptr = nullptr;  // device scalar: current decode position (EPI_QKV_DEC)
+  const int* pos_ptr = nullptr;  // device [rows / pos_div]: current decode position of each window slot (EPI_QKV_DEC)
+  int pos_div = 1;               // rows (beams) per slot
+  const int* slot_map = nullptr; // device [M / t_len]: destination window slot of each window of the batch (EPI_KV_CROSS); null = identity
   float* out_f32 = nullptr;
 };
 

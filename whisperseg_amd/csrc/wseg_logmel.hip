@@ -202,10 +202,13 @@ extern "C" int wseg_logmel_f32(const wseg_logmel_desc* d, const float* audio, in
   const size_t smem = (size_t)nc * 8 + (size_t)a.fpb * nc * 8 + (size_t)a.fpb * (nc + 1) * 4;
   if (a.n_frames > 0) {
     dim3 grid(cdiv(a.n_frames, a.fpb), n_windows);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the function attribute is per device (thread-per-device mode, reference model.py:173-184): set once for each
+    static bool attr_set[64] = {};
+    int dev = 0;
+    WSEG_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
       WSEG_HIP_CHECK(hipFuncSetAttribute((const void*)logmel_stft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set = true;
+      if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(logmel_stft_kernel, grid, dim3(256), smem, stream, a);
     WSEG_LAUNCH_CHECK();

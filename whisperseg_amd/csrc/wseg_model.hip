@@ -4,6 +4,7 @@
 // encoder (HF modeling_whisper.py:592-646), decoder with KV cache (:690-796), tied LM head (:1080) and
 // greedy / beam-search decoding (HF generation/utils.py:3208-3510).  The host code below only enqueues
 // kernels on the caller's stream; all decoding state lives in the caller-provided workspace.
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -21,10 +22,11 @@ struct DecLayer {
       *ln3_g, *ln3_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
 };
 
-struct DecPlan {   // decoder-side buffers of one cohort of windows
-  int W = 0, w0 = 0;           // windows in the cohort, index of its first window
+struct DecPlan {   // decoder-side buffers (W window slots)
+  int W = 0;
   char *ck, *cv, *sk, *sv, *dx, *dy, *dq, *dattn, *dh, *logits, *first_logits, *splitk, *mask;
   char *tk_val, *tk_idx, *tk_stat;
+  int *adm_slots, *adm_wins, *ret_slots;     // device lists written by the scheduler (admission / retirement)
   size_t splitk_bytes;
   DecodeState st;
 };
@@ -32,8 +34,18 @@ struct DecPlan {   // decoder-side buffers of one cohort of windows
 struct Plan {   // workspace carve-up (all offsets 256-byte aligned)
   size_t total = 0;
   char *a1, *h1, *a2, *x, *y, *q, *k, *vt, *hbuf, *enc_out;
-  int n_coh = 1;               // the windows of a call are decoded as 1 or 2 independent cohorts (see wseg_generate)
-  DecPlan dec[2];
+  DecPlan dec;
+};
+
+// Pinned host staging for the scheduler's small host->device lists and the device->host status mirror.  An entry is
+// re-used only after the event recorded behind its copy has completed.
+struct PinnedRing {
+  static constexpr int N = 8;
+  int* host = nullptr;        // [N][cap]
+  int cap = 0;
+  hipEvent_t ev[N] = {};
+  bool used[N] = {};
+  int next = 0;
 };
 
 }  // namespace
@@ -47,18 +59,18 @@ struct wseg_model {
   const void *dec_tok, *dec_pos, *dec_ln_g, *dec_ln_b;
   std::vector<EncLayer> enc;
   std::vector<DecLayer> dec;
-  hipEvent_t ev[4];
-  bool ev_ok = false;
-  int last_steps = 0;
-  int last_W = 0, last_nb = 0, last_L = 0;
+  // per-stage timing of the last wseg_generate call: event pairs around every encoder / cross-K/V pass + the whole call
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  std::vector<int> ev_enc, ev_ckv;     // indices of (begin, end) pairs in ev_pool
+  int ev_total[2] = {-1, -1};
   bool timing_valid = false;
-  int* poll = nullptr;       // pinned host mirror of DecodeState::flags (one int per decode position)
-  int epoch = 0;
+  int last_W = 0, last_nb = 0, last_L = 0;
+  wseg_generate_stats stats = {};
+  PinnedRing ring_h2d, ring_status;
   // decode-step graph (hipGraph): captured once per (workspace, geometry, parameters), replayed per step
   hipGraphExec_t step_graph = nullptr;
   hipStream_t cap_stream = nullptr;   // capture happens on a private stream (the legacy NULL stream cannot capture)
-  hipStream_t cap_stream2 = nullptr;  // second branch of the step graph (two cohorts)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::vector<unsigned char> step_graph_key;
 };
 
@@ -69,7 +81,8 @@ void add_slot(wseg_model* m, const std::string& name, const void** field, size_t
   m->slots[name] = Slot{field, elems * m->es, false};
 }
 
-// Lay out the workspace for W windows, nb beams, capacity L positions.  base may be null (size query).
+// Lay out the workspace for W window slots (and encoder passes of up to W windows), nb beams, capacity L positions.
+// base may be null (size query).
 void make_plan(const wseg_model* m, int W, int nb, int L, char* base, Plan& p) {
   const wseg_model_config& c = m->cfg;
   const size_t es = m->es;
@@ -91,64 +104,57 @@ void make_plan(const wseg_model* m, int W, int nb, int L, char* base, Plan& p) {
   p.k = take((size_t)W * H * m->tp * 64 * es);
   p.vt = take((size_t)W * H * m->tp * 64 * es);
   p.enc_out = take(Mp * d * es);
-  // decoder: one cohort by default.  WSEG_TWO_COHORTS=1 splits the windows into two independent decode chains captured
-  // as parallel branches of the step graph (windows never interact).  Measured on MI355X (large, 120 windows): the
-  // branches do run concurrently, but 8.19 ms per step against 6.60 ms for one chain — the two chains compete for the
-  // same CUs / LDS-DMA path instead of filling each other's gaps — so it stays an experiment.
-  static const bool two_cohorts = getenv("WSEG_TWO_COHORTS") != nullptr;
-  p.n_coh = (W >= 16 && two_cohorts) ? 2 : 1;
   const size_t Ld = c.dec_layers, Tk = c.enc_positions;
   const size_t maxn = 3 * d > ffn ? 3 * d : ffn;
-  int w0 = 0;
-  for (int ci = 0; ci < p.n_coh; ++ci) {
-    DecPlan& q = p.dec[ci];
-    q.W = p.n_coh == 1 ? W : (ci == 0 ? (W + 1) / 2 : W / 2);
-    q.w0 = w0;
-    w0 += q.W;
-    const size_t Wc = q.W, R = Wc * nb, Rp = align_up(R, 256);
-    q.ck = take(Ld * Wc * H * Tk * 64 * es);
-    q.cv = take(Ld * Wc * H * Tk * 64 * es);
-    q.sk = take(Ld * R * H * (size_t)L * 64 * es);
-    q.sv = take(Ld * R * H * (size_t)L * 64 * es);
-    q.dx = take(Rp * d * es);
-    q.dy = take(Rp * d * es);
-    q.dq = take(Rp * d * es);
-    q.dattn = take(Rp * d * es);
-    q.dh = take(Rp * ffn * es);
-    q.logits = take(Rp * (size_t)m->vp * 4);
-    q.first_logits = take(R * (size_t)m->vp * 4);
-    q.splitk_bytes = (size_t)8 * Rp * maxn * 4;   // fp32 partials of the decoder-step GEMMs
-    q.splitk = take(q.splitk_bytes);
-    q.mask = take(align_up((size_t)c.vocab, 4));
-    q.tk_val = take(R * 256 * 4);
-    q.tk_idx = take(R * 256 * 4);
-    q.tk_stat = take(R * 16 * 2 * 4);
-    DecodeState& st = q.st;
-    st.W = (int)Wc; st.nb = nb; st.L = L; st.V = c.vocab; st.ldv = m->vp;
-    st.pos = (int*)take(256);
-    st.tokens_in = (int*)take(R * 4);
-    st.run_seq = (int*)take(R * L * 4);
-    st.fin_seq = (int*)take(R * L * 4);
-    st.run_score = (float*)take(R * 4);
-    st.fin_score = (float*)take(R * 4);
-    st.fin_flag = (int*)take(R * 4);
-    st.fin_len = (int*)take(R * 4);
-    st.unsat = (int*)take(Wc * 4);
-    st.anc = (unsigned char*)take(R * L);
-    st.cand_val = (float*)take(R * MAX_CAND * 4);
-    st.cand_tok = (int*)take(R * MAX_CAND * 4);
-    st.active = (int*)take((size_t)L * 4);
-    st.flags = (int*)take((size_t)L * 4);
-    st.epoch = 0;
-    st.sup_mask = (const unsigned char*)q.mask;
-  }
+  DecPlan& q = p.dec;
+  q.W = W;
+  const size_t Wc = W, R = Wc * nb, Rp = align_up(R, 256);
+  q.ck = take(Ld * Wc * H * Tk * 64 * es);
+  q.cv = take(Ld * Wc * H * Tk * 64 * es);
+  q.sk = take(Ld * R * H * (size_t)L * 64 * es);
+  q.sv = take(Ld * R * H * (size_t)L * 64 * es);
+  q.dx = take(Rp * d * es);
+  q.dy = take(Rp * d * es);
+  q.dq = take(Rp * d * es);
+  q.dattn = take(Rp * d * es);
+  q.dh = take(Rp * ffn * es);
+  q.logits = take(Rp * (size_t)m->vp * 4);
+  q.first_logits = take(R * (size_t)m->vp * 4);
+  q.splitk_bytes = (size_t)8 * Rp * maxn * 4;   // fp32 partials of the decoder-step GEMMs
+  q.splitk = take(q.splitk_bytes);
+  q.mask = take(align_up((size_t)c.vocab, 4));
+  q.tk_val = take(R * 256 * 4);
+  q.tk_idx = take(R * 256 * 4);
+  q.tk_stat = take(R * 16 * 2 * 4);
+  q.adm_slots = (int*)take(Wc * 4);
+  q.adm_wins = (int*)take(Wc * 4);
+  q.ret_slots = (int*)take(Wc * 4);
+  DecodeState& st = q.st;
+  st.W = (int)Wc; st.nb = nb; st.L = L; st.V = c.vocab; st.ldv = m->vp;
+  st.pos = (int*)take(Wc * 4);
+  st.done = (int*)take(Wc * 4);
+  st.win = (int*)take(Wc * 4);
+  st.wmax = (int*)take(Wc * 4);
+  st.win_max_length = nullptr;
+  st.tokens_in = (int*)take(R * 4);
+  st.run_seq = (int*)take(R * L * 4);
+  st.fin_seq = (int*)take(R * L * 4);
+  st.run_score = (float*)take(R * 4);
+  st.fin_score = (float*)take(R * 4);
+  st.fin_flag = (int*)take(R * 4);
+  st.fin_len = (int*)take(R * 4);
+  st.unsat = (int*)take(Wc * 4);
+  st.anc = (unsigned char*)take(R * L);
+  st.cand_val = (float*)take(R * MAX_CAND * 4);
+  st.cand_tok = (int*)take(R * MAX_CAND * 4);
+  st.sup_mask = (const unsigned char*)q.mask;
   p.total = (size_t)(cur - base);
 }
 
 int check_geometry(const wseg_model_config& c) {
   if (c.d_model <= 0 || c.n_heads <= 0 || c.d_model != c.n_heads * 64) { set_error("d_model %d must be n_heads %d * 64", c.d_model, c.n_heads); return WSEG_ERR_INVALID; }
   if (c.d_model % 128 || c.ffn % 128) { set_error("d_model/ffn must be multiples of 128"); return WSEG_ERR_INVALID; }
-  if (c.spec_cols != 2 * c.enc_positions || c.enc_positions > 512) { set_error("spec_cols %d / enc_positions %d unsupported", c.spec_cols, c.enc_positions); return WSEG_ERR_INVALID; }
+  if (c.spec_cols != 2 * c.enc_positions || c.enc_positions > 512 || c.enc_positions < 128) { set_error("spec_cols %d / enc_positions %d unsupported", c.spec_cols, c.enc_positions); return WSEG_ERR_INVALID; }
   if (c.n_mels <= 0 || c.n_mels > 96) { set_error("n_mels %d unsupported", c.n_mels); return WSEG_ERR_INVALID; }
   if (c.dec_positions <= 0 || c.dec_positions > 512) { set_error("dec_positions %d unsupported", c.dec_positions); return WSEG_ERR_INVALID; }
   if (c.dtype != WSEG_F32 && c.dtype != WSEG_BF16) { set_error("dtype %d unsupported", c.dtype); return WSEG_ERR_INVALID; }
@@ -238,7 +244,7 @@ int run_decoder_step(wseg_model* m, DecPlan& p, bool want_logits, hipStream_t s)
       } else {
         e = EpiParams();
         e.bias = L.qkv_b; e.q = p.dq; e.k = p.sk + l * self_stride; e.v = p.sv + l * self_stride;
-        e.d_model = d; e.n_heads = H; e.t_pad = st.L; e.pos_ptr = st.pos; e.scale = 0.125f;
+        e.d_model = d; e.n_heads = H; e.t_pad = st.L; e.pos_ptr = st.pos; e.pos_div = st.nb; e.scale = 0.125f;
         WSEG_TRY(gemm(m, EPI_QKV_DEC, p.dy, d, L.qkv_w, d, R, 3 * d, d, e, &p, s));
         WSEG_TRY(launch_dec_self_attn(dt, st, p.dq, p.sk + l * self_stride, p.sv + l * self_stride, p.dattn, H, d, nullptr, nullptr, 0.125f, s));
       }
@@ -328,15 +334,19 @@ extern "C" int wseg_model_create(const wseg_model_config* cfg, wseg_model** out)
   return WSEG_OK;
 }
 
+static void ring_free(PinnedRing& r) {
+  for (int i = 0; i < PinnedRing::N; ++i) if (r.ev[i]) (void)hipEventDestroy(r.ev[i]);
+  if (r.host) (void)hipHostFree(r.host);
+  r = PinnedRing();
+}
+
 extern "C" void wseg_model_destroy(wseg_model* m) {
   if (!m) return;
-  if (m->ev_ok) for (int i = 0; i < 4; ++i) (void)hipEventDestroy(m->ev[i]);
+  for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
   if (m->step_graph) (void)hipGraphExecDestroy(m->step_graph);
   if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
-  if (m->cap_stream2) (void)hipStreamDestroy(m->cap_stream2);
-  if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
-  if (m->ev_join) (void)hipEventDestroy(m->ev_join);
-  if (m->poll) (void)hipHostFree(m->poll);
+  ring_free(m->ring_h2d);
+  ring_free(m->ring_status);
   delete m;
 }
 
@@ -382,6 +392,53 @@ extern "C" int wseg_encode(wseg_model* m, const float* feats, int32_t n_windows,
   return WSEG_OK;
 }
 
+// ---- scheduler plumbing -------------------------------------------------------------------------
+static int ring_prepare(PinnedRing& r, int cap) {
+  if (r.cap >= cap) return WSEG_OK;
+  // every entry must be idle before the buffer is replaced
+  for (int i = 0; i < PinnedRing::N; ++i) if (r.used[i]) { WSEG_HIP_CHECK(hipEventSynchronize(r.ev[i])); r.used[i] = false; }
+  if (r.host) WSEG_HIP_CHECK(hipHostFree(r.host));
+  r.host = nullptr;
+  WSEG_HIP_CHECK(hipHostMalloc((void**)&r.host, (size_t)PinnedRing::N * cap * sizeof(int), hipHostMallocDefault));
+  r.cap = cap;
+  for (int i = 0; i < PinnedRing::N; ++i) if (!r.ev[i]) WSEG_HIP_CHECK(hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming));
+  return WSEG_OK;
+}
+// next idle entry (waits for the copy that last used it)
+static int ring_acquire(PinnedRing& r, int* idx) {
+  const int i = r.next;
+  r.next = (r.next + 1) % PinnedRing::N;
+  if (r.used[i]) { WSEG_HIP_CHECK(hipEventSynchronize(r.ev[i])); r.used[i] = false; }
+  *idx = i;
+  return WSEG_OK;
+}
+static int h2d_list(wseg_model* m, const int* vals, int n, int* dev, hipStream_t s) {
+  int i;
+  WSEG_TRY(ring_acquire(m->ring_h2d, &i));
+  int* h = m->ring_h2d.host + (size_t)i * m->ring_h2d.cap;
+  memcpy(h, vals, (size_t)n * sizeof(int));
+  WSEG_HIP_CHECK(hipMemcpyAsync(dev, h, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+  WSEG_HIP_CHECK(hipEventRecord(m->ring_h2d.ev[i], s));
+  m->ring_h2d.used[i] = true;
+  return WSEG_OK;
+}
+static int timing_event(wseg_model* m, hipStream_t s, int* idx) {
+  if (m->ev_used == m->ev_pool.size()) { hipEvent_t e; WSEG_HIP_CHECK(hipEventCreate(&e)); m->ev_pool.push_back(e); }
+  *idx = (int)m->ev_used++;
+  WSEG_HIP_CHECK(hipEventRecord(m->ev_pool[*idx], s));
+  return WSEG_OK;
+}
+
+// Decode of n_windows windows through n_slots window slots with in-flight refill (continuous batching).
+//
+// The reference decodes batch by batch (model.py:653): a batch runs until its slowest window has finished.  Here a
+// finished window's slot is retired and handed to the next queued window while the other slots keep decoding: every
+// slot has its own position, every per-step kernel skips idle slots (so they cost no K/V traffic), and the captured
+// step graph never changes.  Windows are independent, so the tokens of a window do not depend on which slot it ran in
+// or on what ran beside it (row-independent kernels, fixed row count => fixed tile / split-K plan).
+// The host runs at most `lookahead` steps ahead of the device: the per-step status mirror (done flag of every slot)
+// is read behind an event, which both bounds the wasted steps after the last window finishes and tells the scheduler
+// which slots to retire / refill.
 extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_windows, const wseg_generate_params* gp,
                              void* workspace, size_t workspace_bytes, int32_t* out_tokens, int32_t* out_lengths,
                              void* stream_) {
@@ -396,134 +453,163 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
   if (gp->n_suppress < 0 || gp->n_begin_suppress < 0 || (gp->n_suppress && !gp->suppress_tokens) || (gp->n_begin_suppress && !gp->begin_suppress_tokens)) {
     set_error("bad suppress-token lists"); return WSEG_ERR_INVALID;
   }
+  if (gp->n_slots < 0 || gp->refill_min < 0 || gp->lookahead < 0) { set_error("bad scheduler parameters"); return WSEG_ERR_INVALID; }
+  const int S = gp->n_slots > 0 && gp->n_slots < n_windows ? gp->n_slots : n_windows;      // window slots
+  const int G = gp->refill_min > 0 ? gp->refill_min : (S >= 16 ? S / 8 : 1);                // admit once this many slots are free
+  const int K = gp->lookahead > 0 ? (gp->lookahead < PinnedRing::N - 2 ? gp->lookahead : PinnedRing::N - 2) : 2;
   Plan p;
-  make_plan(m, n_windows, nb, L, aligned_base(workspace), p);
+  make_plan(m, S, nb, L, aligned_base(workspace), p);
   if (p.total + 256 > workspace_bytes) { set_error("workspace too small: need %zu, have %zu", p.total + 256, workspace_bytes); return WSEG_ERR_STATE; }
-  if (!m->ev_ok) {
-    for (int i = 0; i < 4; ++i) WSEG_HIP_CHECK(hipEventCreate(&m->ev[i]));
-    m->ev_ok = true;
-  }
-  if (!m->poll) WSEG_HIP_CHECK(hipHostMalloc((void**)&m->poll, 2 * 512 * sizeof(int), hipHostMallocDefault));
-  m->epoch = (m->epoch % 100000000) + 1;
-  for (int ci = 0; ci < p.n_coh; ++ci) {
-    DecodeState& st = p.dec[ci].st;
-    st.P = P; st.eos = gp->eos_token_id; st.pad = gp->pad_token_id; st.max_length = L; st.length_penalty = gp->length_penalty;
-    for (int i = 0; i < 8; ++i) st.prompt[i] = i < P ? gp->prompt[i] : 0;
-    st.epoch = m->epoch;
-  }
+  DecPlan& q = p.dec;
+  DecodeState& st = q.st;
+  st.P = P; st.eos = gp->eos_token_id; st.pad = gp->pad_token_id; st.max_length = L; st.length_penalty = gp->length_penalty;
+  for (int i = 0; i < 8; ++i) st.prompt[i] = i < P ? gp->prompt[i] : 0;
+  st.win_max_length = gp->window_max_length;
+  WSEG_TRY(ring_prepare(m->ring_h2d, S));
+  WSEG_TRY(ring_prepare(m->ring_status, S));
 
   m->timing_valid = false;
-  WSEG_HIP_CHECK(hipEventRecord(m->ev[0], s));
-  WSEG_TRY(run_encoder(m, feats, n_windows, p, p.enc_out, s));
-  WSEG_HIP_CHECK(hipEventRecord(m->ev[1], s));
-  // cross-attention K/V of every decoder layer, once per window (shared by its beams), per cohort
-  for (int ci = 0; ci < p.n_coh; ++ci) {
-    DecPlan& q = p.dec[ci];
-    const int d = c.d_model, H = c.n_heads, Tk = c.enc_positions, M = q.W * Tk;
-    const size_t cross_stride = (size_t)q.W * H * Tk * 64 * m->es;
-    const char* enc_rows = p.enc_out + (size_t)q.w0 * Tk * d * m->es;
-    for (int l = 0; l < c.dec_layers; ++l) {
+  m->ev_used = 0; m->ev_enc.clear(); m->ev_ckv.clear();
+  m->stats = wseg_generate_stats();
+  m->stats.n_windows = n_windows; m->stats.n_slots = S;
+  WSEG_TRY(timing_event(m, s, &m->ev_total[0]));
+  WSEG_TRY(launch_build_suppress_mask((unsigned char*)q.mask, c.vocab, gp->suppress_tokens, gp->n_suppress,
+                                      gp->begin_suppress_tokens, gp->n_begin_suppress, s));
+  WSEG_TRY(launch_decode_reset(st, s));
+
+  const int d = c.d_model, H = c.n_heads, Tk = c.enc_positions;
+  const size_t cross_stride = (size_t)S * H * Tk * 64 * m->es;
+  const size_t feat_stride = (size_t)c.n_mels * c.spec_cols;
+
+  // host view of the slots
+  std::vector<int> slot_win(S, -1), slot_from(S, 0);   // window in the slot (-1 = free), first step whose status counts for it
+  std::vector<int> free_slots, tmp_a, tmp_b;
+  for (int i = S - 1; i >= 0; --i) free_slots.push_back(i);   // popped from the back: lowest slot first
+  int next_win = 0, in_flight = 0, t = 0;
+
+  // encoder + cross-K/V of the next `n` queued windows into `n` free slots; their decode state starts at position 0
+  auto admit = [&](int n) -> int {
+    tmp_a.clear(); tmp_b.clear();
+    for (int i = 0; i < n; ++i) {
+      const int sl = free_slots.back(); free_slots.pop_back();
+      tmp_a.push_back(sl); tmp_b.push_back(next_win + i);
+      slot_win[sl] = next_win + i; slot_from[sl] = t;
+    }
+    WSEG_TRY(h2d_list(m, tmp_a.data(), n, q.adm_slots, s));
+    WSEG_TRY(h2d_list(m, tmp_b.data(), n, q.adm_wins, s));
+    int e0, e1, e2;
+    WSEG_TRY(timing_event(m, s, &e0));
+    WSEG_TRY(run_encoder(m, feats + (size_t)next_win * feat_stride, n, p, p.enc_out, s));
+    WSEG_TRY(timing_event(m, s, &e1));
+    for (int l = 0; l < c.dec_layers; ++l) {     // cross-attention K/V of every decoder layer, once per window (shared by its beams)
       EpiParams e;
       e.bias = m->dec[l].ckv_b; e.k = q.ck + l * cross_stride; e.v = q.cv + l * cross_stride;
-      e.d_model = d; e.t_len = Tk; e.n_heads = H;
-      WSEG_TRY(gemm(m, EPI_KV_CROSS, enc_rows, d, m->dec[l].ckv_w, d, M, 2 * d, d, e, nullptr, s));
+      e.d_model = d; e.t_len = Tk; e.n_heads = H; e.slot_map = q.adm_slots;
+      WSEG_TRY(gemm(m, EPI_KV_CROSS, p.enc_out, d, m->dec[l].ckv_w, d, n * Tk, 2 * d, d, e, nullptr, s));
     }
-  }
-  WSEG_HIP_CHECK(hipEventRecord(m->ev[2], s));
-  for (int ci = 0; ci < p.n_coh; ++ci) {
-    WSEG_TRY(launch_build_suppress_mask((unsigned char*)p.dec[ci].mask, c.vocab, gp->suppress_tokens, gp->n_suppress,
-                                        gp->begin_suppress_tokens, gp->n_begin_suppress, s));
-    WSEG_TRY(launch_decode_init(p.dec[ci].st, s));
-  }
-
-  // One generated-token step of one cohort: decoder layers, LM head, candidates, bookkeeping, advance, verdict mirror.
-  auto enqueue_gen_step = [&](int ci, bool snapshot_logits, hipStream_t qs) -> int {
-    DecPlan& q = p.dec[ci];
-    WSEG_TRY(run_decoder_step(m, q, true, qs));
-    if (snapshot_logits)
-      WSEG_HIP_CHECK(hipMemcpyAsync(q.first_logits, q.logits, (size_t)q.W * nb * m->vp * 4, hipMemcpyDeviceToDevice, qs));
-    WSEG_TRY(launch_row_topk(q.st, (const float*)q.logits, (float*)q.tk_val, (int*)q.tk_idx, (float*)q.tk_stat, qs));
-    if (nb == 1) WSEG_TRY(launch_greedy_step(q.st, qs));
-    else WSEG_TRY(launch_beam_step(q.st, qs));
-    WSEG_TRY(launch_advance(q.st, qs));
-    WSEG_HIP_CHECK(hipMemcpyAsync(m->poll + ci * 512, q.st.flags, (size_t)L * sizeof(int), hipMemcpyDeviceToHost, qs));
+    WSEG_TRY(timing_event(m, s, &e2));
+    m->ev_enc.push_back(e0); m->ev_enc.push_back(e1); m->ev_ckv.push_back(e1); m->ev_ckv.push_back(e2);
+    WSEG_TRY(launch_decode_admit(st, q.adm_slots, q.adm_wins, n, s));
+    next_win += n; in_flight += n;
+    m->stats.n_admissions += 1;
     return WSEG_OK;
   };
-  // The step reads every step-dependent value (position, tokens, ancestry, epoch) from device memory, so ONE captured
-  // graph serves all steps and later calls: replay costs ~1.6 us per kernel instead of ~5 us per eager launch.  With two
-  // cohorts the graph has two parallel branches (fork / join through events on two capture streams).
+
+  // One decode step of every active slot: decoder layers, LM head, candidates, bookkeeping (which also advances the slot).
+  auto enqueue_step = [&](bool snapshot_logits, hipStream_t qs) -> int {
+    WSEG_TRY(run_decoder_step(m, q, true, qs));
+    if (snapshot_logits)
+      WSEG_HIP_CHECK(hipMemcpyAsync(q.first_logits, q.logits, (size_t)S * nb * m->vp * 4, hipMemcpyDeviceToDevice, qs));
+    WSEG_TRY(launch_row_topk(st, (const float*)q.logits, (float*)q.tk_val, (int*)q.tk_idx, (float*)q.tk_stat, qs));
+    if (nb == 1) WSEG_TRY(launch_greedy_step(st, qs));
+    else WSEG_TRY(launch_beam_step(st, qs));
+    return WSEG_OK;
+  };
+  // The step reads every step-dependent value (positions, tokens, ancestry, idle flags) from device memory, so ONE
+  // captured graph serves all steps and later calls: replay costs ~1.6 us per kernel instead of ~5 us per eager launch.
   static const bool use_graph = getenv("WSEG_NO_GRAPH") == nullptr;
   std::vector<unsigned char> key;
   {
     auto put = [&](const void* ptr, size_t n) { const unsigned char* b = (const unsigned char*)ptr; key.insert(key.end(), b, b + n); };
     void* base = aligned_base(workspace);
-    const DecodeState& st = p.dec[0].st;
-    put(&base, sizeof(base)); put(&n_windows, 4); put(&nb, 4); put(&L, 4); put(&p.n_coh, 4);
+    put(&base, sizeof(base)); put(&S, 4); put(&nb, 4); put(&L, 4);
     put(&st.P, 4); put(&st.eos, 4); put(&st.pad, 4); put(&st.length_penalty, 4); put(st.prompt, sizeof(st.prompt));
+    put(&st.win_max_length, sizeof(st.win_max_length));
   }
-  int steps = 0;
-  bool stop = false;
-  auto check_stop = [&](int upto) {
-    int done = 0;
-    for (int ci = 0; ci < p.n_coh; ++ci) {
-      const volatile int* pl = (const volatile int*)(m->poll + ci * 512);
-      for (int t = P - 1; t < upto; ++t)
-        if (pl[t] == m->epoch * 4 + 2) { ++done; break; }
+  auto launch_step = [&]() -> int {
+    // the first generated step of a call whose windows all start together is launched eagerly with the logits snapshot
+    // (wseg_debug_first_logits); every other step replays the graph
+    const bool snap = t == P - 1 && n_windows <= S;
+    if (snap || !use_graph) return enqueue_step(snap, s);
+    if (!m->step_graph || m->step_graph_key != key) {
+      if (m->step_graph) { (void)hipGraphExecDestroy(m->step_graph); m->step_graph = nullptr; }
+      hipGraph_t graph = nullptr;
+      if (!m->cap_stream) WSEG_HIP_CHECK(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+      WSEG_HIP_CHECK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
+      const int rc = enqueue_step(false, m->cap_stream);
+      const hipError_t ec = hipStreamEndCapture(m->cap_stream, &graph);
+      if (rc != WSEG_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+      if (ec != hipSuccess) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ec)); return WSEG_ERR_HIP; }
+      WSEG_HIP_CHECK(hipGraphInstantiate(&m->step_graph, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      m->step_graph_key = key;
     }
-    if (done == p.n_coh) stop = true;
+    WSEG_HIP_CHECK(hipGraphLaunch(m->step_graph, s));
+    return WSEG_OK;
   };
-  for (int t = 0; t < L - 1 && !stop; ++t) {
-    if (t < P - 1) {
-      for (int ci = 0; ci < p.n_coh; ++ci) {
-        WSEG_TRY(run_decoder_step(m, p.dec[ci], false, s));
-        WSEG_TRY(launch_prompt_feed(p.dec[ci].st, s));
-        WSEG_TRY(launch_advance(p.dec[ci].st, s));
-      }
-    } else if (t == P - 1 || !use_graph) {
-      for (int ci = 0; ci < p.n_coh; ++ci) WSEG_TRY(enqueue_gen_step(ci, t == P - 1, s));
-    } else {
-      if (!m->step_graph || m->step_graph_key != key) {
-        if (m->step_graph) { (void)hipGraphExecDestroy(m->step_graph); m->step_graph = nullptr; }
-        hipGraph_t graph = nullptr;
-        if (!m->cap_stream) WSEG_HIP_CHECK(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
-        if (!m->cap_stream2) {
-          WSEG_HIP_CHECK(hipStreamCreateWithFlags(&m->cap_stream2, hipStreamNonBlocking));
-          WSEG_HIP_CHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-          WSEG_HIP_CHECK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
-        }
-        WSEG_HIP_CHECK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
-        int rc = WSEG_OK;
-        if (p.n_coh == 2) {
-          hipError_t e1 = hipEventRecord(m->ev_fork, m->cap_stream);
-          hipError_t e2 = hipStreamWaitEvent(m->cap_stream2, m->ev_fork, 0);
-          if (e1 != hipSuccess || e2 != hipSuccess) rc = WSEG_ERR_HIP;
-          if (rc == WSEG_OK) rc = enqueue_gen_step(1, false, m->cap_stream2);
-          if (rc == WSEG_OK) rc = enqueue_gen_step(0, false, m->cap_stream);
-          e1 = hipEventRecord(m->ev_join, m->cap_stream2);
-          e2 = hipStreamWaitEvent(m->cap_stream, m->ev_join, 0);
-          if (rc == WSEG_OK && (e1 != hipSuccess || e2 != hipSuccess)) rc = WSEG_ERR_HIP;
-        } else {
-          rc = enqueue_gen_step(0, false, m->cap_stream);
-        }
-        const hipError_t ec = hipStreamEndCapture(m->cap_stream, &graph);
-        if (rc != WSEG_OK) { if (graph) (void)hipGraphDestroy(graph); if (rc == WSEG_ERR_HIP) set_error("graph capture fork/join failed"); return rc; }
-        if (ec != hipSuccess) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ec)); return WSEG_ERR_HIP; }
-        WSEG_HIP_CHECK(hipGraphInstantiate(&m->step_graph, graph, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(graph);
-        m->step_graph_key = key;
-      }
-      WSEG_HIP_CHECK(hipGraphLaunch(m->step_graph, s));
+
+  // status mirror of step u lives in ring entry status_idx[u % N]
+  int status_idx[PinnedRing::N];
+  auto consume_status = [&](int u) -> int {      // retire every slot that step u left finished
+    const int ri = status_idx[u % PinnedRing::N];
+    WSEG_HIP_CHECK(hipEventSynchronize(m->ring_status.ev[ri]));
+    m->ring_status.used[ri] = false;
+    const int* done = m->ring_status.host + (size_t)ri * m->ring_status.cap;
+    tmp_a.clear();
+    int active = 0;
+    for (int sl = 0; sl < S; ++sl) {
+      if (slot_win[sl] < 0 || u < slot_from[sl]) continue;
+      if (done[sl]) { tmp_a.push_back(sl); slot_win[sl] = -1; }
+      else ++active;
     }
-    ++steps;
-    // lagged, non-blocking poll of the pinned verdict mirror: stop enqueueing once a finished step of EVERY cohort reported
-    // that no window can still improve (steps already enqueued are harmless: finished beams are frozen)
-    check_stop(t);
+    m->stats.slot_steps_active += active + (int64_t)tmp_a.size();
+    if (!tmp_a.empty()) {
+      const int n = (int)tmp_a.size();
+      WSEG_TRY(h2d_list(m, tmp_a.data(), n, q.ret_slots, s));
+      WSEG_TRY(launch_finalize(st, q.ret_slots, n, out_tokens, out_lengths, s));
+      for (int sl : tmp_a) free_slots.push_back(sl);
+      std::sort(free_slots.begin(), free_slots.end(), [](int a, int b) { return a > b; });
+      in_flight -= n;
+    }
+    return WSEG_OK;
+  };
+
+  int consumed = 0;                               // statuses of steps [0, consumed) have been processed
+  while (true) {
+    const int remaining = n_windows - next_win, n_free = (int)free_slots.size();
+    const int n_adm = remaining < n_free ? remaining : n_free;
+    if (n_adm > 0 && (n_adm >= G || n_adm == remaining || in_flight == 0)) WSEG_TRY(admit(n_adm));
+    if (in_flight == 0) break;
+    WSEG_TRY(launch_step());
+    {   // mirror the idle flags of this step
+      int ri;
+      WSEG_TRY(ring_acquire(m->ring_status, &ri));
+      WSEG_HIP_CHECK(hipMemcpyAsync(m->ring_status.host + (size_t)ri * m->ring_status.cap, st.done, (size_t)S * sizeof(int),
+                                    hipMemcpyDeviceToHost, s));
+      WSEG_HIP_CHECK(hipEventRecord(m->ring_status.ev[ri], s));
+      m->ring_status.used[ri] = true;
+      status_idx[t % PinnedRing::N] = ri;
+    }
+    ++t;
+    m->stats.slot_steps_total += S;
+    // stay at most K steps ahead of the device
+    while (consumed < t - K) WSEG_TRY(consume_status(consumed++));
   }
-  for (int ci = 0; ci < p.n_coh; ++ci)
-    WSEG_TRY(launch_finalize(p.dec[ci].st, out_tokens + (size_t)p.dec[ci].w0 * L, out_lengths + p.dec[ci].w0, s));
-  WSEG_HIP_CHECK(hipEventRecord(m->ev[3], s));
-  m->last_steps = steps;
-  m->last_W = n_windows; m->last_nb = nb; m->last_L = L;
+  while (consumed < t) WSEG_TRY(consume_status(consumed++));
+  if (in_flight != 0) { set_error("scheduler ended with %d windows in flight", in_flight); return WSEG_ERR_STATE; }
+  WSEG_TRY(timing_event(m, s, &m->ev_total[1]));
+  m->stats.n_steps = t;
+  m->last_W = S; m->last_nb = nb; m->last_L = L;
   m->timing_valid = true;
   return WSEG_OK;
 }
@@ -531,28 +617,41 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
 extern "C" int wseg_debug_first_logits(wseg_model* m, void* workspace, float* out, int32_t n_rows, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   if (!m || !workspace || !out || n_rows <= 0) { set_error("wseg_debug_first_logits: bad argument"); return WSEG_ERR_INVALID; }
-  if (m->last_W <= 0 || n_rows > m->last_W * m->last_nb) { set_error("no matching wseg_generate call"); return WSEG_ERR_STATE; }
+  if (m->last_W <= 0 || n_rows > m->last_W * m->last_nb || m->stats.n_windows > m->stats.n_slots) {
+    set_error("no matching wseg_generate call (all windows must have started together)"); return WSEG_ERR_STATE;
+  }
   Plan p;
   make_plan(m, m->last_W, m->last_nb, m->last_L, aligned_base(workspace), p);
-  for (int ci = 0; ci < p.n_coh; ++ci) {
-    const DecPlan& q = p.dec[ci];
-    const int r0 = q.w0 * m->last_nb;
-    int rows = q.W * m->last_nb;
-    if (r0 >= n_rows) break;
-    if (r0 + rows > n_rows) rows = n_rows - r0;
-    WSEG_HIP_CHECK(hipMemcpy2DAsync(out + (size_t)r0 * m->cfg.vocab, (size_t)m->cfg.vocab * 4, q.first_logits, (size_t)m->vp * 4,
-                                    (size_t)m->cfg.vocab * 4, (size_t)rows, hipMemcpyDeviceToDevice, s));
-  }
+  WSEG_HIP_CHECK(hipMemcpy2DAsync(out, (size_t)m->cfg.vocab * 4, p.dec.first_logits, (size_t)m->vp * 4,
+                                  (size_t)m->cfg.vocab * 4, (size_t)n_rows, hipMemcpyDeviceToDevice, s));
   return WSEG_OK;
 }
 
 extern "C" int wseg_last_timing(const wseg_model* m, float out[4]) {
   if (!m || !out) { set_error("wseg_last_timing: null argument"); return WSEG_ERR_INVALID; }
   if (!m->timing_valid) { set_error("no completed wseg_generate call to time"); return WSEG_ERR_STATE; }
-  for (int i = 0; i < 3; ++i) {
-    WSEG_HIP_CHECK(hipEventSynchronize(m->ev[i + 1]));
-    WSEG_HIP_CHECK(hipEventElapsedTime(&out[i], m->ev[i], m->ev[i + 1]));
-  }
-  out[3] = (float)m->last_steps;
+  WSEG_HIP_CHECK(hipEventSynchronize(m->ev_pool[m->ev_total[1]]));
+  auto sum_pairs = [&](const std::vector<int>& v, float* acc) -> int {
+    *acc = 0.f;
+    for (size_t i = 0; i + 1 < v.size(); i += 2) {
+      float ms = 0.f;
+      WSEG_HIP_CHECK(hipEventElapsedTime(&ms, m->ev_pool[v[i]], m->ev_pool[v[i + 1]]));
+      *acc += ms;
+    }
+    return WSEG_OK;
+  };
+  float total = 0.f;
+  WSEG_TRY(sum_pairs(m->ev_enc, &out[0]));
+  WSEG_TRY(sum_pairs(m->ev_ckv, &out[1]));
+  WSEG_HIP_CHECK(hipEventElapsedTime(&total, m->ev_pool[m->ev_total[0]], m->ev_pool[m->ev_total[1]]));
+  out[2] = total - out[0] - out[1];
+  out[3] = (float)m->stats.n_steps;
+  return WSEG_OK;
+}
+
+extern "C" int wseg_last_stats(const wseg_model* m, wseg_generate_stats* out) {
+  if (!m || !out) { set_error("wseg_last_stats: null argument"); return WSEG_ERR_INVALID; }
+  if (!m->timing_valid) { set_error("no completed wseg_generate call"); return WSEG_ERR_STATE; }
+  *out = m->stats;
   return WSEG_OK;
 }

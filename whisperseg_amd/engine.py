@@ -25,6 +25,7 @@ DEFAULT_SUPPRESS_TOKENS = [
     18956, 20075, 21675, 22520, 26130, 26161, 26435, 28279, 29464, 31650, 32302, 32470, 36865, 42863, 47425, 49870,
     50254, 50258, 50358, 50359, 50360, 50361, 50362]
 DEFAULT_BEGIN_SUPPRESS_TOKENS = [220, 50257]
+DEFAULT_SLOTS = 256     # window slots decoded concurrently per GPU (in-flight batching; include/wseg.h)
 
 
 def _round_up(v, a):
@@ -56,10 +57,14 @@ def prepare_weights(sd, geo, torch_dtype, device):
     d, n_mels = geo["d_model"], geo["n_mels"]
     dev = torch.device(device)
 
-    def g(name):
+    def g(name):      # one tensor at a time: `sd` may be a LazyCheckpoint reading shards on demand
         return sd[name].to(device=dev, dtype=torch.float32)
 
-    out = {}
+    class _Out(dict):     # every prepared tensor is cast to the model dtype as soon as it exists (no full fp32 copy)
+        def __setitem__(self, key, value):
+            dict.__setitem__(self, key, value.to(torch_dtype).contiguous())
+
+    out = _Out()
     kp1 = _round_up(3 * n_mels, 64)
     w1 = g("model.encoder.conv1.weight").permute(0, 2, 1).reshape(d, 3 * n_mels)
     out["enc.conv1.w"] = torch.nn.functional.pad(w1, (0, kp1 - 3 * n_mels))
@@ -110,7 +115,7 @@ def prepare_weights(sd, geo, torch_dtype, device):
         attn(t, s + "encoder_attn.", fused_kv_only=True)
         ln(t + "ln3", s + "final_layer_norm")
         mlp(t, s)
-    return {k: v.to(torch_dtype).contiguous() for k, v in out.items()}
+    return dict(out)
 
 
 def random_weights(geo, torch_dtype, device, seed=0):
@@ -177,16 +182,16 @@ class Engine:
 
     @classmethod
     def from_pretrained(cls, model_dir, device="cuda:0", dtype="bf16"):
-        """Read an HF-style checkpoint directory (config.json + model.safetensors | pytorch_model.bin)."""
+        """Read an HF-style checkpoint directory: config.json + model.safetensors | pytorch_model.bin, single-file or
+        sharded with an index (whisperseg_amd/checkpoint.py; what the reference's save_pretrained writes, model.py:59-74)."""
+        from .checkpoint import LazyCheckpoint
         with open(os.path.join(model_dir, "config.json")) as f:
             hf_config = json.load(f)
-        st = os.path.join(model_dir, "model.safetensors")
-        if os.path.exists(st):
-            from safetensors.torch import load_file
-            sd = load_file(st)
-        else:
-            sd = torch.load(os.path.join(model_dir, "pytorch_model.bin"), map_location="cpu", weights_only=True)
-        return cls.from_state_dict(sd, hf_config, device, dtype)
+        ckpt = LazyCheckpoint(model_dir)
+        try:
+            return cls.from_state_dict(ckpt, hf_config, device, dtype)
+        finally:
+            ckpt.close()
 
     @classmethod
     def random(cls, hf_config, device="cuda:0", dtype="bf16", seed=0):
@@ -201,14 +206,26 @@ class Engine:
         except Exception:
             pass
 
-    def _workspace(self, n_windows, num_beams, max_length):
-        need = self.lib.wseg_workspace_bytes(self.handle, n_windows, num_beams, max_length)
+    def _workspace(self, n_slots, num_beams, max_length):
+        need = self.lib.wseg_workspace_bytes(self.handle, n_slots, num_beams, max_length)
         if need == 0:
             raise _lib.WsegError("wseg_workspace_bytes rejected the request")
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
+
+    def pick_slots(self, n_windows, num_beams, max_length, n_slots=None):
+        """Window slots for a generate call: min(n_windows, cap) where cap is `n_slots`, else $WSEG_SLOTS, else 256 —
+        halved until the workspace (cross-K/V + encoder activations, ~150 MB per slot for whisperseg-large) fits in
+        80 % of the free device memory (plus what this engine's current workspace already holds)."""
+        cap = int(n_slots or os.environ.get("WSEG_SLOTS", 0) or DEFAULT_SLOTS)
+        s = max(1, min(int(n_windows), cap))
+        free, _ = torch.cuda.mem_get_info(self.device)
+        budget = 0.8 * (free + (self._ws.numel() if self._ws is not None else 0))
+        while s > 1 and self.lib.wseg_workspace_bytes(self.handle, s, num_beams, max_length) > budget:
+            s = (s + 1) // 2
+        return s
 
     def encode(self, feats):
         """feats float32 device tensor [W, 80, 1000] -> [W, 500, d] in the model dtype."""
@@ -222,12 +239,17 @@ class Engine:
         return out
 
     def generate(self, feats, prompt, eos_token_id, pad_token_id, max_length=448, num_beams=4, length_penalty=1.0,
-                 suppress_tokens=(), begin_suppress_tokens=(), return_first_logits=False):
-        """Greedy / beam-search decode.  Returns (tokens int32 [W, max_length] on device, lengths int32 [W])."""
+                 suppress_tokens=(), begin_suppress_tokens=(), return_first_logits=False, n_slots=None, refill_min=0,
+                 lookahead=0, window_max_length=None):
+        """Greedy / beam-search decode of ALL windows of `feats` [N, 80, 1000] through `n_slots` window slots with
+        in-flight refill (a finished window's slot goes to the next queued window; wseg_generate).
+        Returns (tokens int32 [N, max_length] on device, lengths int32 [N])."""
         feats = feats.to(device=self.device, dtype=torch.float32).contiguous()
         W = feats.shape[0]
         max_length = int(min(max_length, self.geo["dec_positions"]))
-        ws = self._workspace(W, num_beams, max_length)
+        with torch.cuda.device(self.device):
+            slots = self.pick_slots(W, num_beams, max_length, n_slots)
+            ws = self._workspace(slots, num_beams, max_length)
         sup = torch.tensor(list(suppress_tokens) or [0], dtype=torch.int32, device=self.device)
         bsup = torch.tensor(list(begin_suppress_tokens) or [0], dtype=torch.int32, device=self.device)
         gp = _lib.GenerateParams()
@@ -238,17 +260,35 @@ class Engine:
         gp.max_length, gp.num_beams, gp.length_penalty = max_length, int(num_beams), float(length_penalty)
         gp.suppress_tokens, gp.n_suppress = sup.data_ptr(), len(suppress_tokens)
         gp.begin_suppress_tokens, gp.n_begin_suppress = bsup.data_ptr(), len(begin_suppress_tokens)
+        gp.n_slots, gp.refill_min, gp.lookahead = int(slots), int(refill_min), int(lookahead)
+        wml = None
+        if window_max_length is not None:      # per-window total-length caps (int32 [W])
+            wml = torch.as_tensor(window_max_length, dtype=torch.int32).to(self.device).contiguous()
+            if wml.numel() != W:
+                raise ValueError("window_max_length needs one entry per window")
+            gp.window_max_length = wml.data_ptr()
         tokens = torch.empty((W, max_length), dtype=torch.int32, device=self.device)
         lengths = torch.empty((W,), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.wseg_generate(self.handle, feats.data_ptr(), W, C.byref(gp), ws.data_ptr(), ws.numel(),
                                               tokens.data_ptr(), lengths.data_ptr(), _lib.stream_ptr()))
             if return_first_logits:
+                if W > slots:
+                    raise ValueError("return_first_logits needs every window to start together (n_slots >= windows)")
                 fl = torch.empty((W * num_beams, self.geo["vocab"]), dtype=torch.float32, device=self.device)
                 _lib.check(self.lib.wseg_debug_first_logits(self.handle, ws.data_ptr(), fl.data_ptr(), W * num_beams,
                                                             _lib.stream_ptr()))
                 return tokens, lengths, fl
         return tokens, lengths
+
+    def last_stats(self):
+        """Scheduler statistics of the last generate call: dict(n_windows, n_slots, n_steps, n_admissions,
+        slot_steps_active, slot_steps_total, occupancy)."""
+        st = _lib.GenerateStats()
+        _lib.check(self.lib.wseg_last_stats(self.handle, C.byref(st)))
+        out = {k: int(getattr(st, k)) for k, _ in st._fields_}
+        out["occupancy"] = out["slot_steps_active"] / max(1, out["slot_steps_total"])
+        return out
 
     def last_timing(self):
         """(encoder_ms, cross_kv_ms, decode_ms, n_steps) of the last generate call (synchronises)."""

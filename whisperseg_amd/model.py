@@ -17,12 +17,14 @@ import torch
 
 from . import _lib, postprocess, scoring
 from .audio_utils import get_feature_extractor, get_n_fft_given_sr
+from .checkpoint import checkpoint_files
 from .engine import DEFAULT_BEGIN_SUPPRESS_TOKENS, DEFAULT_SUPPRESS_TOKENS, Engine
 from .tokenizer import WhisperSegTokenizer
 from .utils import RATIO_DECODING_TIME_STEP_TO_SPEC_TIME_STEP
 from .windows import shard_bounds, window_table
 
 PROMPT_TOKENS = ["<|startoftranscript|>", "<|en|>", "<|notimestamps|>"]   # reference model.py:656
+POOL_WINDOWS = 2048      # windows per engine call / per pooled group of files (655 MB of log-mel features)
 
 
 def _read_json(path, default=None):
@@ -130,21 +132,27 @@ class SegmenterBase:
 
     def _decode_token_batches(self, engine, tokenizer, sliced, batch_size, max_length, num_beams, top_k, top_p,
                               length_penalty, status_monitor=None):
-        """-> list of (tokens int32 [b, L] device, lengths int32 [b] device), one entry per batch."""
+        """-> list of (tokens int32 [b, L] device, lengths int32 [b] device).
+
+        The reference decodes `batch_size` windows per `generate` call (model.py:653) and every batch runs until its slowest
+        window ends.  Here ALL windows go to the engine, which decodes them through its window slots with in-flight refill
+        (wseg_generate); `batch_size` is accepted for API compatibility and does not cap the concurrency (the engine bounds
+        its slots by device memory; $WSEG_SLOTS overrides).  Calls are chunked at POOL_WINDOWS windows only to bound the
+        stacked feature tensor."""
         if num_beams == 1 and top_k != 1:
             raise NotImplementedError("sampling (num_beams=1 with top_k != 1) is not implemented; the reference's "
                                       "default top_k=1 is the deterministic argmax")
         prompt = tokenizer.convert_tokens_to_ids(PROMPT_TOKENS)
         out = []
         n = len(sliced)
-        for pos in range(0, n, batch_size):
-            batch = torch.stack([item[2].to(engine.device) for item in sliced[pos:pos + batch_size]])
+        for pos in range(0, n, POOL_WINDOWS):
+            batch = torch.stack([item[2].to(engine.device) for item in sliced[pos:pos + POOL_WINDOWS]])
             out.append(engine.generate(batch, prompt, tokenizer.eos_token_id, tokenizer.pad_token_id,
                                        max_length=max_length, num_beams=num_beams, length_penalty=length_penalty,
                                        suppress_tokens=self.suppress_tokens,
                                        begin_suppress_tokens=self.begin_suppress_tokens))
             if status_monitor is not None:
-                status_monitor["progress"] = int(100 * min(1, (pos + batch_size) / n))
+                status_monitor["progress"] = int(100 * min(1, (pos + POOL_WINDOWS) / n))
         return out
 
     def _decode_batches(self, engine, tokenizer, sliced, batch_size, max_length, num_beams, top_k, top_p,
@@ -221,7 +229,7 @@ class SegmenterBase:
 
     # ---- many recordings at once (continuous batching across files) -----------------
     @torch.no_grad()
-    def segment_batch(self, audios, srs, min_frequency=None, spec_time_step=None, min_segment_length=None, eps=None,
+    def segment_batch(self, audios, srs=None, min_frequency=None, spec_time_step=None, min_segment_length=None, eps=None,
                       time_per_frame_for_voting=None, consolidation_method="clustering", max_length=448, batch_size=4,
                       num_trials=1, num_beams=4, top_k=1, top_p=1.0, length_penalty=1.0, status_monitor=None):
         """segment() for a list of recordings with their windows POOLED into shared decode batches.
@@ -229,9 +237,15 @@ class SegmenterBase:
         The reference batches only inside one file (model.py:653) and its folder mode is a serial loop
         (scripts/segment.py:39-56), so short clips decode with 1-2 windows per launch.  Windows are independent, hence
         pooling changes nothing but the batch a window is decoded in: the per-recording results equal segment()'s
-        (bit-identical in f32 mode).  `srs` is one int or a list.  Returns a list of prediction dicts."""
-        if isinstance(srs, (int, float)):
-            srs = [srs] * len(audios)
+        (bit-identical in f32 mode).  `srs` is one int, a list, or None when `audios` yields (audio, sr) pairs — `audios`
+        may be a generator that loads files lazily: recordings are consumed group by group.  Returns a list of
+        prediction dicts."""
+        if srs is None:
+            pairs = iter(audios)
+        elif isinstance(srs, (int, float)):
+            pairs = ((a, srs) for a in audios)
+        else:
+            pairs = zip(audios, srs)
         defaults = self.default_segmentation_config
         if min_frequency is None:
             min_frequency = defaults.get("min_frequency", 0)
@@ -243,18 +257,33 @@ class SegmenterBase:
             eps = spec_time_step * RATIO_DECODING_TIME_STEP_TO_SPEC_TIME_STEP * 4
         if time_per_frame_for_voting is None:
             time_per_frame_for_voting = spec_time_step
-        per_file = [self.get_sliced_audios_features(a, sr, min_frequency, spec_time_step, num_trials) for a, sr in zip(audios, srs)]
-        pooled = [w for windows in per_file for w in windows]
-        texts = self.generate_segment_text(pooled, batch_size, max_length, num_beams, top_k, top_p, length_penalty,
-                                           status_monitor) if pooled else []
-        out, pos = [], 0
-        for audio, sr, windows in zip(audios, srs, per_file):
-            mine = texts[pos:pos + len(windows)]
-            pos += len(windows)
-            pred = self.parse_generation(mine, windows, min_segment_length, len(audio) / sr, spec_time_step, num_trials, eps,
-                                         time_per_frame_for_voting, consolidation_method)
-            pred = postprocess.correct_fft_blur(pred, get_n_fft_given_sr(sr), sr)
-            out.append(postprocess.drop_consecutive_duplicates(pred))
+        out, group, pending = [], [], 0
+
+        def flush():
+            nonlocal group, pending
+            pooled = [w for _, _, windows in group for w in windows]
+            texts = self.generate_segment_text(pooled, batch_size, max_length, num_beams, top_k, top_p, length_penalty,
+                                               status_monitor) if pooled else []
+            pos = 0
+            for duration, sr, windows in group:
+                mine = texts[pos:pos + len(windows)]
+                pos += len(windows)
+                pred = self.parse_generation(mine, windows, min_segment_length, duration, spec_time_step, num_trials,
+                                             eps, time_per_frame_for_voting, consolidation_method)
+                pred = postprocess.correct_fft_blur(pred, get_n_fft_given_sr(sr), sr)
+                out.append(postprocess.drop_consecutive_duplicates(pred))
+            group, pending = [], 0
+
+        # recordings are pooled in bounded groups (~POOL_WINDOWS windows): features of a group are freed before the next
+        # group is cut, so a large folder needs no more device memory than a small one
+        for audio, sr in pairs:
+            windows = self.get_sliced_audios_features(audio, sr, min_frequency, spec_time_step, num_trials)
+            group.append((len(audio) / sr, sr, windows))
+            pending += len(windows)
+            if pending >= POOL_WINDOWS:
+                flush()
+        if group:
+            flush()
         return out
 
     # ---- scoring helpers (reference model.py:474-569) --------------------------------------------
@@ -316,8 +345,7 @@ class WhisperSegmenterFast(WhisperSegmenter):
 
     def __init__(self, model_path, device=None, device_ids=[0, ]):
         model_dir = resolve_model_dir(model_path)
-        if not any(os.path.exists(os.path.join(model_dir, n)) for n in ("model.safetensors", "pytorch_model.bin")):
-            raise FileNotFoundError(f"{model_dir} holds no HF weights (CTranslate2 model.bin is not supported)")
+        checkpoint_files(model_dir)      # raises FileNotFoundError for a CTranslate2-only directory
         super().__init__(model_path, device=device, device_ids=device_ids, dtype="bf16")
 
 
