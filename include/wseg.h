@@ -141,9 +141,12 @@ typedef struct {
    * scripts/segment.py:39-56).  0 selects the default of each. */
   int32_t n_slots;                /* window slots decoded concurrently; 0 or >= n_windows: one slot per window          */
   int32_t refill_min;             /* admit queued windows once this many slots are free; 0: n_slots / 8 (min 1)         */
-  int32_t lookahead;              /* decode steps the host may run ahead of the device; 0: 2                            */
+  int32_t lookahead;              /* decode steps the host may run ahead of the device; 0: 1                            */
   const int32_t* window_max_length; /* device [n_windows] per-window cap on the total length (clamped to max_length), or
                                      NULL: every window may run to max_length                                           */
+  const void* encoder_output;     /* device [n_windows][enc_positions][d_model] in the model dtype: precomputed encoder
+                                     states (wseg_encode) used instead of running the encoder on feats (feats may then
+                                     be NULL; rows past the last window must be readable up to a multiple of 256), or NULL */
 } wseg_generate_params;
 
 /*

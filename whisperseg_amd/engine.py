@@ -240,7 +240,7 @@ class Engine:
 
     def generate(self, feats, prompt, eos_token_id, pad_token_id, max_length=448, num_beams=4, length_penalty=1.0,
                  suppress_tokens=(), begin_suppress_tokens=(), return_first_logits=False, n_slots=None, refill_min=0,
-                 lookahead=0, window_max_length=None):
+                 lookahead=0, window_max_length=None, encoder_output=None):
         """Greedy / beam-search decode of ALL windows of `feats` [N, 80, 1000] through `n_slots` window slots with
         in-flight refill (a finished window's slot goes to the next queued window; wseg_generate).
         Returns (tokens int32 [N, max_length] on device, lengths int32 [N])."""
@@ -267,6 +267,12 @@ class Engine:
             if wml.numel() != W:
                 raise ValueError("window_max_length needs one entry per window")
             gp.window_max_length = wml.data_ptr()
+        enc = None
+        if encoder_output is not None:         # precomputed encoder states [W, 500, d] (padded to the GEMM's 256-row granularity)
+            enc = encoder_output.to(device=self.device, dtype=self.torch_dtype).reshape(W * self.geo["enc_positions"], self.geo["d_model"])
+            pad = _round_up(enc.shape[0], 256) - enc.shape[0]
+            enc = torch.nn.functional.pad(enc, (0, 0, 0, pad)).contiguous()
+            gp.encoder_output = enc.data_ptr()
         tokens = torch.empty((W, max_length), dtype=torch.int32, device=self.device)
         lengths = torch.empty((W,), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
