@@ -219,7 +219,7 @@ def main(argv=None, backend=make_backend):
     ap.add_argument("--beams", type=int, default=4)
     ap.add_argument("--sr", type=int, default=16000)
     ap.add_argument("--spec-time-step", type=float, default=0.03)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--cpu-windows", type=int, default=2)
     ap.add_argument("--check-windows", type=int, default=4, help="windows re-decoded in f32 mode for the self-check")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -322,7 +322,7 @@ def main(argv=None, backend=make_backend):
         torch.distributed.all_gather_object(ranks, me)
 
     roofline = None
-    if on_gpu and not args.no_roofline and args.dtype == "bf16":
+    if on_gpu and not args.no_roofline and args.dtype != "f32":
         roofline = roofline_leg(args, lib, step, W, world, windows_per_s, enc_f + ckv_f + dec_f)
 
     check = None
@@ -392,7 +392,7 @@ def roofline_leg(args, lib, step, W, world, windows_per_s, flops_window):
     if not n.value:
         return None
     achieved = fl.value / (ms.value * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_bf16_pp_kernel<*> (256x256 ping-pong tiles; + the 128x128 persistent kernel for narrow problems)",
+    return {"bound": "mfma", "kernel": "gemm_h16_pp_kernel<*> (256x256 ping-pong MFMA tiles; + the 128x128 persistent kernel for narrow problems)",
             "achieved": achieved, "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / (MFMA_PEAK_BF16 / 1e12),
             "traffic": traffic, "traffic_note": traffic_note, "launches_per_step": int(n.value),
             "avg_launch_us": ms.value * 1e3 / n.value, "flops_per_step": fl.value,
@@ -411,7 +411,7 @@ def self_check(args, eng, step, main_in, hashes, W):
     n = max(1, min(args.check_windows, W))
     out = {"deterministic": len(hashes) == 1, "tokens_sha256": sorted(hashes)[0][:16], "subset_windows": n}
     ok = out["deterministic"]
-    if args.dtype == "bf16":
+    if args.dtype != "f32":
         toks, lens, logits = step(want_logits=True)
         nb = args.beams
         got = logits[: n * nb].float().cpu()

@@ -37,7 +37,11 @@ typedef enum {
   WSEG_ERR_NO_DEVICE = -4   /* no gfx950 device visible */
 } wseg_status;
 
-typedef enum { WSEG_F32 = 0, WSEG_BF16 = 1 } wseg_dtype;
+typedef enum {
+  WSEG_F32 = 0,             /* exact-parity mode: fp32 storage, VALU GEMM with fmaf chains in k order */
+  WSEG_BF16 = 1,            /* bfloat16 storage + MFMA, fp32 accumulation */
+  WSEG_F16 = 2              /* IEEE half storage + MFMA, fp32 accumulation (reference WhisperSegmenterFast: CT2 float16, model.py:691) */
+} wseg_dtype;
 
 int wseg_abi_version(void);
 const char* wseg_last_error(void);

@@ -27,7 +27,7 @@ def make(cfg, dtype, seed=1):
     from whisperseg_amd.engine import Engine
     rc = R.RefConfig.from_hf_dict(cfg)
     sd = R.random_state_dict(rc, seed=seed)
-    if dtype == "bf16":
+    if dtype in ("bf16", "f16"):      # bf16-representable weights are exact in f16 too
         sd = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
     eng = Engine.from_state_dict(sd, cfg, "cuda:0", dtype)
     return rc, sd, eng
@@ -38,7 +38,7 @@ def feats(n, seed=0):
     return torch.randn(n, 80, 1000, generator=g) * 0.5
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 5e-4), ("bf16", 6e-2)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 5e-4), ("bf16", 6e-2), ("f16", 1e-2)])
 @pytest.mark.parametrize("n", [1, 3])
 def test_encoder_matches_oracle(gpu_lib, dtype, tol, n):
     cfg = hf_cfg()
@@ -51,7 +51,7 @@ def test_encoder_matches_oracle(gpu_lib, dtype, tol, n):
     assert err <= tol * max(1.0, want.abs().max().item()), err
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 5e-4), ("bf16", 8e-2)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 5e-4), ("bf16", 8e-2), ("f16", 1.5e-2)])
 def test_encoder_wider_geometry(gpu_lib, dtype, tol):
     """d=256 / 4 heads / ffn 1024: exercises multi-tile N and more than two heads."""
     cfg = hf_cfg(d=256, heads=4, layers=2, ffn=1024)

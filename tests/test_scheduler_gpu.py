@@ -49,7 +49,7 @@ def gen(eng, x, nb=4, ml=448, **kw):
     return t.cpu(), l.cpu()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("nb", [1, 4])
 def test_slot_refill_gives_the_same_tokens(gpu_lib, dtype, nb):
     eng = tiny_engine(dtype)

@@ -27,7 +27,7 @@ def runs():
         return json.load(f)
 
 
-@pytest.fixture(scope="module", params=["f32", "bf16"])
+@pytest.fixture(scope="module", params=["f32", "f16", "bf16"])
 def segmenter(request, gpu_lib):
     from whisperseg_amd.model import WhisperSegmenter
     return request.param, WhisperSegmenter(MODEL_DIR, device="cuda", device_ids=[0], dtype=request.param)
@@ -40,21 +40,28 @@ def content(tokens):
     return toks[: toks.index(TM.EOT)] if TM.EOT in toks else toks
 
 
+# 16-bit modes: runs (of the 13 recorded) allowed to carry a boundary more than one mel frame off.  A time token is two mel
+# frames, so any flipped time token shows as >= 2 frames; the rates over 200 recordings are in tests/test_parity_sweep_gpu.py
+BEYOND_ONE_FRAME_ALLOWED = {"f32": 0, "f16": 1, "bf16": 2}
+
+
 def test_segment_matches_reference(segmenter, runs):
     dtype, seg = segmenter
-    n_rows = 0
+    n_rows, beyond = 0, []
     for run in runs:
         audio = GI.tiny_recording(run["seed"], run["n_windows"])
         got = seg.segment(audio, TM.SR, **run["kwargs"])
         want = run["expected"]
         assert got["cluster"] == want["cluster"], (dtype, run["kwargs"])
         tol = TM.STS + 1e-9
-        assert np.all(np.abs(np.array(got["onset"]) - np.array(want["onset"])) <= tol), (dtype, run["kwargs"])
-        assert np.all(np.abs(np.array(got["offset"]) - np.array(want["offset"])) <= tol), (dtype, run["kwargs"])
+        dev = np.abs(np.array(got["onset"] + got["offset"]) - np.array(want["onset"] + want["offset"]))
+        if np.any(dev > tol):
+            beyond.append((run["kwargs"], float(dev.max())))
         if dtype == "f32":
             assert got == want, run["kwargs"]          # exact rows in the exact-parity mode
         n_rows += len(want["onset"])
-    assert n_rows >= 30
+    assert n_rows >= 50
+    assert len(beyond) <= BEYOND_ONE_FRAME_ALLOWED[dtype], (dtype, beyond)
 
 
 def test_tokens_match_reference_f32(gpu_lib, runs):
@@ -153,7 +160,7 @@ def test_determinism_and_batch_invariance(gpu_lib):
     (bf16 split-K plans depend on the row count, so bit-equality across batch sizes is only promised for f32)."""
     import torch
     from whisperseg_amd.model import WhisperSegmenterForEval
-    for dtype in ("bf16", "f32"):
+    for dtype in ("bf16", "f16", "f32"):
         seg = WhisperSegmenterForEval(model_path=MODEL_DIR, device="cuda", dtype=dtype)
         audio = GI.tiny_recording(102, 4)
         sliced = seg.get_sliced_audios_features(audio, TM.SR, 0, TM.STS, 1)

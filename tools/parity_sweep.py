@@ -72,7 +72,7 @@ def main():
     with open(os.path.join(ROOT, "tests", "golden", "tiny_sweep.json")) as f:
         sweep = json.load(f)
     res = {}
-    modes = [m for m in sys.argv[2:]] or ["f32", "bf16"]
+    modes = [m for m in sys.argv[2:]] or ["f32", "f16", "bf16"]
     segs = {}
     for dtype in modes:
         if "+" in dtype:       # "enc:f32+dec:bf16"

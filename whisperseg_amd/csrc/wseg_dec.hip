@@ -66,29 +66,20 @@ __global__ __launch_bounds__(256) void embed_kernel(DecodeState st, const T* __r
 // ------------------------------------------------------------------------------------------------
 // streaming variant: cross-attention K/V (82 MB per window per step) are read exactly once per step by one workgroup, far more
 // than L2 + Infinity Cache hold, so the loads are marked non-temporal.
-template <typename T> __device__ __forceinline__ void load8_nt(const T* p, float v[8]);
+template <typename T> __device__ __forceinline__ void load8_nt(const T* p, float v[8]) {      // 16-bit element types
+  typedef unsigned int nt_u4 __attribute__((ext_vector_type(4)));
+  const nt_u4 t = __builtin_nontemporal_load((const nt_u4*)p);
+  unpack8<T>(make_uint4(t[0], t[1], t[2], t[3]), v);
+}
 template <> __device__ __forceinline__ void load8_nt<float>(const float* p, float v[8]) {
   typedef float nt_f4 __attribute__((ext_vector_type(4)));
   const nt_f4 a = __builtin_nontemporal_load((const nt_f4*)p), b = __builtin_nontemporal_load((const nt_f4*)p + 1);
   v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
 }
-template <> __device__ __forceinline__ void load8_nt<bf16_t>(const bf16_t* p, float v[8]) {
-  typedef unsigned int nt_u4 __attribute__((ext_vector_type(4)));
-  const nt_u4 t = __builtin_nontemporal_load((const nt_u4*)p);
-  const uint32_t w[4] = {t[0], t[1], t[2], t[3]};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
-}
-template <typename T> __device__ __forceinline__ void load8(const T* p, float v[8]);
+template <typename T> __device__ __forceinline__ void load8(const T* p, float v[8]) { unpack8<T>(*(const uint4*)p, v); }
 template <> __device__ __forceinline__ void load8<float>(const float* p, float v[8]) {
   const float4 a = ((const float4*)p)[0], b = ((const float4*)p)[1];
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
-template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float v[8]) {
-  const uint4 t = *(const uint4*)p;
-  const uint32_t w[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
 }
 
 // sum_z part[z][row][col .. col+8) + bias[col .. col+8)   (fixed order z = 0, 1, ...: deterministic)
@@ -123,16 +114,10 @@ __device__ __forceinline__ void reduce8(const PartialInfo& pi, int row, int col,
   }
 }
 
-template <typename T> __device__ __forceinline__ void store8(T* p, const float v[8]);
+template <typename T> __device__ __forceinline__ void store8(T* p, const float v[8]) { *(uint4*)p = pack8<T>(v); }
 template <> __device__ __forceinline__ void store8<float>(float* p, const float v[8]) {
   ((float4*)p)[0] = make_float4(v[0], v[1], v[2], v[3]);
   ((float4*)p)[1] = make_float4(v[4], v[5], v[6], v[7]);
-}
-template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float v[8]) {
-  uint32_t w[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) w[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
-  *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // Sum over the 8 lanes that share a K/V row (lanes 8k .. 8k+7), result in all of them, with DPP adds (no LDS traffic:
@@ -390,11 +375,11 @@ __global__ __launch_bounds__(256, 5) void dec_cross_attn_kernel(DecodeState st, 
 // (v_dot2c_f32_bf16 scores are 8 instructions per row shorter still, but sum in another order — one boundary of the
 // tiny-model parity test moved by two mel frames — so the FMA chain stays.)
 // ------------------------------------------------------------------------------------------------
-template <int NB>
-__global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState st, const bf16_t* __restrict__ q,
-                                                                   const bf16_t* __restrict__ ck, const bf16_t* __restrict__ cv,
-                                                                   bf16_t* __restrict__ out, int H, int Tk, int d, PartialInfo pi,
-                                                                   const bf16_t* __restrict__ q_bias, float scale) {
+template <typename HT, int NB>
+__global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState st, const HT* __restrict__ q,
+                                                                   const HT* __restrict__ ck, const HT* __restrict__ cv,
+                                                                   HT* __restrict__ out, int H, int Tk, int d, PartialInfo pi,
+                                                                   const HT* __restrict__ q_bias, float scale) {
   typedef unsigned int raw16 __attribute__((ext_vector_type(4)));
   typedef float f2 __attribute__((ext_vector_type(2)));
   constexpr int U = 8;                                  // K/V rows in flight per lane
@@ -406,8 +391,8 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
   if (st.done[w]) return;                              // idle slot: its 128 KiB of K/V are not streamed
   const int nb = st.nb;
   const int sub = lane & 7, rowl = lane >> 3;
-  const bf16_t* Kb = ck + ((size_t)w * H + h) * Tk * 64;
-  const bf16_t* Vb = cv + ((size_t)w * H + h) * Tk * 64;
+  const HT* Kb = ck + ((size_t)w * H + h) * Tk * 64;
+  const HT* Vb = cv + ((size_t)w * H + h) * Tk * 64;
   // this lane's 8-dim slice of every beam's (pre-scaled) query, fp32, beams paired for v_pk_fma_f32: qq[e][j2] holds
   // dim e of beams 2*j2 and 2*j2+1
   constexpr int NP = (NB + 1) / 2;
@@ -417,11 +402,11 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       if (pi.part != nullptr) {
-        reduce8<bf16_t>(pi, w * nb + min(j, nb - 1), h * 64 + sub * 8, q_bias, qv);
+        reduce8<HT>(pi, w * nb + min(j, nb - 1), h * 64 + sub * 8, q_bias, qv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) qv[e] = El<bf16_t>::rnd(qv[e] * scale);
+        for (int e = 0; e < 8; ++e) qv[e] = El<HT>::rnd(qv[e] * scale);
       } else {
-        load8<bf16_t>(q + (size_t)(w * nb + min(j, nb - 1)) * d + h * 64 + sub * 8, qv);
+        load8<HT>(q + (size_t)(w * nb + min(j, nb - 1)) * d + h * 64 + sub * 8, qv);
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) qq[e][j >> 1][j & 1] = qv[e];
@@ -444,7 +429,7 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
       // scores: the fp32 FMA chain over the 8 dims of the kernel above (bit-equal), two beams per v_pk_fma_f32
       float kv[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { kv[2 * e] = __uint_as_float(kr[u][e] << 16); kv[2 * e + 1] = __uint_as_float(kr[u][e] & 0xffff0000u); }
+      for (int e = 0; e < 4; ++e) { kv[2 * e] = H16<HT>::lo(kr[u][e]); kv[2 * e + 1] = H16<HT>::hi(kr[u][e]); }
       f2 a2[NP];
 #pragma unroll
       for (int j2 = 0; j2 < NP; ++j2) a2[j2] = (f2){0.f, 0.f};
@@ -503,7 +488,7 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
       const int tc = ok ? t : Tk - 1;
       f2 vv[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) vv[e] = (f2){__uint_as_float(vr[u][e] << 16), __uint_as_float(vr[u][e] & 0xffff0000u)};
+      for (int e = 0; e < 4; ++e) vv[e] = (f2){H16<HT>::lo(vr[u][e]), H16<HT>::hi(vr[u][e])};
       // probabilities of this row through opaque ds_reads: as C++ loads the compiler gathers all U x NB of them in front
       // of the loop and spills the rows that are in flight (reading the next row's ahead of time costs more registers
       // than it hides: measured slower).  Early-clobber outputs: a result register must not be the address register —
@@ -540,7 +525,7 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
   for (int i = tid; i < nb * 64; i += 256) {
     const int j = i >> 6, e = i & 63;
     const float o = ((red[0][j][e] + red[1][j][e]) + red[2][j][e]) + red[3][j][e];
-    El<bf16_t>::st(out + (size_t)(w * nb + j) * d + h * 64 + e, o * sinv[j]);
+    El<HT>::st(out + (size_t)(w * nb + j) * d + h * 64 + e, o * sinv[j]);
   }
 }
 
@@ -872,6 +857,7 @@ int launch_build_suppress_mask(unsigned char* mask, int V, const int* sup, int n
 int launch_embed(int dtype, const DecodeState& st, const void* tok_emb, const void* pos_emb, void* x, int d, hipStream_t s) {
   const int R = st.W * st.nb;
   if (dtype == WSEG_BF16) hipLaunchKernelGGL((embed_kernel<bf16_t>), dim3(R), dim3(256), 0, s, st, (const bf16_t*)tok_emb, (const bf16_t*)pos_emb, (bf16_t*)x, d);
+  else if (dtype == WSEG_F16) hipLaunchKernelGGL((embed_kernel<f16_t>), dim3(R), dim3(256), 0, s, st, (const f16_t*)tok_emb, (const f16_t*)pos_emb, (f16_t*)x, d);
   else hipLaunchKernelGGL((embed_kernel<float>), dim3(R), dim3(256), 0, s, st, (const float*)tok_emb, (const float*)pos_emb, (float*)x, d);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
@@ -883,6 +869,7 @@ int launch_dec_self_attn(int dtype, const DecodeState& st, const void* q, void* 
   PartialInfo pi;
   if (qkv_part) pi = *qkv_part;
   if (dtype == WSEG_BF16) hipLaunchKernelGGL((dec_self_attn_kernel<bf16_t>), dim3(R * H), dim3(64), 0, s, st, (const bf16_t*)q, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)out, H, d, pi, (const bf16_t*)qkv_bias, scale);
+  else if (dtype == WSEG_F16) hipLaunchKernelGGL((dec_self_attn_kernel<f16_t>), dim3(R * H), dim3(64), 0, s, st, (const f16_t*)q, (f16_t*)kc, (f16_t*)vc, (f16_t*)out, H, d, pi, (const f16_t*)qkv_bias, scale);
   else hipLaunchKernelGGL((dec_self_attn_kernel<float>), dim3(R * H), dim3(64), 0, s, st, (const float*)q, (float*)kc, (float*)vc, (float*)out, H, d, pi, (const float*)qkv_bias, scale);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
@@ -902,13 +889,14 @@ int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const
   PartialInfo pi;
   if (q_part) pi = *q_part;
   static const bool deep = getenv("WSEG_CROSS_NO_PK") == nullptr;         // tuning knob: fp32-FMA kernel
-  if (dtype == WSEG_BF16 && deep && Tk <= 512 && st.nb <= 4) {
+  if (dtype != WSEG_F32 && deep && Tk <= 512 && st.nb <= 4) {
     dim3 grid(st.W * H), block(256);
-    const bf16_t *qb = (const bf16_t*)q, *kb = (const bf16_t*)ck, *vb = (const bf16_t*)cv, *bb = (const bf16_t*)q_bias;
-    if (st.nb <= 1) hipLaunchKernelGGL((dec_cross_attn_pk_kernel<1>), grid, block, 0, s, st, qb, kb, vb, (bf16_t*)out, H, Tk, d, pi, bb, scale);
-    else if (st.nb <= 2) hipLaunchKernelGGL((dec_cross_attn_pk_kernel<2>), grid, block, 0, s, st, qb, kb, vb, (bf16_t*)out, H, Tk, d, pi, bb, scale);
-    else hipLaunchKernelGGL((dec_cross_attn_pk_kernel<4>), grid, block, 0, s, st, qb, kb, vb, (bf16_t*)out, H, Tk, d, pi, bb, scale);
+#define WSEG_PK(HT_, NB_) hipLaunchKernelGGL((dec_cross_attn_pk_kernel<HT_, NB_>), grid, block, 0, s, st, (const HT_*)q, (const HT_*)ck, (const HT_*)cv, (HT_*)out, H, Tk, d, pi, (const HT_*)q_bias, scale)
+    if (dtype == WSEG_BF16) { if (st.nb <= 1) WSEG_PK(bf16_t, 1); else if (st.nb <= 2) WSEG_PK(bf16_t, 2); else WSEG_PK(bf16_t, 4); }
+    else { if (st.nb <= 1) WSEG_PK(f16_t, 1); else if (st.nb <= 2) WSEG_PK(f16_t, 2); else WSEG_PK(f16_t, 4); }
+#undef WSEG_PK
   } else if (dtype == WSEG_BF16) launch_cross_t<bf16_t>(st, (const bf16_t*)q, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)out, H, Tk, d, pi, (const bf16_t*)q_bias, scale, s);
+  else if (dtype == WSEG_F16) launch_cross_t<f16_t>(st, (const f16_t*)q, (const f16_t*)ck, (const f16_t*)cv, (f16_t*)out, H, Tk, d, pi, (const f16_t*)q_bias, scale, s);
   else launch_cross_t<float>(st, (const float*)q, (const float*)ck, (const float*)cv, (float*)out, H, Tk, d, pi, (const float*)q_bias, scale, s);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;

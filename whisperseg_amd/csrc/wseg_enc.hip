@@ -62,26 +62,15 @@ __global__ __launch_bounds__(256) void im2col_conv2_kernel(const T* __restrict__
 // ------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, 16-byte vector loads, two-pass statistics in registers.
 // ------------------------------------------------------------------------------------------------
-template <typename T> struct VecIO;
+template <typename T> struct VecIO {      // 16-bit element types: 8 per 16-byte access
+  static constexpr int V = 8;
+  static __device__ __forceinline__ void ld(const T* p, float v[8]) { unpack8<T>(*(const uint4*)p, v); }
+  static __device__ __forceinline__ void st(T* p, const float v[8]) { *(uint4*)p = pack8<T>(v); }
+};
 template <> struct VecIO<float> {
   static constexpr int V = 4;
   static __device__ __forceinline__ void ld(const float* p, float v[4]) { const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
   static __device__ __forceinline__ void st(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
-};
-template <> struct VecIO<bf16_t> {
-  static constexpr int V = 8;
-  static __device__ __forceinline__ void ld(const bf16_t* p, float v[8]) {
-    const uint4 t = *(const uint4*)p;
-    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
-  }
-  static __device__ __forceinline__ void st(bf16_t* p, const float v[8]) {
-    uint32_t w[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
-    *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
-  }
 };
 
 template <typename T, int NIT>
@@ -133,23 +122,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 // ------------------------------------------------------------------------------------------------
 // Encoder attention, bf16 MFMA.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return pack_bf16x2(a, b); }
-
-__global__ __launch_bounds__(256) void enc_attention_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                                 const bf16_t* __restrict__ Vt, bf16_t* __restrict__ out,
+template <typename HT>
+__global__ __launch_bounds__(256) void enc_attention_h16_kernel(const HT* __restrict__ Q, const HT* __restrict__ K,
+                                                                const HT* __restrict__ Vt, HT* __restrict__ out,
                                                                  int H, int T, int Tp, int d) {
   // [key][64 hd], 16-B slots XOR ((key >> 1) & 7): a 32-row MFMA fragment read (lane = row + 32*half) is serviced in the
   // lane groups {0-3,12-15,20-27}, ... and needs 16 distinct (row & 1, slot) pairs per group — XOR (key & 7), right for
   // 16-row fragments, was 2-way conflicted here (SQ_LDS_BANK_CONFLICT 44 % of LDS cycles)
-  __shared__ __attribute__((aligned(16))) bf16_t sK[64 * 64];
-  __shared__ __attribute__((aligned(16))) bf16_t sV[64 * 64];   // [hd][64 keys], 8-B granules XOR ((hd >> 1) & 15)
+  __shared__ __attribute__((aligned(16))) HT sK[64 * 64];
+  __shared__ __attribute__((aligned(16))) HT sV[64 * 64];   // [hd][64 keys], 8-B granules XOR ((hd >> 1) & 15)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const int qi = lane & 31, g2 = lane >> 5;
-  const bf16_t* Qb = Q + (size_t)bh * Tp * 64;
-  const bf16_t* Kb = K + (size_t)bh * Tp * 64;
-  const bf16_t* Vb = Vt + (size_t)bh * 64 * Tp;
+  const HT* Qb = Q + (size_t)bh * Tp * 64;
+  const HT* Kb = K + (size_t)bh * Tp * 64;
+  const HT* Vb = Vt + (size_t)bh * 64 * Tp;
 
   bf16x8 qf[4];
 #pragma unroll
@@ -197,7 +185,7 @@ __global__ __launch_bounds__(256) void enc_attention_bf16_kernel(const bf16_t* _
 #pragma unroll
       for (int hs = 0; hs < 4; ++hs) {
         const bf16x8 kf = *(const bf16x8*)(sK + krow * 64 + (((hs * 2 + g2) ^ ((krow >> 1) & 7)) << 3));
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[hs], s, 0, 0, 0);
+        s = H16<HT>::mfma32(kf, qf[hs], s);
       }
       if (key_base + 32 > T) {
 #pragma unroll
@@ -228,7 +216,7 @@ __global__ __launch_bounds__(256) void enc_attention_bf16_kernel(const bf16_t* _
       for (int mm = 0; mm < 2; ++mm) {
         union { bf16x8 v; uint32_t u[4]; } pf;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pf.u[j] = pack_bf16(s[8 * mm + 2 * j], s[8 * mm + 2 * j + 1]);
+        for (int j = 0; j < 4; ++j) pf.u[j] = H16<HT>::pack(s[8 * mm + 2 * j], s[8 * mm + 2 * j + 1]);
         const int gran = sub * 8 + 4 * mm + g2;
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht) {
@@ -236,8 +224,8 @@ __global__ __launch_bounds__(256) void enc_attention_bf16_kernel(const bf16_t* _
           union { bf16x8 v; uint2 u[2]; } vf;
           vf.u[0] = *(const uint2*)(sV + hd * 64 + ((gran ^ sw) << 2));
           vf.u[1] = *(const uint2*)(sV + hd * 64 + (((gran + 2) ^ sw) << 2));
-          if (ht == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o0, 0, 0, 0);
-          else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o1, 0, 0, 0);
+          if (ht == 0) o0 = H16<HT>::mfma32(vf.v, pf.v, o0);
+          else o1 = H16<HT>::mfma32(vf.v, pf.v, o1);
         }
       }
     }
@@ -245,7 +233,7 @@ __global__ __launch_bounds__(256) void enc_attention_bf16_kernel(const bf16_t* _
   const int q = q0 + qi;
   if (q < T) {
     const float inv = 1.0f / l_run;
-    bf16_t* orow = out + ((size_t)b * T + q) * d + h * 64;
+    HT* orow = out + ((size_t)b * T + q) * d + h * 64;
 #pragma unroll
     for (int ht = 0; ht < 2; ++ht) {
 #pragma unroll
@@ -253,8 +241,8 @@ __global__ __launch_bounds__(256) void enc_attention_bf16_kernel(const bf16_t* _
         const int hd = ht * 32 + 8 * rg + 4 * g2;
         const f32x16& o = ht == 0 ? o0 : o1;
         uint2 pk;
-        pk.x = pack_bf16(o[4 * rg + 0] * inv, o[4 * rg + 1] * inv);
-        pk.y = pack_bf16(o[4 * rg + 2] * inv, o[4 * rg + 3] * inv);
+        pk.x = H16<HT>::pack(o[4 * rg + 0] * inv, o[4 * rg + 1] * inv);
+        pk.y = H16<HT>::pack(o[4 * rg + 2] * inv, o[4 * rg + 3] * inv);
         *(uint2*)(orow + hd) = pk;
       }
     }
@@ -306,16 +294,17 @@ int launch_im2col_conv1(int dtype, const float* feats, void* a1, int B, int n_me
   if (n_mels > 96 || 3 * n_mels > kp) { set_error("im2col_conv1: n_mels %d unsupported", n_mels); return WSEG_ERR_INVALID; }
   dim3 grid(cdiv(cols, 32), B);
   if (dtype == WSEG_BF16) hipLaunchKernelGGL((im2col_conv1_kernel<bf16_t>), grid, dim3(256), 0, s, feats, (bf16_t*)a1, n_mels, cols, kp);
+  else if (dtype == WSEG_F16) hipLaunchKernelGGL((im2col_conv1_kernel<f16_t>), grid, dim3(256), 0, s, feats, (f16_t*)a1, n_mels, cols, kp);
   else hipLaunchKernelGGL((im2col_conv1_kernel<float>), grid, dim3(256), 0, s, feats, (float*)a1, n_mels, cols, kp);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
 
 int launch_im2col_conv2(int dtype, const void* h1, void* a2, int B, int cols, int d, hipStream_t s) {
-  const size_t vec = dtype == WSEG_BF16 ? 8 : 4;
+  const size_t vec = dtype == WSEG_F32 ? 4 : 8;
   const size_t total = (size_t)B * (cols / 2) * 3 * (d / vec);
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  if (dtype == WSEG_BF16) hipLaunchKernelGGL((im2col_conv2_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)h1, (bf16_t*)a2, B, cols, d);
+  if (dtype != WSEG_F32) hipLaunchKernelGGL((im2col_conv2_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)h1, (bf16_t*)a2, B, cols, d);   // a pure 16-byte copy
   else hipLaunchKernelGGL((im2col_conv2_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)h1, (float*)a2, B, cols, d);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
@@ -324,11 +313,13 @@ int launch_im2col_conv2(int dtype, const void* h1, void* a2, int B, int cols, in
 int launch_layernorm(int dtype, const void* x, const void* g, const void* b, void* y, int M, int d, hipStream_t s) {
   if (M <= 0) return WSEG_OK;
   dim3 grid(cdiv(M, 4));
-  if (dtype == WSEG_BF16) {
+  if (dtype != WSEG_F32) {
     if (d % 8 || d > 64 * 8 * 4) { set_error("layernorm: d %d unsupported", d); return WSEG_ERR_INVALID; }
-    if (d <= 512) hipLaunchKernelGGL((layernorm_kernel<bf16_t, 1>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)g, (const bf16_t*)b, (bf16_t*)y, M, d);
-    else if (d <= 1024) hipLaunchKernelGGL((layernorm_kernel<bf16_t, 2>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)g, (const bf16_t*)b, (bf16_t*)y, M, d);
-    else hipLaunchKernelGGL((layernorm_kernel<bf16_t, 4>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)g, (const bf16_t*)b, (bf16_t*)y, M, d);
+#define WSEG_LN(HT_, NIT_) hipLaunchKernelGGL((layernorm_kernel<HT_, NIT_>), grid, dim3(256), 0, s, (const HT_*)x, (const HT_*)g, (const HT_*)b, (HT_*)y, M, d)
+    const int nit = d <= 512 ? 1 : (d <= 1024 ? 2 : 4);
+    if (dtype == WSEG_BF16) { if (nit == 1) WSEG_LN(bf16_t, 1); else if (nit == 2) WSEG_LN(bf16_t, 2); else WSEG_LN(bf16_t, 4); }
+    else { if (nit == 1) WSEG_LN(f16_t, 1); else if (nit == 2) WSEG_LN(f16_t, 2); else WSEG_LN(f16_t, 4); }
+#undef WSEG_LN
   } else {
     if (d % 4 || d > 64 * 4 * 8) { set_error("layernorm: d %d unsupported", d); return WSEG_ERR_INVALID; }
     if (d <= 512) hipLaunchKernelGGL((layernorm_kernel<float, 2>), grid, dim3(256), 0, s, (const float*)x, (const float*)g, (const float*)b, (float*)y, M, d);
@@ -340,10 +331,11 @@ int launch_layernorm(int dtype, const void* x, const void* g, const void* b, voi
 
 int launch_enc_attention(int dtype, const void* q, const void* k, const void* vt, void* out,
                          int B, int H, int T, int Tp, int d, hipStream_t s) {
-  if (dtype == WSEG_BF16) {
+  if (dtype != WSEG_F32) {
     if (Tp % 128) { set_error("enc_attention: Tp %d %% 128", Tp); return WSEG_ERR_INVALID; }
     dim3 grid(cdiv(T, 128), B * H);
-    hipLaunchKernelGGL(enc_attention_bf16_kernel, grid, dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, T, Tp, d);
+    if (dtype == WSEG_BF16) hipLaunchKernelGGL(enc_attention_h16_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, T, Tp, d);
+    else hipLaunchKernelGGL(enc_attention_h16_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)q, (const f16_t*)k, (const f16_t*)vt, (f16_t*)out, H, T, Tp, d);
   } else {
     dim3 grid(cdiv(T, 64), B * H);
     hipLaunchKernelGGL(enc_attention_f32_kernel, grid, dim3(64), 0, s, (const float*)q, (const float*)k, (const float*)vt, (float*)out, H, T, Tp, d);

@@ -21,25 +21,24 @@ namespace wseg {
 // ------------------------------------------------------------------------------------------------
 // Epilogue: 4 consecutive columns n0..n0+3 of row m.
 // ------------------------------------------------------------------------------------------------
-template <typename T> struct Vec4;
+template <typename T> struct Vec4 {      // 16-bit element types
+  static __device__ __forceinline__ void ld(const T* p, float v[4]) {
+    const uint2 t = *(const uint2*)p;
+    v[0] = H16<T>::lo(t.x); v[1] = H16<T>::hi(t.x);
+    v[2] = H16<T>::lo(t.y); v[3] = H16<T>::hi(t.y);
+  }
+  static __device__ __forceinline__ void st(T* p, const float v[4]) {
+    uint2 t;
+    t.x = H16<T>::pack(v[0], v[1]);
+    t.y = H16<T>::pack(v[2], v[3]);
+    *(uint2*)p = t;
+  }
+};
 template <> struct Vec4<float> {
   static __device__ __forceinline__ void ld(const float* p, float v[4]) {
     const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
   }
   static __device__ __forceinline__ void st(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
-};
-template <> struct Vec4<bf16_t> {
-  static __device__ __forceinline__ void ld(const bf16_t* p, float v[4]) {
-    const uint2 t = *(const uint2*)p;
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
-  }
-  static __device__ __forceinline__ void st(bf16_t* p, const float v[4]) {
-    uint2 t;
-    t.x = pack_bf16x2(v[0], v[1]);
-    t.y = pack_bf16x2(v[2], v[3]);
-    *(uint2*)p = t;
-  }
 };
 
 template <int EPI, typename T>
@@ -109,47 +108,37 @@ __device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, fl
   }
 }
 
-// 8 consecutive columns n0..n0+7 of row m (bf16 path, LDS-staged epilogue): 16-byte loads / stores.
-__device__ __forceinline__ void ld8_bf16(const bf16_t* p, float v[8]) {
-  const uint4 t = *(const uint4*)p;
-  const uint32_t w[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
-}
-__device__ __forceinline__ void st8_bf16(bf16_t* p, const float v[8]) {
-  uint32_t w[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) w[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
-  *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
-}
+// 8 consecutive columns n0..n0+7 of row m (16-bit paths, LDS-staged epilogue): 16-byte loads / stores.
+template <typename HT> __device__ __forceinline__ void ld8_h(const HT* p, float v[8]) { unpack8<HT>(*(const uint4*)p, v); }
+template <typename HT> __device__ __forceinline__ void st8_h(HT* p, const float v[8]) { *(uint4*)p = pack8<HT>(v); }
 
-template <int EPI>
+template <int EPI, typename HT>
 __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, float v[8]) {
-  typedef bf16_t T;
+  typedef HT T;
   if (ep.bias) {
     float b[8];
-    ld8_bf16((const T*)ep.bias + n0, b);
+    ld8_h<T>((const T*)ep.bias + n0, b);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] += b[i];
   }
   if constexpr (EPI == EPI_STORE) {
-    st8_bf16((T*)ep.out + (size_t)m * ep.ldc + n0, v);
+    st8_h<T>((T*)ep.out + (size_t)m * ep.ldc + n0, v);
   } else if constexpr (EPI == EPI_GELU) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = gelu_for<T>(v[i]);
-    st8_bf16((T*)ep.out + (size_t)m * ep.ldc + n0, v);
+    st8_h<T>((T*)ep.out + (size_t)m * ep.ldc + n0, v);
   } else if constexpr (EPI == EPI_RESID) {
     float r[8];
-    ld8_bf16((const T*)ep.resid + (size_t)m * ep.ldc + n0, r);
+    ld8_h<T>((const T*)ep.resid + (size_t)m * ep.ldc + n0, r);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = r[i] + v[i];
-    st8_bf16((T*)ep.out + (size_t)m * ep.ldc + n0, v);
+    st8_h<T>((T*)ep.out + (size_t)m * ep.ldc + n0, v);
   } else if constexpr (EPI == EPI_GELU_POS) {
     float p[8];
-    ld8_bf16((const T*)ep.pos + (size_t)(m % ep.pos_rows) * ep.ldc + n0, p);
+    ld8_h<T>((const T*)ep.pos + (size_t)(m % ep.pos_rows) * ep.ldc + n0, p);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = gelu_for<T>(v[i]) + p[i];
-    st8_bf16((T*)ep.out + (size_t)m * ep.ldc + n0, v);
+    st8_h<T>((T*)ep.out + (size_t)m * ep.ldc + n0, v);
   } else if constexpr (EPI == EPI_QKV_ENC) {
     const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
     const int b = m / ep.t_len, t = m - b * ep.t_len;
@@ -157,20 +146,20 @@ __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, f
     if (sec == 0) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] *= ep.scale;
-      st8_bf16((T*)ep.q + (bh * ep.t_pad + t) * 64 + e, v);
+      st8_h<T>((T*)ep.q + (bh * ep.t_pad + t) * 64 + e, v);
     } else if (sec == 1) {
-      st8_bf16((T*)ep.k + (bh * ep.t_pad + t) * 64 + e, v);
+      st8_h<T>((T*)ep.k + (bh * ep.t_pad + t) * 64 + e, v);
     } else {
       T* vt = (T*)ep.v + (bh * 64 + e) * ep.t_pad + t;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) vt[(size_t)i * ep.t_pad] = f2bf(v[i]);
+      for (int i = 0; i < 8; ++i) vt[(size_t)i * ep.t_pad] = H16<T>::from(v[i]);
     }
   } else if constexpr (EPI == EPI_KV_CROSS) {
     const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
     const int b = m / ep.t_len, t = m - b * ep.t_len;
     const int bs = ep.slot_map ? ep.slot_map[b] : b;
     T* dst = (T*)(sec == 0 ? ep.k : ep.v) + (((size_t)bs * ep.n_heads + h) * ep.t_len + t) * 64 + e;
-    st8_bf16(dst, v);
+    st8_h<T>(dst, v);
   } else if constexpr (EPI == EPI_F32) {
     float* o = ep.out_f32 + (size_t)m * ep.ldc + n0;
     *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
@@ -191,9 +180,9 @@ __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, f
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // SPLIT: write fp32 partials [z][m_pad][n] (epilogue applied later by splitk_reduce_kernel).
-template <int BM, int BN, int WM, int WN, int EPI, bool SPLIT, int NST = 2>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const bf16_t* __restrict__ A, int lda,
-                                                        const bf16_t* __restrict__ W, int ldw,
+template <typename HT, int BM, int BN, int WM, int WN, int EPI, bool SPLIT, int NST = 2>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_h16_kernel(const HT* __restrict__ A, int lda,
+                                                        const HT* __restrict__ W, int ldw,
                                                         int M, int N, int k_len, EpiParams ep,
                                                         float* __restrict__ part, int m_pad, int ntm) {
   constexpr int BK = 64;
@@ -203,9 +192,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const bf16_t* _
   constexpr int A_IT = BM * 8 / NT, W_IT = BN * 8 / NT;
   constexpr int NLD = A_IT + W_IT;
   static_assert((WM * WN == 4 || WM * WN == 8) && A_IT >= 1 && W_IT >= 1, "tile config");
-  __shared__ __attribute__((aligned(16))) bf16_t smem[NST * (BM + BN) * BK];
-  bf16_t* sA = smem;                     // [NST][BM*64]
-  bf16_t* sW = smem + NST * BM * BK;     // [NST][BN*64]
+  __shared__ __attribute__((aligned(16))) HT smem[NST * (BM + BN) * BK];
+  HT* sA = smem;                     // [NST][BM*64]
+  HT* sW = smem + NST * BM * BK;     // [NST][BN*64]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -227,8 +216,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const bf16_t* _
   const int nk = k_len / BK;
 
   // per-thread source pointers (swizzle on the source: LDS slot p holds logical 16-B slot (p&7)^(row&7))
-  const bf16_t* a_src[A_IT];
-  const bf16_t* w_src[W_IT];
+  const HT* a_src[A_IT];
+  const HT* w_src[W_IT];
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
     const int p = it * NT + tid, row = p >> 3, sl = (p & 7) ^ (row & 7);
@@ -279,8 +268,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const bf16_t* _
       wait_vmcnt<NLD*(NST - 1)>();
     }
     __builtin_amdgcn_s_barrier();
-    const bf16_t* cA = sA + buf * BM * BK + (wm * TM) * BK;
-    const bf16_t* cW = sW + buf * BN * BK + (wn * TN) * BK;
+    const HT* cA = sA + buf * BM * BK + (wm * TM) * BK;
+    const HT* cW = sW + buf * BN * BK + (wn * TN) * BK;
     // Fragment reads are software-pipelined against the MFMAs: the activation fragments of BOTH k-steps of the tile
     // and the next weight fragment are requested while the current weight fragment is being multiplied, so a wave
     // only stalls on LDS at the head of a tile (the co-resident wave of the SIMD covers that).
@@ -304,7 +293,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const bf16_t* _
         for (int j = 0; j < MI; ++j) af1[j] = lda(1, j);
       }
 #pragma unroll
-      for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur, af0[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < MI; ++j) acc[i][j] = H16<HT>::mfma16(wcur, af0[j], acc[i][j]);
       wcur = wnxt;
     }
 #pragma unroll
@@ -312,7 +301,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const bf16_t* _
       bf16x8 wnxt = wcur;
       if (i + 1 < NI) wnxt = ldw(1, i + 1);
 #pragma unroll
-      for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur, af1[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < MI; ++j) acc[i][j] = H16<HT>::mfma16(wcur, af1[j], acc[i][j]);
       wcur = wnxt;
     }
     __builtin_amdgcn_s_barrier();
@@ -338,7 +327,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const bf16_t* _
         const float4 a = *(const float4*)(strip + r * LDT + cc), b = *(const float4*)(strip + r * LDT + cc + 4);
         float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
         const int m = m0 + wm * TM + j * 16 + r;
-        if (m < M) epi_apply8<EPI>(ep, m, n0 + wn * TN + cc, v);
+        if (m < M) epi_apply8<EPI, HT>(ep, m, n0 + wn * TN + cc, v);
       }
     }
   } else {
@@ -352,7 +341,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const bf16_t* _
         if constexpr (SPLIT) {
           *(float4*)(part + ((size_t)blockIdx.z * m_pad + m) * N + n) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-          if (m < M) epi_apply<EPI, bf16_t>(ep, m, n, v);
+          if (m < M) epi_apply<EPI, HT>(ep, m, n, v);
         }
       }
     }
@@ -366,7 +355,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const bf16_t* _
 // gfx9, so a load issued after a store cannot be consumed before that store has completed — a bias load per
 // output row made each of the 16 stores a full round trip (measured 16-42 % of a launch).
 // ------------------------------------------------------------------------------------------------
-template <int EPI, int MI, int NI>
+template <typename HT, int EPI, int MI, int NI>
 __device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NI][MI], float* stage, const EpiParams& ep, int M, int mb,
                                                 int nb, int lane, int wave) {
   static_assert(NI == 4, "64-column wave tiles");
@@ -375,7 +364,7 @@ __device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NI][MI], floa
   const int fr = lane & 15, fg = lane >> 4, rr = lane >> 3, cc = (lane & 7) * 8;
   const int nc = nb + cc;
   float bv[8];
-  if (ep.bias) ld8_bf16((const bf16_t*)ep.bias + nc, bv);
+  if (ep.bias) ld8_h<HT>((const HT*)ep.bias + nc, bv);
   else {
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = 0.f;
@@ -385,7 +374,7 @@ __device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NI][MI], floa
 #pragma unroll
     for (int t = 0; t < MI * 2; ++t) {
       const int m = min(mb + t * 8 + rr, M - 1);
-      rraw[t] = *(const uint4*)((const bf16_t*)ep.resid + (size_t)m * ep.ldc + nc);
+      rraw[t] = *(const uint4*)((const HT*)ep.resid + (size_t)m * ep.ldc + nc);
     }
   }
   EpiParams ep2 = ep;
@@ -419,16 +408,16 @@ __device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NI][MI], floa
         const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[2 * e] = __uint_as_float(w4[e] << 16) + v[2 * e];
-          v[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u) + v[2 * e + 1];
+          v[2 * e] = H16<HT>::lo(w4[e]) + v[2 * e];
+          v[2 * e + 1] = H16<HT>::hi(w4[e]) + v[2 * e + 1];
         }
-        if (m < M) st8_bf16((bf16_t*)ep.out + (size_t)m * ep.ldc + nc, v);
+        if (m < M) st8_h<HT>((HT*)ep.out + (size_t)m * ep.ldc + nc, v);
       } else if constexpr (EPI == EPI_KV_CROSS) {
         int mm = m;
         if (ep.slot_map) { const int b = m / ep.t_len; mm = (b == kv_b0 ? kv_s0 : kv_s1) * ep.t_len + (m - b * ep.t_len); }
-        if (m < M) epi_apply8<EPI>(ep2, mm, nc, v);
+        if (m < M) epi_apply8<EPI, HT>(ep2, mm, nc, v);
       } else {
-        if (m < M) epi_apply8<EPI>(ep2, m, nc, v);
+        if (m < M) epi_apply8<EPI, HT>(ep2, m, nc, v);
       }
     }
   }
@@ -442,9 +431,9 @@ __device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NI][MI], floa
 // Tile order: XCD x (workgroup id % 8, observed dispatch, speed only) owns a contiguous run of the m-fastest /
 // 8-row-group tile order; its workgroups interleave over that run, so tiles in flight on one L2 are neighbours.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_persist_kernel(const bf16_t* __restrict__ A, int lda,
-                                                                         const bf16_t* __restrict__ W, int ldw, int M, int N,
+template <typename HT, int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_h16_persist_kernel(const HT* __restrict__ A, int lda,
+                                                                         const HT* __restrict__ W, int ldw, int M, int N,
                                                                          int K, EpiParams ep, int ntm, int GM) {
   constexpr int BK = 64;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -454,7 +443,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_persist_kernel(const b
   constexpr int NLD = A_IT + W_IT;
   constexpr int STAGE = (BM + BN) * BK;            // elements per LDS stage: [A tile | W tile]
   static_assert(TN == 64, "staged epilogue needs 64-column wave tiles");
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) HT smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -471,8 +460,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_persist_kernel(const b
     m0 = (grp * GM + rem % gm) * BM;
     n0 = (rem / gm) * BN;
   };
-  const bf16_t* a_src[A_IT];
-  const bf16_t* w_src[W_IT];
+  const HT* a_src[A_IT];
+  const HT* w_src[W_IT];
   auto set_src = [&](int m0, int n0) {
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
@@ -486,7 +475,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_persist_kernel(const b
     }
   };
   auto issue = [&](int kt, int buf) {
-    bf16_t* st = smem + buf * STAGE;
+    HT* st = smem + buf * STAGE;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) WSEG_GLDS16(a_src[it] + kt * BK, st + (it * NT + wave * 64) * 8);
 #pragma unroll
@@ -523,8 +512,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_persist_kernel(const b
         wait_vmcnt<0>();
       }
       __builtin_amdgcn_s_barrier();
-      const bf16_t* cA = smem + buf * STAGE + (wm * TM) * BK;
-      const bf16_t* cW = smem + buf * STAGE + BM * BK + (wn * TN) * BK;
+      const HT* cA = smem + buf * STAGE + (wm * TM) * BK;
+      const HT* cW = smem + buf * STAGE + BM * BK + (wn * TN) * BK;
       auto lda_f = [&](int kk, int j) {
         const int rw = j * 16 + fr;
         return *(const bf16x8*)(cA + rw * BK + (((kk * 4 + fg) ^ (rw & 7)) << 3));
@@ -545,7 +534,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_persist_kernel(const b
           for (int j = 0; j < MI; ++j) af1[j] = lda_f(1, j);
         }
 #pragma unroll
-        for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur, af0[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < MI; ++j) acc[i][j] = H16<HT>::mfma16(wcur, af0[j], acc[i][j]);
         wcur = wnxt;
       }
 #pragma unroll
@@ -553,14 +542,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_persist_kernel(const b
         bf16x8 wnxt = wcur;
         if (i + 1 < NI) wnxt = ldw_f(1, i + 1);
 #pragma unroll
-        for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur, af1[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < MI; ++j) acc[i][j] = H16<HT>::mfma16(wcur, af1[j], acc[i][j]);
         wcur = wnxt;
       }
       __builtin_amdgcn_s_barrier();
     }
     g += nk;
     // LDS-staged epilogue in the stage consumed last ((g-1)&1); the other stage is receiving the next tile
-    staged_epilogue<EPI, MI, NI>(acc, (float*)(smem + ((g - 1) & 1) * STAGE), ep, M, m0 + wm * TM, n0 + wn * TN, lane, wave);
+    staged_epilogue<HT, EPI, MI, NI>(acc, (float*)(smem + ((g - 1) & 1) * STAGE), ep, M, m0 + wm * TM, n0 + wn * TN, lane, wave);
     if (!has_next) break;
     __builtin_amdgcn_s_barrier();                   // every wave is done with its strip before the stage is refilled
     m0 = nm0; n0 = nn0; idx = nidx;
@@ -596,13 +585,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_persist_kernel(const b
 // leaves buffer e & 1 to the epilogue as its staging area: the B pair of K tile e+2 is held back to phase 1 of K tile
 // e+1, which both groups reach only after the barrier that closes the (shared) epilogue interval.
 // ------------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
+template <typename HT, int EPI>
+__global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const HT* __restrict__ A, int lda, const HT* __restrict__ W,
                                                           int ldw, int M, int N, int K, EpiParams ep, int ntm, int GM) {
   constexpr int BM = 256, BN = 256, BK = 64, TM = 128, TN = 64, MI = 8, NI = 4;
-  constexpr int HT = 128 * BK;                      // elements per half-tile (16 KB)
-  constexpr int BUF = 4 * HT;                       // elements per K-tile buffer: [A0 | A1 | B0 | B1]
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * BUF];
+  constexpr int HTILE = 128 * BK;                      // elements per half-tile (16 KB)
+  constexpr int BUF = 4 * HTILE;                       // elements per K-tile buffer: [A0 | A1 | B0 | B1]
+  __shared__ __attribute__((aligned(16))) HT smem[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -632,8 +621,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
   tile_coords(start + loc, tm, tn);
   size_t ca_row = (size_t)tm * lda, cb_row = (size_t)tn * ldw;                    // scalar
   auto issue_a = [&](int half) {                       // half-tile A<half> of K tile ca_g; the cursor advances after A1
-    bf16_t* dst = smem + (ca_g & 1) * BUF + half * HT + wave * 512;
-    const bf16_t* src = A + (ca_row + (size_t)(half * 128) * lda + ca_kt * BK) + a_lane;
+    HT* dst = smem + (ca_g & 1) * BUF + half * HTILE + wave * 512;
+    const HT* src = A + (ca_row + (size_t)(half * 128) * lda + ca_kt * BK) + a_lane;
     WSEG_GLDS16(src, dst);
     WSEG_GLDS16(src + (size_t)64 * lda, dst + 4096);
     if (half == 1) {
@@ -649,8 +638,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
     }
   };
   auto issue_b = [&](int half) {
-    bf16_t* dst = smem + (cb_g & 1) * BUF + (2 + half) * HT + wave * 512;
-    const bf16_t* src = W + (cb_row + (size_t)(half * 128) * ldw + cb_kt * BK) + w_lane;
+    HT* dst = smem + (cb_g & 1) * BUF + (2 + half) * HTILE + wave * 512;
+    const HT* src = W + (cb_row + (size_t)(half * 128) * ldw + cb_kt * BK) + w_lane;
     WSEG_GLDS16(src, dst);
     WSEG_GLDS16(src + (size_t)64 * ldw, dst + 4096);
     if (half == 1) {
@@ -675,8 +664,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 
   // fragment addressing: row j*16 + fr of a half-tile, 16-B slot (kk*4 + fg) ^ (fr & 7); kk = 1 is the kk = 0 address ^ 64 B
   const int frag0 = fr * BK + ((fg ^ (fr & 7)) << 3);
-  const int fa0 = wr * HT + frag0, fa1 = fa0 ^ 32;
-  const int fb0 = (2 + (wc >> 1)) * HT + (wc & 1) * 64 * BK + frag0, fb1 = fb0 ^ 32;
+  const int fa0 = wr * HTILE + frag0, fa1 = fa0 ^ 32;
+  const int fb0 = (2 + (wc >> 1)) * HTILE + (wc & 1) * 64 * BK + frag0, fb1 = fb0 ^ 32;
 
 #define WSEG_PP_MFMA(JA, IB)                                                                                          \
   do {                                                                                                                \
@@ -687,7 +676,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                                  \
       _Pragma("unroll") for (int i = 2 * (IB); i < 2 * (IB) + 2; ++i)                                                 \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
-          acc[i][4 * (JA) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[i][kk], afr[j][kk], acc[i][4 * (JA) + j], 0, 0, 0); \
+          acc[i][4 * (JA) + j] = H16<HT>::mfma16(bfr[i][kk], afr[j][kk], acc[i][4 * (JA) + j]); \
     __builtin_amdgcn_s_setprio(0);                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                                \
   } while (0)
@@ -704,7 +693,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
 #pragma nounroll
   for (int kt = 0; kt < nk; ++kt, ++g) {
     const bool first = kt == 0 && g > 0, final = kt == nk - 1;
-    const bf16_t* cur = smem + (g & 1) * BUF;
+    const HT* cur = smem + (g & 1) * BUF;
     bf16x8 afr[4][2], bfr[NI][2];
     // ---- phase 0: b0, a0 -> quadrant (a0, b0) ----
 #pragma unroll
@@ -754,7 +743,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const bf16_t* __restr
   // is prefetched into that buffer before phase 1 of the next K tile, which both groups reach only after the barrier
   // below.  (Requesting group 0's residual rows before its idle interval measured no further gain.)
   if (wr == 0) __builtin_amdgcn_s_barrier();
-  staged_epilogue<EPI, MI, NI>(acc, (float*)(smem + ((g - 1) & 1) * BUF), ep, M, m0 + wr * TM, n0 + wc * TN, lane, wave);
+  staged_epilogue<HT, EPI, MI, NI>(acc, (float*)(smem + ((g - 1) & 1) * BUF), ep, M, m0 + wr * TM, n0 + wc * TN, lane, wave);
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();
   }
@@ -884,9 +873,10 @@ static SkinnyPlan plan_skinny(const GemmArgs& g) {
 }
 
 // fp32 partial sums [splits][m_pad][N] into g.splitk_ws (valid for splits == 1 too)
+template <typename HT>
 static int launch_skinny_partial(const GemmArgs& g, const SkinnyPlan& sp, hipStream_t s) {
-  const bf16_t* A = (const bf16_t*)g.A;
-  const bf16_t* W = (const bf16_t*)g.W;
+  const HT* A = (const HT*)g.A;
+  const HT* W = (const HT*)g.W;
   if (!g.splitk_ws || (size_t)sp.splits * sp.m_pad * g.N * sizeof(float) > g.splitk_ws_bytes) {
     set_error("split-K workspace missing or too small");
     return WSEG_ERR_STATE;
@@ -896,7 +886,7 @@ static int launch_skinny_partial(const GemmArgs& g, const SkinnyPlan& sp, hipStr
   // SLOWER than 3-4 stages at two workgroups per CU, and 2 stages (3-5 workgroups per CU) is another 2-3 % faster at every
   // batch size — these kernels want co-resident workgroups to cover their barriers, not more bytes in flight each.
 #define WSEG_SKINNY_P(BM_, WM_, WN_)                                                                                     \
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM_, 64, WM_, WN_, EPI_STORE, true, 2>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, \
+  hipLaunchKernelGGL((gemm_h16_kernel<HT, BM_, 64, WM_, WN_, EPI_STORE, true, 2>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, \
                      g.N, sp.k_len, g.ep, g.splitk_ws, sp.m_pad, 0)
   if (sp.bm == 32) WSEG_SKINNY_P(32, 1, 4);
   else if (sp.bm == 64) WSEG_SKINNY_P(64, 1, 4);
@@ -910,10 +900,11 @@ static int launch_skinny_partial(const GemmArgs& g, const SkinnyPlan& sp, hipStr
 // One wave per row.  LayerNorm is computed from the ROUNDED x so that the result is bit-identical to running the
 // generic reduction and layernorm_kernel back to back.
 // One workgroup per row, one 8-element chunk per thread (d <= 2048), all split partials loaded up front.
+template <typename HT>
 __global__ __launch_bounds__(256) void splitk_reduce_resid_ln_kernel(const float* __restrict__ part, int splits, int m_pad, int M,
-                                                                     int d, const bf16_t* __restrict__ bias, bf16_t* __restrict__ x,
-                                                                     const bf16_t* __restrict__ gam, const bf16_t* __restrict__ bet,
-                                                                     bf16_t* __restrict__ y) {
+                                                                     int d, const HT* __restrict__ bias, HT* __restrict__ x,
+                                                                     const HT* __restrict__ gam, const HT* __restrict__ bet,
+                                                                     HT* __restrict__ y) {
   __shared__ float s_red[4];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = tid * 8;
@@ -935,11 +926,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_resid_ln_kernel(const float
     uint32_t o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float r0 = __uint_as_float(w[j] << 16), r1 = __uint_as_float(w[j] & 0xffff0000u);
-      const float b0 = __uint_as_float(zb[j] << 16), b1 = __uint_as_float(zb[j] & 0xffff0000u);
-      const bf16_t q0 = f2bf(r0 + (a[2 * j] + b0)), q1 = f2bf(r1 + (a[2 * j + 1] + b1));
-      v[2 * j] = bf2f(q0); v[2 * j + 1] = bf2f(q1);
-      o[j] = (uint32_t)q0 | ((uint32_t)q1 << 16);
+      const float r0 = H16<HT>::lo(w[j]), r1 = H16<HT>::hi(w[j]);
+      const float b0 = H16<HT>::lo(zb[j]), b1 = H16<HT>::hi(zb[j]);
+      const HT q0 = H16<HT>::from(r0 + (a[2 * j] + b0)), q1 = H16<HT>::from(r1 + (a[2 * j + 1] + b1));
+      v[2 * j] = H16<HT>::one(q0); v[2 * j + 1] = H16<HT>::one(q1);
+      o[j] = raw16(q0) | (raw16(q1) << 16);
     }
     *(uint4*)(x + (size_t)row * d + c) = make_uint4(o[0], o[1], o[2], o[3]);
 #pragma unroll
@@ -965,9 +956,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_resid_ln_kernel(const float
     uint32_t o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float y0 = (v[2 * j] - mean) * rstd * __uint_as_float(wg[j] << 16) + __uint_as_float(wb[j] << 16);
-      const float y1 = (v[2 * j + 1] - mean) * rstd * __uint_as_float(wg[j] & 0xffff0000u) + __uint_as_float(wb[j] & 0xffff0000u);
-      o[j] = pack_bf16x2(y0, y1);
+      const float y0 = (v[2 * j] - mean) * rstd * H16<HT>::lo(wg[j]) + H16<HT>::lo(wb[j]);
+      const float y1 = (v[2 * j + 1] - mean) * rstd * H16<HT>::hi(wg[j]) + H16<HT>::hi(wb[j]);
+      o[j] = H16<HT>::pack(y0, y1);
     }
     *(uint4*)(y + (size_t)row * d + c) = make_uint4(o[0], o[1], o[2], o[3]);
   }
@@ -982,10 +973,10 @@ static bool big_tile_path(const GemmArgs& g) {
   return g.M > 128 && g.N % 128 == 0 && (long)cdiv(g.M, 128) * (g.N / 128) >= big_min;
 }
 
-template <int EPI>
-static int launch_bf16(const GemmArgs& g, hipStream_t s) {
-  const bf16_t* A = (const bf16_t*)g.A;
-  const bf16_t* W = (const bf16_t*)g.W;
+template <int EPI, typename HT>
+static int launch_h16(const GemmArgs& g, hipStream_t s) {
+  const HT* A = (const HT*)g.A;
+  const HT* W = (const HT*)g.W;
   if (g.K % 64 || g.N % 64) { set_error("gemm bf16: K %d / N %d not tile multiples", g.K, g.N); return WSEG_ERR_INVALID; }
   if (big_tile_path(g)) {
     static const bool no_swz = getenv("WSEG_NO_XCD_SWIZZLE") != nullptr;
@@ -1008,15 +999,15 @@ static int launch_bf16(const GemmArgs& g, hipStream_t s) {
       if (pingpong && g.K >= 128) {
         int grid = ntiles < n_cu ? ntiles : n_cu;
         grid &= ~7;
-        hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K, g.ep, ntm,
+        hipLaunchKernelGGL((gemm_h16_pp_kernel<HT, EPI>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K, g.ep, ntm,
                            group_m);
       } else if (persist) {
         int grid = ntiles < n_cu ? ntiles : n_cu;
         grid &= ~7;
-        hipLaunchKernelGGL((gemm_bf16_persist_kernel<256, 256, 2, 4, EPI>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
+        hipLaunchKernelGGL((gemm_h16_persist_kernel<HT, 256, 256, 2, 4, EPI>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
                            g.K, g.ep, ntm, group_m);
       } else {
-        hipLaunchKernelGGL((gemm_bf16_kernel<256, 256, 2, 4, EPI, false>), dim3(ntiles), dim3(512), 0, s, A, g.lda, W, g.ldw,
+        hipLaunchKernelGGL((gemm_h16_kernel<HT, 256, 256, 2, 4, EPI, false>), dim3(ntiles), dim3(512), 0, s, A, g.lda, W, g.ldw,
                            g.M, g.N, g.K, g.ep, (float*)nullptr, 0, ntm);
       }
     } else {
@@ -1024,12 +1015,12 @@ static int launch_bf16(const GemmArgs& g, hipStream_t s) {
       if (persist && !no_swz && ntiles >= 16) {
         int grid = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;
         grid &= ~7;
-        hipLaunchKernelGGL((gemm_bf16_persist_kernel<128, 128, 2, 2, EPI>), dim3(grid), dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
+        hipLaunchKernelGGL((gemm_h16_persist_kernel<HT, 128, 128, 2, 2, EPI>), dim3(grid), dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
                            g.K, g.ep, ntm, group_m);
       } else {
         dim3 grid(g.N / 128, ntm, 1);
         if (!no_swz) grid = dim3(ntiles, 1, 1);
-        hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 2, 2, EPI, false>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
+        hipLaunchKernelGGL((gemm_h16_kernel<HT, 128, 128, 2, 2, EPI, false>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
                            g.K, g.ep, (float*)nullptr, 0, no_swz ? 0 : ntm);
       }
     }
@@ -1041,7 +1032,7 @@ static int launch_bf16(const GemmArgs& g, hipStream_t s) {
   if (sp.splits == 1) {
     dim3 grid(g.N / 64, sp.mt, 1);
 #define WSEG_SKINNY(BM_, WM_, WN_)                                                                                      \
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM_, 64, WM_, WN_, EPI, false, 2>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, \
+  hipLaunchKernelGGL((gemm_h16_kernel<HT, BM_, 64, WM_, WN_, EPI, false, 2>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, \
                      g.K, g.ep, (float*)nullptr, sp.m_pad, 0)
     if (sp.bm == 32) WSEG_SKINNY(32, 1, 4);
     else if (sp.bm == 64) WSEG_SKINNY(64, 1, 4);
@@ -1050,9 +1041,9 @@ static int launch_bf16(const GemmArgs& g, hipStream_t s) {
     WSEG_LAUNCH_CHECK();
     return WSEG_OK;
   }
-  WSEG_TRY_(launch_skinny_partial(g, sp, s));
+  WSEG_TRY_(launch_skinny_partial<HT>(g, sp, s));
   const int work = g.M * (g.N / 4);
-  hipLaunchKernelGGL((splitk_reduce_kernel<EPI, bf16_t>), dim3(cdiv(work, 256)), dim3(256), 0, s, g.splitk_ws, sp.splits, sp.m_pad, g.M, g.N, g.ep);
+  hipLaunchKernelGGL((splitk_reduce_kernel<EPI, HT>), dim3(cdiv(work, 256)), dim3(256), 0, s, g.splitk_ws, sp.splits, sp.m_pad, g.M, g.N, g.ep);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
@@ -1068,16 +1059,19 @@ static int launch_f32(const GemmArgs& g, hipStream_t s) {
 
 template <int EPI>
 static int launch_any(int dtype, const GemmArgs& g, hipStream_t s) {
-  return dtype == WSEG_BF16 ? launch_bf16<EPI>(g, s) : launch_f32<EPI>(g, s);
+  if (dtype == WSEG_BF16) return launch_h16<EPI, bf16_t>(g, s);
+  if (dtype == WSEG_F16) return launch_h16<EPI, f16_t>(g, s);
+  return launch_f32<EPI>(g, s);
 }
 
 int launch_gemm_partial(int dtype, const GemmArgs& g, PartialInfo* info, bool* ok, hipStream_t s) {
   *ok = false;
   const bool big = big_tile_path(g);
-  if (dtype != WSEG_BF16 || big || !g.splitk_ws || g.K % 64 || g.N % 64) return WSEG_OK;
+  if (dtype == WSEG_F32 || big || !g.splitk_ws || g.K % 64 || g.N % 64) return WSEG_OK;
   SkinnyPlan sp = plan_skinny(g);
   if ((size_t)sp.splits * sp.m_pad * g.N * sizeof(float) > g.splitk_ws_bytes) return WSEG_OK;
-  WSEG_TRY_(launch_skinny_partial(g, sp, s));
+  if (dtype == WSEG_BF16) WSEG_TRY_(launch_skinny_partial<bf16_t>(g, sp, s));
+  else WSEG_TRY_(launch_skinny_partial<f16_t>(g, sp, s));
   info->part = g.splitk_ws; info->splits = sp.splits; info->m_pad = sp.m_pad; info->n = g.N;
   *ok = true;
   return WSEG_OK;
@@ -1089,13 +1083,19 @@ int launch_gemm_resid_ln(int dtype, const GemmArgs& g0, const void* gamma, const
   GemmArgs g = g0;
   const int d = g.N;
   const bool big = big_tile_path(g);
-  if (dtype == WSEG_BF16 && !big && g.splitk_ws && d % 8 == 0 && d <= 2048 && g.ep.bias && g.ep.resid == g.ep.out && g.ep.ldc == d &&
+  if (dtype != WSEG_F32 && !big && g.splitk_ws && d % 8 == 0 && d <= 2048 && g.ep.bias && g.ep.resid == g.ep.out && g.ep.ldc == d &&
       g.K % 64 == 0 && g.N % 64 == 0) {
     SkinnyPlan sp = plan_skinny(g);
     if ((size_t)sp.splits * sp.m_pad * g.N * sizeof(float) <= g.splitk_ws_bytes) {
-      WSEG_TRY_(launch_skinny_partial(g, sp, s));
-      hipLaunchKernelGGL(splitk_reduce_resid_ln_kernel, dim3(g.M), dim3(256), 0, s, g.splitk_ws, sp.splits, sp.m_pad, g.M, d,
-                         (const bf16_t*)g.ep.bias, (bf16_t*)g.ep.out, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y);
+      if (dtype == WSEG_BF16) {
+        WSEG_TRY_(launch_skinny_partial<bf16_t>(g, sp, s));
+        hipLaunchKernelGGL(splitk_reduce_resid_ln_kernel<bf16_t>, dim3(g.M), dim3(256), 0, s, g.splitk_ws, sp.splits, sp.m_pad, g.M, d,
+                           (const bf16_t*)g.ep.bias, (bf16_t*)g.ep.out, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y);
+      } else {
+        WSEG_TRY_(launch_skinny_partial<f16_t>(g, sp, s));
+        hipLaunchKernelGGL(splitk_reduce_resid_ln_kernel<f16_t>, dim3(g.M), dim3(256), 0, s, g.splitk_ws, sp.splits, sp.m_pad, g.M, d,
+                           (const f16_t*)g.ep.bias, (f16_t*)g.ep.out, (const f16_t*)gamma, (const f16_t*)beta, (f16_t*)y);
+      }
       WSEG_LAUNCH_CHECK();
       return WSEG_OK;
     }

@@ -157,7 +157,7 @@ int check_geometry(const wseg_model_config& c) {
   if (c.spec_cols != 2 * c.enc_positions || c.enc_positions > 512 || c.enc_positions < 128) { set_error("spec_cols %d / enc_positions %d unsupported", c.spec_cols, c.enc_positions); return WSEG_ERR_INVALID; }
   if (c.n_mels <= 0 || c.n_mels > 96) { set_error("n_mels %d unsupported", c.n_mels); return WSEG_ERR_INVALID; }
   if (c.dec_positions <= 0 || c.dec_positions > 512) { set_error("dec_positions %d unsupported", c.dec_positions); return WSEG_ERR_INVALID; }
-  if (c.dtype != WSEG_F32 && c.dtype != WSEG_BF16) { set_error("dtype %d unsupported", c.dtype); return WSEG_ERR_INVALID; }
+  if (c.dtype != WSEG_F32 && c.dtype != WSEG_BF16 && c.dtype != WSEG_F16) { set_error("dtype %d unsupported", c.dtype); return WSEG_ERR_INVALID; }
   if (c.enc_layers <= 0 || c.dec_layers <= 0 || c.vocab <= 0) { set_error("bad layer/vocab counts"); return WSEG_ERR_INVALID; }
   return WSEG_OK;
 }
@@ -288,7 +288,7 @@ extern "C" int wseg_model_create(const wseg_model_config* cfg, wseg_model** out)
   WSEG_TRY(check_geometry(*cfg));
   wseg_model* m = new wseg_model();
   m->cfg = *cfg;
-  m->es = cfg->dtype == WSEG_BF16 ? 2 : 4;
+  m->es = cfg->dtype == WSEG_F32 ? 4 : 2;
   m->kp1 = (int)align_up((size_t)3 * cfg->n_mels, 64);
   m->vp = (int)align_up((size_t)cfg->vocab, 128);
   m->tp = (int)align_up((size_t)cfg->enc_positions, 128);

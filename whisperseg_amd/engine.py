@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 
-DTYPES = {"f32": (0, torch.float32), "bf16": (1, torch.bfloat16)}
+DTYPES = {"f32": (0, torch.float32), "bf16": (1, torch.bfloat16), "f16": (2, torch.float16)}
 
 # generation_config.suppress_tokens of the multilingual Whisper checkpoints WhisperSeg fine-tunes
 # (saved with the trained models: reference docs/WhisperSeg_Training_Pipeline.ipynb, generation params).

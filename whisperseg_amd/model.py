@@ -337,16 +337,17 @@ class WhisperSegmenter(SegmenterBase):
 
 
 class WhisperSegmenterFast(WhisperSegmenter):
-    """reference model.py:678-746 is the CTranslate2 backend.  Here the bf16 MFMA engine *is* the fast
-    path, so this is WhisperSegmenter pinned to bf16.  A CTranslate2-converted directory (binary
-    `model.bin` + `hf_model/` without HF weights) cannot be read and raises, which makes
-    `scripts/segment.py`'s try-Fast-then-fallback idiom (reference scripts/segment.py:34-37) behave as
-    it does upstream when ctranslate2 is missing."""
+    """reference model.py:678-746 is the CTranslate2 backend, which computes in float16 on a GPU (model.py:691).  Here it is
+    the same engine pinned to IEEE half ("f16": half storage, MFMA, fp32 accumulation) — the 16-bit mode with the better
+    parity margin (profiles/: boundary deviations vs the fp32 reference).  A CTranslate2-converted directory (binary
+    `model.bin` + `hf_model/` without HF weights) cannot be read and raises, which makes `scripts/segment.py`'s
+    try-Fast-then-fallback idiom (reference scripts/segment.py:34-37) behave as it does upstream when ctranslate2 is
+    missing."""
 
     def __init__(self, model_path, device=None, device_ids=[0, ]):
         model_dir = resolve_model_dir(model_path)
         checkpoint_files(model_dir)      # raises FileNotFoundError for a CTranslate2-only directory
-        super().__init__(model_path, device=device, device_ids=device_ids, dtype="bf16")
+        super().__init__(model_path, device=device, device_ids=device_ids, dtype="f16")
 
 
 class WhisperSegmenterForEval(SegmenterBase):
