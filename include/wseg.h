@@ -175,6 +175,8 @@ typedef struct {
   int32_t n_admissions;           /* encoder + cross-K/V passes (groups of windows admitted into free slots)            */
   int64_t slot_steps_active;      /* sum over steps of slots that were decoding a window                                */
   int64_t slot_steps_total;       /* n_steps * n_slots                                                                  */
+  int64_t queued_slot_steps_active; /* the same two sums over the steps launched while windows were still queued, i.e.   */
+  int64_t queued_slot_steps_total;  /* without the drain of the last windows (steady-state occupancy of the refill)      */
 } wseg_generate_stats;
 int wseg_last_stats(const wseg_model* m, wseg_generate_stats* out);
 
@@ -188,7 +190,8 @@ int wseg_debug_first_logits(wseg_model* m, void* workspace, float* out, int32_t 
 int wseg_last_timing(const wseg_model* m, float out[4]);
 
 /* Test / tuning tap: out[M][N] = epilogue(A[M][K] * W[N][K]^T + bias) with the library's GEMM of the given dtype.
- * epi: 0 store, 1 GELU, 2 residual add (resid[M][N]).  A must have round_up(M,256) readable rows, N % 128 == 0,
+ * epi: 0 store, 1 GELU, 2 residual add (resid[M][N] and out are the fp32 residual stream in every dtype).  A must have
+ * round_up(M,256) readable rows, N % 128 == 0,
  * K % 64 == 0.  Used by tests/test_gemm_gpu.py (parity vs torch) and tools/gemm_bench.py. */
 int wseg_debug_gemm(int32_t dtype, int32_t epi, int32_t M, int32_t N, int32_t K, const void* A, const void* W,
                     const void* bias, const void* resid, void* out, void* splitk_ws, size_t splitk_ws_bytes, void* stream);

@@ -23,8 +23,10 @@ def test_gemm_matches_torch(gpu_lib, M, N, K, epi, dtype):
     A = (torch.rand(Mp, K, device="cuda", generator=g) * 2 - 1).to(td)
     W = ((torch.rand(N, K, device="cuda", generator=g) * 2 - 1) * K ** -0.5).to(td)      # asymmetric operands
     bias = (torch.rand(N, device="cuda", generator=g) - 0.5).to(td)
-    res = (torch.rand(Mp, N, device="cuda", generator=g) - 0.5).to(td)
-    out = torch.full((Mp, N), float("nan"), device="cuda", dtype=td)
+    # epi 2 is the residual-stream epilogue: resid and out are fp32 in every mode
+    od = torch.float32 if epi == 2 else td
+    res = (torch.rand(Mp, N, device="cuda", generator=g) - 0.5).to(od)
+    out = torch.full((Mp, N), float("nan"), device="cuda", dtype=od)
     ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
     _lib.check(gpu_lib.wseg_debug_gemm({"f32": 0, "bf16": 1, "f16": 2}[dtype], epi, M, N, K, A.data_ptr(), W.data_ptr(), bias.data_ptr(),
                                        res.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
@@ -56,17 +58,19 @@ def test_pingpong_gemm_matches_torch(gpu_lib, M, N, K, epi):
     A = (torch.rand(Mp, K, device="cuda", generator=g) * 2 - 1).to(torch.bfloat16)
     W = ((torch.rand(N, K, device="cuda", generator=g) * 2 - 1) * K ** -0.5).to(torch.bfloat16)
     bias = (torch.rand(N, device="cuda", generator=g) - 0.5).to(torch.bfloat16)
-    res = (torch.rand(Mp, N, device="cuda", generator=g) - 0.5).to(torch.bfloat16)
+    od = torch.float32 if epi == 2 else torch.bfloat16        # the residual-stream epilogue reads / writes fp32
+    res = (torch.rand(Mp, N, device="cuda", generator=g) - 0.5).to(od)
     ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
     outs = []
     for rep in range(3):          # race screen: a mis-ordered LDS-DMA / ds_read shows up as run-to-run differences
-        out = torch.full((Mp, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        out = torch.full((Mp, N), float("nan"), device="cuda", dtype=od)
         _lib.check(gpu_lib.wseg_debug_gemm(1, epi, M, N, K, A.data_ptr(), W.data_ptr(), bias.data_ptr(), res.data_ptr(),
                                            out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
         torch.cuda.synchronize()
         outs.append(out)
-    assert torch.equal(outs[0][:M].view(torch.int16), outs[1][:M].view(torch.int16))
-    assert torch.equal(outs[0][:M].view(torch.int16), outs[2][:M].view(torch.int16))
+    bits = torch.int32 if epi == 2 else torch.int16
+    assert torch.equal(outs[0][:M].view(bits), outs[1][:M].view(bits))
+    assert torch.equal(outs[0][:M].view(bits), outs[2][:M].view(bits))
     assert torch.isnan(outs[0][M:]).all()                      # rows past M are never written
     worst = 0.0
     for lo in range(0, M, 16384):                              # reference in row blocks (fp32 128000 x 5120 would be 2.6 GB)

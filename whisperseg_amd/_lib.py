@@ -30,7 +30,8 @@ class GenerateParams(C.Structure):
 
 class GenerateStats(C.Structure):
     _fields_ = [("n_windows", C.c_int32), ("n_slots", C.c_int32), ("n_steps", C.c_int32), ("n_admissions", C.c_int32),
-                ("slot_steps_active", C.c_int64), ("slot_steps_total", C.c_int64)]
+                ("slot_steps_active", C.c_int64), ("slot_steps_total", C.c_int64),
+                ("queued_slot_steps_active", C.c_int64), ("queued_slot_steps_total", C.c_int64)]
 
 
 # name -> (restype, argtypes); every symbol include/wseg.h declares.

@@ -76,8 +76,6 @@ template <> struct H16<f16_t> {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hw_f16x8, a), __builtin_bit_cast(hw_f16x8, b), c, 0, 0, 0);
   }
 };
-__device__ __forceinline__ uint32_t raw16(bf16_t v) { return v; }
-__device__ __forceinline__ uint32_t raw16(f16_t v) { return v.bits; }
 __device__ __forceinline__ float bf2f(bf16_t v) { return H16<bf16_t>::one(v); }
 __device__ __forceinline__ bf16_t f2bf(float f) { return H16<bf16_t>::from(f); }
 

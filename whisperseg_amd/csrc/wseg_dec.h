@@ -41,7 +41,7 @@ int launch_decode_reset(const DecodeState& st, hipStream_t s);
 // slots[i] starts decoding window wins[i] at position 0 (device arrays of n entries)
 int launch_decode_admit(const DecodeState& st, const int* slots, const int* wins, int n, hipStream_t s);
 int launch_build_suppress_mask(unsigned char* mask, int V, const int* sup, int n_sup, const int* bsup, int n_bsup, hipStream_t s);
-// x[r][:] = tok_emb[tokens_in[r]][:] + pos_emb[pos[slot of r]][:]
+// x[r][:] = tok_emb[tokens_in[r]][:] + pos_emb[pos[slot of r]][:]   (x: fp32 residual stream)
 int launch_embed(int dtype, const DecodeState& st, const void* tok_emb, const void* pos_emb, void* x, int d, hipStream_t s);
 // decoder self-attention over the KV cache [R][H][L][64] with per-position ancestry
 // qkv_part != nullptr: q/k/v of this step arrive as split-K partials [z][m_pad][3d] (+ qkv_bias); the kernel finishes the

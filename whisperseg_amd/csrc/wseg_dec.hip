@@ -53,11 +53,11 @@ __global__ void suppress_mask_kernel(unsigned char* mask, int V, const int* sup,
 
 template <typename T>
 __global__ __launch_bounds__(256) void embed_kernel(DecodeState st, const T* __restrict__ tok_emb, const T* __restrict__ pos_emb,
-                                                    T* __restrict__ x, int d) {
+                                                    float* __restrict__ x, int d) {      // x: the fp32 residual stream
   const int r = blockIdx.x;
   const int tok = st.tokens_in[r], pos = st.pos[r / st.nb];
   for (int c = threadIdx.x; c < d; c += 256)
-    El<T>::st(x + (size_t)r * d + c, El<T>::ld(tok_emb + (size_t)tok * d + c) + El<T>::ld(pos_emb + (size_t)pos * d + c));
+    x[(size_t)r * d + c] = El<T>::ld(tok_emb + (size_t)tok * d + c) + El<T>::ld(pos_emb + (size_t)pos * d + c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -856,8 +856,8 @@ int launch_build_suppress_mask(unsigned char* mask, int V, const int* sup, int n
 }
 int launch_embed(int dtype, const DecodeState& st, const void* tok_emb, const void* pos_emb, void* x, int d, hipStream_t s) {
   const int R = st.W * st.nb;
-  if (dtype == WSEG_BF16) hipLaunchKernelGGL((embed_kernel<bf16_t>), dim3(R), dim3(256), 0, s, st, (const bf16_t*)tok_emb, (const bf16_t*)pos_emb, (bf16_t*)x, d);
-  else if (dtype == WSEG_F16) hipLaunchKernelGGL((embed_kernel<f16_t>), dim3(R), dim3(256), 0, s, st, (const f16_t*)tok_emb, (const f16_t*)pos_emb, (f16_t*)x, d);
+  if (dtype == WSEG_BF16) hipLaunchKernelGGL((embed_kernel<bf16_t>), dim3(R), dim3(256), 0, s, st, (const bf16_t*)tok_emb, (const bf16_t*)pos_emb, (float*)x, d);
+  else if (dtype == WSEG_F16) hipLaunchKernelGGL((embed_kernel<f16_t>), dim3(R), dim3(256), 0, s, st, (const f16_t*)tok_emb, (const f16_t*)pos_emb, (float*)x, d);
   else hipLaunchKernelGGL((embed_kernel<float>), dim3(R), dim3(256), 0, s, st, (const float*)tok_emb, (const float*)pos_emb, (float*)x, d);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;

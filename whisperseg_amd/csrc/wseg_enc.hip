@@ -60,33 +60,38 @@ __global__ __launch_bounds__(256) void im2col_conv2_kernel(const T* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm: one wave per row, 16-byte vector loads, two-pass statistics in registers.
+// LayerNorm of the fp32 residual stream: one wave per row, 8 elements per lane and iteration (two 16-byte loads),
+// two-pass statistics in registers, output in the model dtype TO (float in exact-parity mode).
 // ------------------------------------------------------------------------------------------------
 template <typename T> struct VecIO {      // 16-bit element types: 8 per 16-byte access
-  static constexpr int V = 8;
   static __device__ __forceinline__ void ld(const T* p, float v[8]) { unpack8<T>(*(const uint4*)p, v); }
   static __device__ __forceinline__ void st(T* p, const float v[8]) { *(uint4*)p = pack8<T>(v); }
 };
 template <> struct VecIO<float> {
-  static constexpr int V = 4;
-  static __device__ __forceinline__ void ld(const float* p, float v[4]) { const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-  static __device__ __forceinline__ void st(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+  static __device__ __forceinline__ void ld(const float* p, float v[8]) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  static __device__ __forceinline__ void st(float* p, const float v[8]) {
+    *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
 };
 
-template <typename T, int NIT>
-__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ bta,
-                                                        T* __restrict__ y, int M, int d) {
-  constexpr int V = VecIO<T>::V;
+template <typename TO, int NIT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const TO* __restrict__ g, const TO* __restrict__ bta,
+                                                        TO* __restrict__ y, int M, int d) {
+  constexpr int V = 8;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
-  const T* xr = x + (size_t)row * d;
+  const float* xr = x + (size_t)row * d;
   float v[NIT][V];
   float sum = 0.f;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int c = (it * 64 + lane) * V;
     if (c < d) {
-      VecIO<T>::ld(xr + c, v[it]);
+      VecIO<float>::ld(xr + c, v[it]);
 #pragma unroll
       for (int j = 0; j < V; ++j) sum += v[it][j];
     } else {
@@ -110,11 +115,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     const int c = (it * 64 + lane) * V;
     if (c < d) {
       float gg[V], bb[V], o[V];
-      VecIO<T>::ld(g + c, gg);
-      VecIO<T>::ld(bta + c, bb);
+      VecIO<TO>::ld(g + c, gg);
+      VecIO<TO>::ld(bta + c, bb);
 #pragma unroll
       for (int j = 0; j < V; ++j) o[j] = (v[it][j] - mean) * rstd * gg[j] + bb[j];
-      VecIO<T>::st(y + (size_t)row * d + c, o);
+      VecIO<TO>::st(y + (size_t)row * d + c, o);
     }
   }
 }
@@ -310,21 +315,17 @@ int launch_im2col_conv2(int dtype, const void* h1, void* a2, int B, int cols, in
   return WSEG_OK;
 }
 
-int launch_layernorm(int dtype, const void* x, const void* g, const void* b, void* y, int M, int d, hipStream_t s) {
+int launch_layernorm(int dtype, const float* x, const void* g, const void* b, void* y, int M, int d, hipStream_t s) {
   if (M <= 0) return WSEG_OK;
   dim3 grid(cdiv(M, 4));
-  if (dtype != WSEG_F32) {
-    if (d % 8 || d > 64 * 8 * 4) { set_error("layernorm: d %d unsupported", d); return WSEG_ERR_INVALID; }
-#define WSEG_LN(HT_, NIT_) hipLaunchKernelGGL((layernorm_kernel<HT_, NIT_>), grid, dim3(256), 0, s, (const HT_*)x, (const HT_*)g, (const HT_*)b, (HT_*)y, M, d)
-    const int nit = d <= 512 ? 1 : (d <= 1024 ? 2 : 4);
-    if (dtype == WSEG_BF16) { if (nit == 1) WSEG_LN(bf16_t, 1); else if (nit == 2) WSEG_LN(bf16_t, 2); else WSEG_LN(bf16_t, 4); }
-    else { if (nit == 1) WSEG_LN(f16_t, 1); else if (nit == 2) WSEG_LN(f16_t, 2); else WSEG_LN(f16_t, 4); }
+  if (d % 8 || d > 64 * 8 * 4) { set_error("layernorm: d %d unsupported", d); return WSEG_ERR_INVALID; }
+#define WSEG_LN(TO_, NIT_) hipLaunchKernelGGL((layernorm_kernel<TO_, NIT_>), grid, dim3(256), 0, s, x, (const TO_*)g, (const TO_*)b, (TO_*)y, M, d)
+#define WSEG_LN3(TO_) do { if (d <= 512) WSEG_LN(TO_, 1); else if (d <= 1024) WSEG_LN(TO_, 2); else WSEG_LN(TO_, 4); } while (0)
+  if (dtype == WSEG_BF16) WSEG_LN3(bf16_t);
+  else if (dtype == WSEG_F16) WSEG_LN3(f16_t);
+  else WSEG_LN3(float);
+#undef WSEG_LN3
 #undef WSEG_LN
-  } else {
-    if (d % 4 || d > 64 * 4 * 8) { set_error("layernorm: d %d unsupported", d); return WSEG_ERR_INVALID; }
-    if (d <= 512) hipLaunchKernelGGL((layernorm_kernel<float, 2>), grid, dim3(256), 0, s, (const float*)x, (const float*)g, (const float*)b, (float*)y, M, d);
-    else hipLaunchKernelGGL((layernorm_kernel<float, 8>), grid, dim3(256), 0, s, (const float*)x, (const float*)g, (const float*)b, (float*)y, M, d);
-  }
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }

@@ -55,18 +55,18 @@ __device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, fl
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = gelu_for<T>(v[i]);
     Vec4<T>::st((T*)ep.out + (size_t)m * ep.ldc + n0, v);
-  } else if constexpr (EPI == EPI_RESID) {
+  } else if constexpr (EPI == EPI_RESID) {      // the residual stream is fp32 in every mode
     float r[4];
-    Vec4<T>::ld((const T*)ep.resid + (size_t)m * ep.ldc + n0, r);
+    Vec4<float>::ld((const float*)ep.resid + (size_t)m * ep.ldc + n0, r);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = r[i] + v[i];
-    Vec4<T>::st((T*)ep.out + (size_t)m * ep.ldc + n0, v);
-  } else if constexpr (EPI == EPI_GELU_POS) {
+    Vec4<float>::st((float*)ep.out + (size_t)m * ep.ldc + n0, v);
+  } else if constexpr (EPI == EPI_GELU_POS) {   // conv2 -> residual stream (fp32)
     float p[4];
     Vec4<T>::ld((const T*)ep.pos + (size_t)(m % ep.pos_rows) * ep.ldc + n0, p);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = gelu_for<T>(v[i]) + p[i];
-    Vec4<T>::st((T*)ep.out + (size_t)m * ep.ldc + n0, v);
+    Vec4<float>::st((float*)ep.out + (size_t)m * ep.ldc + n0, v);
   } else if constexpr (EPI == EPI_QKV_ENC) {
     const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
     const int b = m / ep.t_len, t = m - b * ep.t_len;
@@ -127,18 +127,20 @@ __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, f
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = gelu_for<T>(v[i]);
     st8_h<T>((T*)ep.out + (size_t)m * ep.ldc + n0, v);
-  } else if constexpr (EPI == EPI_RESID) {
-    float r[8];
-    ld8_h<T>((const T*)ep.resid + (size_t)m * ep.ldc + n0, r);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = r[i] + v[i];
-    st8_h<T>((T*)ep.out + (size_t)m * ep.ldc + n0, v);
-  } else if constexpr (EPI == EPI_GELU_POS) {
+  } else if constexpr (EPI == EPI_RESID) {      // the residual stream is fp32 in every mode
+    const float* rp = (const float*)ep.resid + (size_t)m * ep.ldc + n0;
+    const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
+    float* o = (float*)ep.out + (size_t)m * ep.ldc + n0;
+    *(float4*)o = make_float4(r0.x + v[0], r0.y + v[1], r0.z + v[2], r0.w + v[3]);
+    *(float4*)(o + 4) = make_float4(r1.x + v[4], r1.y + v[5], r1.z + v[6], r1.w + v[7]);
+  } else if constexpr (EPI == EPI_GELU_POS) {   // conv2 -> residual stream (fp32)
     float p[8];
     ld8_h<T>((const T*)ep.pos + (size_t)(m % ep.pos_rows) * ep.ldc + n0, p);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = gelu_for<T>(v[i]) + p[i];
-    st8_h<T>((T*)ep.out + (size_t)m * ep.ldc + n0, v);
+    float* o = (float*)ep.out + (size_t)m * ep.ldc + n0;
+    *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
   } else if constexpr (EPI == EPI_QKV_ENC) {
     const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
     const int b = m / ep.t_len, t = m - b * ep.t_len;
@@ -369,12 +371,17 @@ __device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NI][MI], floa
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = 0.f;
   }
-  uint4 rraw[EPI == EPI_RESID ? MI * 2 : 1];
+  // fp32 residual rows: NS rows (8 floats = two 16-byte loads each) are in flight per lane.  All of them are requested
+  // before the first store; row t + NS is requested right after row t has been stored, NS - 1 stores ahead of its use, so
+  // it never waits for a store it was issued behind (vmcnt retires in order).
+  constexpr int NROW = MI * 2, NS = NROW < 8 ? NROW : 8;
+  float4 rres[EPI == EPI_RESID ? NS : 1][2];
+  const float* rbase = (const float*)ep.resid + nc;
   if constexpr (EPI == EPI_RESID) {
 #pragma unroll
-    for (int t = 0; t < MI * 2; ++t) {
-      const int m = min(mb + t * 8 + rr, M - 1);
-      rraw[t] = *(const uint4*)((const HT*)ep.resid + (size_t)m * ep.ldc + nc);
+    for (int t = 0; t < NS; ++t) {
+      const float* rp = rbase + (size_t)min(mb + t * 8 + rr, M - 1) * ep.ldc;
+      rres[t][0] = *(const float4*)rp; rres[t][1] = *(const float4*)(rp + 4);
     }
   }
   EpiParams ep2 = ep;
@@ -404,14 +411,17 @@ __device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NI][MI], floa
       float v[8] = {a.x + bv[0], a.y + bv[1], a.z + bv[2], a.w + bv[3], b.x + bv[4], b.y + bv[5], b.z + bv[6], b.w + bv[7]};
       const int m = mb + j * 16 + rw;
       if constexpr (EPI == EPI_RESID) {
-        const uint4 t = rraw[j * 2 + hh];
-        const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[2 * e] = H16<HT>::lo(w4[e]) + v[2 * e];
-          v[2 * e + 1] = H16<HT>::hi(w4[e]) + v[2 * e + 1];
+        const int t = j * 2 + hh, sl = t % NS;
+        const float4 r0 = rres[sl][0], r1 = rres[sl][1];
+        if (m < M) {
+          float* o = (float*)ep.out + (size_t)m * ep.ldc + nc;
+          *(float4*)o = make_float4(r0.x + v[0], r0.y + v[1], r0.z + v[2], r0.w + v[3]);
+          *(float4*)(o + 4) = make_float4(r1.x + v[4], r1.y + v[5], r1.z + v[6], r1.w + v[7]);
         }
-        if (m < M) st8_h<HT>((HT*)ep.out + (size_t)m * ep.ldc + nc, v);
+        if (t + NS < NROW) {
+          const float* rp = rbase + (size_t)min(mb + (t + NS) * 8 + rr, M - 1) * ep.ldc;
+          rres[sl][0] = *(const float4*)rp; rres[sl][1] = *(const float4*)(rp + 4);
+        }
       } else if constexpr (EPI == EPI_KV_CROSS) {
         int mm = m;
         if (ep.slot_map) { const int b = m / ep.t_len; mm = (b == kv_b0 ? kv_s0 : kv_s1) * ep.t_len + (m - b * ep.t_len); }
@@ -896,13 +906,11 @@ static int launch_skinny_partial(const GemmArgs& g, const SkinnyPlan& sp, hipStr
   return WSEG_OK;
 }
 
-// x[m][:] = resid[m][:] + bias + sum_z part[z][m][:]  (stored in the model dtype), then y[m][:] = LayerNorm(x[m][:]).
-// One wave per row.  LayerNorm is computed from the ROUNDED x so that the result is bit-identical to running the
-// generic reduction and layernorm_kernel back to back.
+// x[m][:] += bias + sum_z part[z][m][:]  (x is the fp32 residual stream), then y[m][:] = LayerNorm(x[m][:]) in the model dtype.
 // One workgroup per row, one 8-element chunk per thread (d <= 2048), all split partials loaded up front.
 template <typename HT>
 __global__ __launch_bounds__(256) void splitk_reduce_resid_ln_kernel(const float* __restrict__ part, int splits, int m_pad, int M,
-                                                                     int d, const HT* __restrict__ bias, HT* __restrict__ x,
+                                                                     int d, const HT* __restrict__ bias, float* __restrict__ x,
                                                                      const HT* __restrict__ gam, const HT* __restrict__ bet,
                                                                      HT* __restrict__ y) {
   __shared__ float s_red[4];
@@ -920,21 +928,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_resid_ln_kernel(const float
       const float4 p0 = *(const float4*)(pp + z * zs), p1 = *(const float4*)(pp + z * zs + 4);
       a[0] += p0.x; a[1] += p0.y; a[2] += p0.z; a[3] += p0.w; a[4] += p1.x; a[5] += p1.y; a[6] += p1.z; a[7] += p1.w;
     }
-    const uint4 t = *(const uint4*)(x + (size_t)row * d + c);
-    const uint4 u = *(const uint4*)(bias + c);
-    const uint32_t w[4] = {t.x, t.y, t.z, t.w}, zb[4] = {u.x, u.y, u.z, u.w};
-    uint32_t o[4];
+    float* xp = x + (size_t)row * d + c;
+    const float4 x0 = *(const float4*)xp, x1 = *(const float4*)(xp + 4);
+    const float r[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    float bb[8];
+    unpack8<HT>(*(const uint4*)(bias + c), bb);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float r0 = H16<HT>::lo(w[j]), r1 = H16<HT>::hi(w[j]);
-      const float b0 = H16<HT>::lo(zb[j]), b1 = H16<HT>::hi(zb[j]);
-      const HT q0 = H16<HT>::from(r0 + (a[2 * j] + b0)), q1 = H16<HT>::from(r1 + (a[2 * j + 1] + b1));
-      v[2 * j] = H16<HT>::one(q0); v[2 * j + 1] = H16<HT>::one(q1);
-      o[j] = raw16(q0) | (raw16(q1) << 16);
-    }
-    *(uint4*)(x + (size_t)row * d + c) = make_uint4(o[0], o[1], o[2], o[3]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) sum += v[j];
+    for (int j = 0; j < 8; ++j) { v[j] = r[j] + (a[j] + bb[j]); sum += v[j]; }
+    *(float4*)xp = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)(xp + 4) = make_float4(v[4], v[5], v[6], v[7]);
   }
   sum = wave_sum(sum);
   if (lane == 0) s_red[wave] = sum;
@@ -951,16 +953,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_resid_ln_kernel(const float
   __syncthreads();
   const float rstd = 1.0f / sqrtf(((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / (float)d + 1e-5f);
   if (act) {
-    const uint4 tg = *(const uint4*)(gam + c), tb = *(const uint4*)(bet + c);
-    const uint32_t wg[4] = {tg.x, tg.y, tg.z, tg.w}, wb[4] = {tb.x, tb.y, tb.z, tb.w};
-    uint32_t o[4];
+    float gg[8], be[8], o[8];
+    unpack8<HT>(*(const uint4*)(gam + c), gg);
+    unpack8<HT>(*(const uint4*)(bet + c), be);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float y0 = (v[2 * j] - mean) * rstd * H16<HT>::lo(wg[j]) + H16<HT>::lo(wb[j]);
-      const float y1 = (v[2 * j + 1] - mean) * rstd * H16<HT>::hi(wg[j]) + H16<HT>::hi(wb[j]);
-      o[j] = H16<HT>::pack(y0, y1);
-    }
-    *(uint4*)(y + (size_t)row * d + c) = make_uint4(o[0], o[1], o[2], o[3]);
+    for (int j = 0; j < 8; ++j) o[j] = (v[j] - mean) * rstd * gg[j] + be[j];
+    *(uint4*)(y + (size_t)row * d + c) = pack8<HT>(o);
   }
 }
 
@@ -1090,18 +1088,18 @@ int launch_gemm_resid_ln(int dtype, const GemmArgs& g0, const void* gamma, const
       if (dtype == WSEG_BF16) {
         WSEG_TRY_(launch_skinny_partial<bf16_t>(g, sp, s));
         hipLaunchKernelGGL(splitk_reduce_resid_ln_kernel<bf16_t>, dim3(g.M), dim3(256), 0, s, g.splitk_ws, sp.splits, sp.m_pad, g.M, d,
-                           (const bf16_t*)g.ep.bias, (bf16_t*)g.ep.out, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y);
+                           (const bf16_t*)g.ep.bias, (float*)g.ep.out, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y);
       } else {
         WSEG_TRY_(launch_skinny_partial<f16_t>(g, sp, s));
         hipLaunchKernelGGL(splitk_reduce_resid_ln_kernel<f16_t>, dim3(g.M), dim3(256), 0, s, g.splitk_ws, sp.splits, sp.m_pad, g.M, d,
-                           (const f16_t*)g.ep.bias, (f16_t*)g.ep.out, (const f16_t*)gamma, (const f16_t*)beta, (f16_t*)y);
+                           (const f16_t*)g.ep.bias, (float*)g.ep.out, (const f16_t*)gamma, (const f16_t*)beta, (f16_t*)y);
       }
       WSEG_LAUNCH_CHECK();
       return WSEG_OK;
     }
   }
   WSEG_TRY_(launch_gemm(dtype, EPI_RESID, g, s));
-  return launch_layernorm(dtype, g.ep.out, gamma, beta, y, g.M, d, s);
+  return launch_layernorm(dtype, (const float*)g.ep.out, gamma, beta, y, g.M, d, s);
 }
 
 int launch_gemm(int dtype, EpiKind epi, const GemmArgs& g, hipStream_t s) {

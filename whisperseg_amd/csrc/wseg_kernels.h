@@ -23,9 +23,9 @@ enum EpiKind {
 
 struct EpiParams {
   const void* bias = nullptr;  // model dtype [N] (nullptr = none)
-  void* out = nullptr;         // model dtype
+  void* out = nullptr;         // model dtype; fp32 for the residual-stream epilogues (EPI_RESID, EPI_GELU_POS)
   int ldc = 0;
-  const void* resid = nullptr;
+  const void* resid = nullptr; // fp32 residual stream [M][ldc]
   const void* pos = nullptr;
   int pos_rows = 1;
   float scale = 1.f;
@@ -69,8 +69,8 @@ int launch_gemm_resid_ln(int dtype, const GemmArgs& g, const void* gamma, const 
 int launch_im2col_conv1(int dtype, const float* feats, void* a1, int B, int n_mels, int cols, int kp, hipStream_t s);
 // h1 [B*1000][d] -> A2 [B*500][3d] with k = tap*d + c, stride 2, pad 1.
 int launch_im2col_conv2(int dtype, const void* h1, void* a2, int B, int cols, int d, hipStream_t s);
-// y[m][:] = LayerNorm(x[m][:]) * g + b, eps 1e-5.
-int launch_layernorm(int dtype, const void* x, const void* g, const void* b, void* y, int M, int d, hipStream_t s);
+// y[m][:] = LayerNorm(x[m][:]) * g + b, eps 1e-5; x is the fp32 residual stream, y / g / b have the model dtype.
+int launch_layernorm(int dtype, const float* x, const void* g, const void* b, void* y, int M, int d, hipStream_t s);
 // Encoder self-attention over Q,K [B][H][Tp][64], Vt [B][H][64][Tp] (q pre-scaled) -> out [B*T][d].
 int launch_enc_attention(int dtype, const void* q, const void* k, const void* vt, void* out,
                          int B, int H, int T, int Tp, int d, hipStream_t s);

@@ -98,7 +98,7 @@ void make_plan(const wseg_model* m, int W, int nb, int L, char* base, Plan& p) {
   p.h1 = p.a1 + align_up(M1p * m->kp1 * es, 256);
   p.a2 = p.h1 + align_up(M1p * d * es, 256);
   p.hbuf = u;
-  p.x = take(Mp * d * es);
+  p.x = take(Mp * d * 4);                          // the residual stream is fp32 in every mode
   p.y = take(Mp * d * es);
   p.q = take((size_t)W * H * m->tp * 64 * es);
   p.k = take((size_t)W * H * m->tp * 64 * es);
@@ -113,7 +113,7 @@ void make_plan(const wseg_model* m, int W, int nb, int L, char* base, Plan& p) {
   q.cv = take(Ld * Wc * H * Tk * 64 * es);
   q.sk = take(Ld * R * H * (size_t)L * 64 * es);
   q.sv = take(Ld * R * H * (size_t)L * 64 * es);
-  q.dx = take(Rp * d * es);
+  q.dx = take(Rp * d * 4);                         // decoder residual stream, fp32
   q.dy = take(Rp * d * es);
   q.dq = take(Rp * d * es);
   q.dattn = take(Rp * d * es);
@@ -191,7 +191,7 @@ int run_encoder(wseg_model* m, const float* feats, int W, Plan& p, void* enc_out
   WSEG_TRY(gemm(m, EPI_GELU_POS, p.a2, 3 * d, m->conv2_w, 3 * d, M, d, 3 * d, e, nullptr, s));
   for (int l = 0; l < c.enc_layers; ++l) {
     const EncLayer& L = m->enc[l];
-    WSEG_TRY(launch_layernorm(dt, p.x, L.ln1_g, L.ln1_b, p.y, M, d, s));
+    WSEG_TRY(launch_layernorm(dt, (const float*)p.x, L.ln1_g, L.ln1_b, p.y, M, d, s));
     e = EpiParams();
     e.bias = L.qkv_b; e.q = p.q; e.k = p.k; e.v = p.vt; e.d_model = d; e.t_len = T; e.t_pad = Tp; e.n_heads = H; e.scale = 0.125f;
     WSEG_TRY(gemm(m, EPI_QKV_ENC, p.y, d, L.qkv_w, d, M, 3 * d, d, e, nullptr, s));
@@ -199,7 +199,7 @@ int run_encoder(wseg_model* m, const float* feats, int W, Plan& p, void* enc_out
     e = EpiParams();
     e.bias = L.o_b; e.out = p.x; e.resid = p.x; e.ldc = d;
     WSEG_TRY(gemm(m, EPI_RESID, p.y, d, L.o_w, d, M, d, d, e, nullptr, s));
-    WSEG_TRY(launch_layernorm(dt, p.x, L.ln2_g, L.ln2_b, p.y, M, d, s));
+    WSEG_TRY(launch_layernorm(dt, (const float*)p.x, L.ln2_g, L.ln2_b, p.y, M, d, s));
     e = EpiParams();
     e.bias = L.fc1_b; e.out = p.hbuf; e.ldc = ffn;
     WSEG_TRY(gemm(m, EPI_GELU, p.y, d, L.fc1_w, d, M, ffn, d, e, nullptr, s));
@@ -207,7 +207,7 @@ int run_encoder(wseg_model* m, const float* feats, int W, Plan& p, void* enc_out
     e.bias = L.fc2_b; e.out = p.x; e.resid = p.x; e.ldc = d;
     WSEG_TRY(gemm(m, EPI_RESID, p.hbuf, ffn, L.fc2_w, ffn, M, d, ffn, e, nullptr, s));
   }
-  WSEG_TRY(launch_layernorm(dt, p.x, m->enc_ln_g, m->enc_ln_b, enc_out, M, d, s));
+  WSEG_TRY(launch_layernorm(dt, (const float*)p.x, m->enc_ln_g, m->enc_ln_b, enc_out, M, d, s));
   return WSEG_OK;
 }
 
@@ -230,7 +230,7 @@ int run_decoder_step(wseg_model* m, DecPlan& p, bool want_logits, hipStream_t s)
     return launch_gemm_resid_ln(dt, g, g_, b_, p.dy, s);
   };
   // y = LN1(x) of layer 0; every later LayerNorm is fused into the reduction of the GEMM that precedes it
-  WSEG_TRY(launch_layernorm(dt, p.dx, m->dec[0].ln1_g, m->dec[0].ln1_b, p.dy, R, d, s));
+  WSEG_TRY(launch_layernorm(dt, (const float*)p.dx, m->dec[0].ln1_g, m->dec[0].ln1_b, p.dy, R, d, s));
   for (int l = 0; l < c.dec_layers; ++l) {
     const DecLayer& L = m->dec[l];
     {   // q|k|v projection: partial sums only when possible; the attention kernel finishes the reduction
@@ -562,6 +562,7 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
 
   // status mirror of step u lives in ring entry status_idx[u % N]
   int status_idx[PinnedRing::N];
+  bool step_queued[PinnedRing::N];             // were windows still waiting in the queue when the step was launched?
   auto consume_status = [&](int u) -> int {      // retire every slot that step u left finished
     const int ri = status_idx[u % PinnedRing::N];
     WSEG_HIP_CHECK(hipEventSynchronize(m->ring_status.ev[ri]));
@@ -575,6 +576,10 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
       else ++active;
     }
     m->stats.slot_steps_active += active + (int64_t)tmp_a.size();
+    if (step_queued[u % PinnedRing::N]) {
+      m->stats.queued_slot_steps_active += active + (int64_t)tmp_a.size();
+      m->stats.queued_slot_steps_total += S;
+    }
     if (!tmp_a.empty()) {
       const int n = (int)tmp_a.size();
       WSEG_TRY(h2d_list(m, tmp_a.data(), n, q.ret_slots, s));
@@ -606,6 +611,7 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
       WSEG_HIP_CHECK(hipEventRecord(m->ring_status.ev[ri], s));
       m->ring_status.used[ri] = true;
       status_idx[t % PinnedRing::N] = ri;
+      step_queued[t % PinnedRing::N] = next_win < n_windows;
     }
     ++t;
     m->stats.slot_steps_total += S;

@@ -289,11 +289,12 @@ class Engine:
 
     def last_stats(self):
         """Scheduler statistics of the last generate call: dict(n_windows, n_slots, n_steps, n_admissions,
-        slot_steps_active, slot_steps_total, occupancy)."""
+        slot_steps_active, slot_steps_total, occupancy, steady_occupancy = occupancy while windows were still queued)."""
         st = _lib.GenerateStats()
         _lib.check(self.lib.wseg_last_stats(self.handle, C.byref(st)))
         out = {k: int(getattr(st, k)) for k, _ in st._fields_}
         out["occupancy"] = out["slot_steps_active"] / max(1, out["slot_steps_total"])
+        out["steady_occupancy"] = out["queued_slot_steps_active"] / max(1, out["queued_slot_steps_total"])
         return out
 
     def last_timing(self):
