@@ -34,8 +34,9 @@ for name, m, n, k, epi in shapes:
     Ws = [W] + [W.clone() for _ in range(a.rotate - 1)]
     call = [0]
     bias = torch.rand(n, device="cuda").to(torch.bfloat16)
-    res = torch.rand(mp, n, device="cuda").to(torch.bfloat16)
-    out = torch.empty(mp, n, device="cuda", dtype=torch.bfloat16)
+    od = torch.float32 if epi == 2 else torch.bfloat16       # the residual-stream epilogue reads / writes fp32
+    res = torch.rand(mp, n, device="cuda").to(od)
+    out = torch.empty(mp, n, device="cuda", dtype=od)
     st = _lib.stream_ptr()
 
     def run():

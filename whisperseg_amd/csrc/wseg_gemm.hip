@@ -852,7 +852,7 @@ static int device_cu_count() {
 // skinny family (decoder steps, small encoders): BN = 64, BM in {32, 64, 128}; K is split across workgroups until
 // ~256+ of them stream the weight matrix.  Partials are reduced (in a fixed order) by a second kernel that
 // applies the epilogue (or the fused residual + LayerNorm).
-struct SkinnyPlan { int bm, mt, m_pad, splits, k_len; };
+struct SkinnyPlan { int bm, bn, mt, m_pad, splits, k_len; };
 
 static SkinnyPlan plan_skinny(const GemmArgs& g) {
   SkinnyPlan sp;
@@ -864,9 +864,12 @@ static SkinnyPlan plan_skinny(const GemmArgs& g) {
     if (nt * cdiv(g.M, 128) < 160 && nt * cdiv(g.M, 64) >= 160) sp.bm = 64;
     if (force_bm == 64 || force_bm == 128) sp.bm = force_bm;
   }
+  // experiment knob: 128-column tiles (half the LDS-fill traffic per flop of the 64-column family) for row counts >= 512
+  static const bool bn128 = getenv("WSEG_SKINNY_BN128") != nullptr;
+  sp.bn = (bn128 && g.M >= 512 && g.N % 128 == 0 && sp.bm == 128) ? 128 : 64;
   sp.mt = cdiv(g.M, sp.bm);
   sp.m_pad = sp.mt * sp.bm;
-  const int blocks = (g.N / 64) * sp.mt;
+  const int blocks = (g.N / sp.bn) * sp.mt;
   sp.splits = 1;
   if (g.splitk_ws) {
     // split K (in whole 64-wide tiles, >= 2 tiles per split) until ~256 workgroups stream the weights
@@ -891,7 +894,18 @@ static int launch_skinny_partial(const GemmArgs& g, const SkinnyPlan& sp, hipStr
     set_error("split-K workspace missing or too small");
     return WSEG_ERR_STATE;
   }
-  dim3 grid(g.N / 64, sp.mt, sp.splits);
+  dim3 grid(g.N / sp.bn, sp.mt, sp.splits);
+  static const int nst = getenv("WSEG_SKINNY_NST") ? atoi(getenv("WSEG_SKINNY_NST")) : 2;       // experiment knob (128-row tiles)
+  if (sp.bm == 128 && (sp.bn == 128 || nst != 2)) {
+#define WSEG_SKINNY_X(BN_, NST_)                                                                                             \
+  hipLaunchKernelGGL((gemm_h16_kernel<HT, 128, BN_, 2, 2, EPI_STORE, true, NST_>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, \
+                     g.N, sp.k_len, g.ep, g.splitk_ws, sp.m_pad, 0)
+    if (sp.bn == 128) { if (nst == 4) WSEG_SKINNY_X(128, 4); else if (nst == 3) WSEG_SKINNY_X(128, 3); else WSEG_SKINNY_X(128, 2); }
+    else { if (nst == 4) WSEG_SKINNY_X(64, 4); else WSEG_SKINNY_X(64, 3); }
+#undef WSEG_SKINNY_X
+    WSEG_LAUNCH_CHECK();
+    return WSEG_OK;
+  }
   // LDS ring depth: 2 stages.  Measured (large, 120 windows): 6-8 K tiles in flight with one workgroup per CU is 1.7x
   // SLOWER than 3-4 stages at two workgroups per CU, and 2 stages (3-5 workgroups per CU) is another 2-3 % faster at every
   // batch size — these kernels want co-resident workgroups to cover their barriers, not more bytes in flight each.
@@ -1023,6 +1037,15 @@ static int launch_h16(const GemmArgs& g, hipStream_t s) {
       }
     }
     if (e1) (void)hipEventRecord(e1, s);
+    WSEG_LAUNCH_CHECK();
+    return WSEG_OK;
+  }
+  // experiment knob: no split-K at >= 512 rows, 128x128 tiles with a 3-deep LDS ring and the fused epilogue
+  static const bool direct128 = getenv("WSEG_SKINNY_DIRECT128") != nullptr;
+  if (direct128 && g.M >= 512 && g.N % 128 == 0) {
+    dim3 grid(g.N / 128, cdiv(g.M, 128), 1);
+    hipLaunchKernelGGL((gemm_h16_kernel<HT, 128, 128, 2, 2, EPI, false, 3>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K, g.ep,
+                       (float*)nullptr, 0, 0);
     WSEG_LAUNCH_CHECK();
     return WSEG_OK;
   }
