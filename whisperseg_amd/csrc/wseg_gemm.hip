@@ -246,35 +246,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h16_kernel(const HT* __rest
     for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fg = lane >> 4;
-  // NST-deep LDS ring.  NST == 2: prefetch one tile ahead.  NST > 2 (decoder weight streams, few K tiles per
-  // workgroup): NST-1 tiles are kept in flight; past the end the last tile is re-issued so the counted vmcnt
-  // stays a compile-time constant.
-  if constexpr (NST == 2) {
-    issue(0, 0);
-  } else {
-#pragma unroll
-    for (int t = 0; t < NST - 1; ++t) issue(t < nk ? t : nk - 1, t);
-  }
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt % NST;
-    if constexpr (NST == 2) {
-      if (kt + 1 < nk) {
-        issue(kt + 1, buf ^ 1);
-        wait_vmcnt<NLD>();
-      } else {
-        wait_vmcnt<0>();
-      }
-    } else {
-      const int nt = kt + NST - 1;
-      issue(nt < nk ? nt : nk - 1, nt % NST);
-      wait_vmcnt<NLD*(NST - 1)>();
-    }
-    __builtin_amdgcn_s_barrier();
+  // one K tile (64) of the wave tile from LDS stage `buf`.  Fragment reads are software-pipelined against the MFMAs: the
+  // activation fragments of BOTH k-steps of the tile and the next weight fragment are requested while the current weight
+  // fragment is being multiplied, so a wave only stalls on LDS at the head of a tile.
+  auto compute = [&](int buf) {
     const HT* cA = sA + buf * BM * BK + (wm * TM) * BK;
     const HT* cW = sW + buf * BN * BK + (wn * TN) * BK;
-    // Fragment reads are software-pipelined against the MFMAs: the activation fragments of BOTH k-steps of the tile
-    // and the next weight fragment are requested while the current weight fragment is being multiplied, so a wave
-    // only stalls on LDS at the head of a tile (the co-resident wave of the SIMD covers that).
     auto lda = [&](int kk, int j) {
       const int r = j * 16 + fr;
       return *(const bf16x8*)(cA + r * BK + (((kk * 4 + fg) ^ (r & 7)) << 3));
@@ -306,6 +283,32 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h16_kernel(const HT* __rest
       for (int j = 0; j < MI; ++j) acc[i][j] = H16<HT>::mfma16(wcur, af1[j], acc[i][j]);
       wcur = wnxt;
     }
+  };
+  // NST-deep LDS ring.  NST == 2: prefetch one tile ahead.  NST > 2 (decoder weight streams, few K tiles per
+  // workgroup): NST-1 tiles are kept in flight; past the end the last tile is re-issued so the counted vmcnt
+  // stays a compile-time constant.
+  if constexpr (NST == 2) {
+    issue(0, 0);
+  } else {
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) issue(t < nk ? t : nk - 1, t);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt % NST;
+    if constexpr (NST == 2) {
+      if (kt + 1 < nk) {
+        issue(kt + 1, buf ^ 1);
+        wait_vmcnt<NLD>();
+      } else {
+        wait_vmcnt<0>();
+      }
+    } else {
+      const int nt = kt + NST - 1;
+      issue(nt < nk ? nt : nk - 1, nt % NST);
+      wait_vmcnt<NLD*(NST - 1)>();
+    }
+    __builtin_amdgcn_s_barrier();
+    compute(buf);
     __builtin_amdgcn_s_barrier();
   }
 
@@ -864,9 +867,7 @@ static SkinnyPlan plan_skinny(const GemmArgs& g) {
     if (nt * cdiv(g.M, 128) < 160 && nt * cdiv(g.M, 64) >= 160) sp.bm = 64;
     if (force_bm == 64 || force_bm == 128) sp.bm = force_bm;
   }
-  // experiment knob: 128-column tiles (half the LDS-fill traffic per flop of the 64-column family) for row counts >= 512
-  static const bool bn128 = getenv("WSEG_SKINNY_BN128") != nullptr;
-  sp.bn = (bn128 && g.M >= 512 && g.N % 128 == 0 && sp.bm == 128) ? 128 : 64;
+  sp.bn = 64;
   sp.mt = cdiv(g.M, sp.bm);
   sp.m_pad = sp.mt * sp.bm;
   const int blocks = (g.N / sp.bn) * sp.mt;
@@ -895,20 +896,14 @@ static int launch_skinny_partial(const GemmArgs& g, const SkinnyPlan& sp, hipStr
     return WSEG_ERR_STATE;
   }
   dim3 grid(g.N / sp.bn, sp.mt, sp.splits);
-  static const int nst = getenv("WSEG_SKINNY_NST") ? atoi(getenv("WSEG_SKINNY_NST")) : 2;       // experiment knob (128-row tiles)
-  if (sp.bm == 128 && (sp.bn == 128 || nst != 2)) {
-#define WSEG_SKINNY_X(BN_, NST_)                                                                                             \
-  hipLaunchKernelGGL((gemm_h16_kernel<HT, 128, BN_, 2, 2, EPI_STORE, true, NST_>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, \
-                     g.N, sp.k_len, g.ep, g.splitk_ws, sp.m_pad, 0)
-    if (sp.bn == 128) { if (nst == 4) WSEG_SKINNY_X(128, 4); else if (nst == 3) WSEG_SKINNY_X(128, 3); else WSEG_SKINNY_X(128, 2); }
-    else { if (nst == 4) WSEG_SKINNY_X(64, 4); else WSEG_SKINNY_X(64, 3); }
-#undef WSEG_SKINNY_X
-    WSEG_LAUNCH_CHECK();
-    return WSEG_OK;
-  }
   // LDS ring depth: 2 stages.  Measured (large, 120 windows): 6-8 K tiles in flight with one workgroup per CU is 1.7x
   // SLOWER than 3-4 stages at two workgroups per CU, and 2 stages (3-5 workgroups per CU) is another 2-3 % faster at every
   // batch size — these kernels want co-resident workgroups to cover their barriers, not more bytes in flight each.
+  // Round 2, at 1024 rows (profiles/README.md, "decode GEMM experiments"): 3 / 4 stages 12.8 / 16.7 us against 11.1 us;
+  // 128x128 tiles (split 4) 13.6 us; no split with 128x128 tiles and 3 stages 24 us; register staging (global -> VGPR ->
+  // ds_write, one barrier per K tile) 35.8 us; dropping the loads OR the MFMAs from the loop changes nothing (11.3 / 9.8
+  // us): a K tile costs ~0.6 us of serialised issue -> land -> barrier -> fragment reads -> MFMA -> barrier per workgroup,
+  // while a bare LDS-DMA stream of the same L2-resident data runs at 123 GB/s per CU (tools/probes/l2fill_probe.hip).
 #define WSEG_SKINNY_P(BM_, WM_, WN_)                                                                                     \
   hipLaunchKernelGGL((gemm_h16_kernel<HT, BM_, 64, WM_, WN_, EPI_STORE, true, 2>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, \
                      g.N, sp.k_len, g.ep, g.splitk_ws, sp.m_pad, 0)
@@ -1037,15 +1032,6 @@ static int launch_h16(const GemmArgs& g, hipStream_t s) {
       }
     }
     if (e1) (void)hipEventRecord(e1, s);
-    WSEG_LAUNCH_CHECK();
-    return WSEG_OK;
-  }
-  // experiment knob: no split-K at >= 512 rows, 128x128 tiles with a 3-deep LDS ring and the fused epilogue
-  static const bool direct128 = getenv("WSEG_SKINNY_DIRECT128") != nullptr;
-  if (direct128 && g.M >= 512 && g.N % 128 == 0) {
-    dim3 grid(g.N / 128, cdiv(g.M, 128), 1);
-    hipLaunchKernelGGL((gemm_h16_kernel<HT, 128, 128, 2, 2, EPI, false, 3>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K, g.ep,
-                       (float*)nullptr, 0, 0);
     WSEG_LAUNCH_CHECK();
     return WSEG_OK;
   }
