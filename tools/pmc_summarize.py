@@ -3,8 +3,8 @@ import csv, json, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 windows = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 MM = windows * 500
-g = [r for r in csv.DictReader(open(f"gpurun_out/{tag}_pmc_FETCH_SIZE.csv")) if "gemm_bf16" in r["Kernel_Name"]]
-w = [r for r in csv.DictReader(open(f"gpurun_out/{tag}_pmc_WRITE_SIZE.csv")) if "gemm_bf16" in r["Kernel_Name"]]
+g = [r for r in csv.DictReader(open(f"gpurun_out/{tag}_pmc_FETCH_SIZE.csv")) if "gemm_h16" in r["Kernel_Name"] or "gemm_bf16" in r["Kernel_Name"]]
+w = [r for r in csv.DictReader(open(f"gpurun_out/{tag}_pmc_WRITE_SIZE.csv")) if "gemm_h16" in r["Kernel_Name"] or "gemm_bf16" in r["Kernel_Name"]]
 names = ["qkv", "o-proj", "fc1", "fc2", "conv2"]      # dispatch order of tools/gemm_bench.py --encoder-only (3 warm-up + 2 timed each)
 shapes = {"qkv": (MM, 3840, 1280, 0), "o-proj": (MM, 1280, 1280, 2), "fc1": (MM, 5120, 1280, 1),
           "fc2": (MM, 1280, 5120, 2), "conv2": (MM, 1280, 3840, 1)}
@@ -14,7 +14,8 @@ for i, n in enumerate(names):
     fs = [float(r["Counter_Value"]) for r in g[i * 5:(i + 1) * 5]][2:]
     ws = [float(r["Counter_Value"]) for r in w[i * 5:(i + 1) * 5]][2:]
     M, N, K, epi = shapes[n]
-    alg = (M * K + N * K + M * N * (2 if epi == 2 else 1)) * 2
+    # operands and plain outputs are 2 bytes; the residual epilogue (epi 2) reads and writes the fp32 residual stream
+    alg = (M * K + N * K) * 2 + M * N * (8 if epi == 2 else 2)
     fetch, write = 2 * 1024 * sum(fs) / len(fs), 1024 * sum(ws) / len(ws)
     out[n] = dict(M=M, N=N, K=K, algorithmic_bytes=alg, fetch_bytes=fetch, write_bytes=write, hbm_bytes=fetch + write,
                   ratio=(fetch + write) / alg)
