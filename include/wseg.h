@@ -148,6 +148,13 @@ typedef struct {
   int32_t lookahead;              /* decode steps the host may run ahead of the device; 0: 1                            */
   const int32_t* window_max_length; /* device [n_windows] per-window cap on the total length (clamped to max_length), or
                                      NULL: every window may run to max_length                                           */
+  /* Sampling (reference model.py:615-616, 662-663: do_sample = (num_beams == 1) with top_k / top_p).  Used only when
+   * num_beams == 1 and top_k > 1: the next token is drawn from softmax over the top_k processed logits, further cut to the
+   * nucleus top_p (HF TopKLogitsWarper then TopPLogitsWarper), with a counter-based generator keyed by (seed, window,
+   * position) — reproducible for a seed, but not the torch generator stream HF would consume.  top_k <= 1: argmax. */
+  int32_t top_k;                  /* 0 / 1: deterministic argmax (the reference's default top_k = 1); 2..16: sample       */
+  float top_p;                    /* nucleus mass in (0, 1]; values <= 0 or >= 1 disable the cut                          */
+  uint64_t seed;
   const void* encoder_output;     /* device [n_windows][enc_positions][d_model] in the model dtype: precomputed encoder
                                      states (wseg_encode) used instead of running the encoder on feats (feats may then
                                      be NULL; rows past the last window must be readable up to a multiple of 256), or NULL */

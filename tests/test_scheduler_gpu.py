@@ -110,3 +110,52 @@ def test_more_windows_than_slots_bounds_the_workspace(gpu_lib):
     t, l = gen(eng, x, 4, 448, n_slots=8)
     for r in range(1, 16):                               # identical windows decode identically wherever they ran
         assert torch.equal(t[4 * r:4 * r + 4], t[:4]) and torch.equal(l[4 * r:4 * r + 4], l[:4])
+
+
+def test_sampling_top_k_top_p(gpu_lib):
+    """num_beams == 1 with top_k > 1 (reference model.py:615-616: do_sample): reproducible for a seed, seed-dependent, and
+    the first sampled token follows softmax over the top_k processed logits cut to the nucleus top_p (HF TopK + TopP
+    warpers) — checked against the first-step logits over 600 seeds."""
+    eng = tiny_engine("f32")
+    x = tiny_feats(3, seed0=40)
+    kw = dict(max_length=6, num_beams=1, suppress_tokens=TM.SUPPRESS, begin_suppress_tokens=TM.BEGIN_SUPPRESS)
+    _, _, logits = eng.generate(x, TM.PROMPT, TM.EOT, TM.EOT, return_first_logits=True, **kw)
+    logits = logits.cpu().double()
+    logits[:, TM.SUPPRESS] = -float("inf")
+    logits[:, TM.BEGIN_SUPPRESS] = -float("inf")
+    a = eng.generate(x, TM.PROMPT, TM.EOT, TM.EOT, top_k=5, top_p=0.9, seed=7, **kw)[0].cpu()
+    b = eng.generate(x, TM.PROMPT, TM.EOT, TM.EOT, top_k=5, top_p=0.9, seed=7, **kw)[0].cpu()
+    assert torch.equal(a, b)
+    for top_k, top_p in ((4, 1.0), (6, 0.8)):
+        vals, idx = logits.topk(top_k, dim=1)
+        probs = torch.softmax(vals, dim=1)
+        keep = (probs.cumsum(1) - probs) < top_p                 # mass before the candidate < top_p
+        keep[:, 0] = True
+        want = torch.where(keep, probs, torch.zeros_like(probs))
+        want = want / want.sum(1, keepdim=True)
+        counts = torch.zeros_like(want)
+        n_draws = 600
+        for seed in range(n_draws):
+            t = eng.generate(x, TM.PROMPT, TM.EOT, TM.EOT, top_k=top_k, top_p=top_p, seed=seed, **kw)[0].cpu()
+            for i in range(3):
+                hit = (idx[i] == int(t[i, 3])).nonzero()
+                assert len(hit) == 1, (top_k, top_p, i, int(t[i, 3]))          # only top_k candidates are ever drawn
+                counts[i, hit[0, 0]] += 1
+        freq = counts / n_draws
+        assert (freq[~keep] == 0).all()                          # outside the nucleus: never
+        assert (freq - want).abs().max().item() < 0.07, (freq, want)   # 600 draws: 3.4 sigma of a p = 0.5 proportion
+    with pytest.raises(Exception):
+        eng.generate(x, TM.PROMPT, TM.EOT, TM.EOT, top_k=17, **kw)
+
+
+def test_segment_with_sampling_is_seeded_by_torch(gpu_lib):
+    from whisperseg_amd.model import WhisperSegmenter
+    seg = WhisperSegmenter(MODEL_DIR, device="cuda", device_ids=[0], dtype="f32")
+    audio = GI.tiny_recording(100, 3)
+    torch.manual_seed(5)
+    a = seg.segment(audio, TM.SR, num_beams=1, top_k=3, top_p=0.95)
+    torch.manual_seed(5)
+    b = seg.segment(audio, TM.SR, num_beams=1, top_k=3, top_p=0.95)
+    assert a == b and set(a) == {"onset", "offset", "cluster"}
+    with pytest.raises(NotImplementedError):
+        seg.segment(audio, TM.SR, num_beams=1, top_k=50)

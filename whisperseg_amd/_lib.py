@@ -25,7 +25,8 @@ class GenerateParams(C.Structure):
                 ("length_penalty", C.c_float), ("suppress_tokens", C.c_void_p), ("n_suppress", C.c_int32),
                 ("begin_suppress_tokens", C.c_void_p), ("n_begin_suppress", C.c_int32),
                 ("n_slots", C.c_int32), ("refill_min", C.c_int32), ("lookahead", C.c_int32),
-                ("window_max_length", C.c_void_p), ("encoder_output", C.c_void_p)]
+                ("window_max_length", C.c_void_p), ("top_k", C.c_int32), ("top_p", C.c_float), ("seed", C.c_uint64),
+                ("encoder_output", C.c_void_p)]
 
 
 class GenerateStats(C.Structure):

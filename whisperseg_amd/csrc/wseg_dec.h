@@ -22,6 +22,9 @@ struct DecodeState {
   int* win;                        // [W]   index of the window decoded in the slot (row of the output arrays)
   int* wmax;                       // [W]   total-length cap of the slot's window (<= max_length)
   const int* win_max_length;       // [n_windows] per-window caps (device) or null
+  int top_k;                       // > 1 (greedy path only): sample among the top_k processed logits
+  float top_p;                     // nucleus mass for sampling
+  unsigned long long seed;
   int* tokens_in;                  // [R]   token fed at this step
   int* run_seq;                    // [W][nb][L]
   int* fin_seq;                    // [W][nb][L]

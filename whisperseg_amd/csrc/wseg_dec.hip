@@ -643,7 +643,7 @@ __global__ __launch_bounds__(64) void row_topk_merge_kernel(DecodeState st, int 
   const int r = blockIdx.x, lane = threadIdx.x;
   if (st.done[r / st.nb]) return;
   const bool greedy = st.nb == 1;
-  const int Kc = greedy ? 1 : 2 * st.nb;
+  const int Kc = greedy ? st.top_k : 2 * st.nb;          // greedy: 1 candidate; sampling: top_k raw logits
   float mx = -3.0e38f;
   for (int s = lane; s < nseg; s += 64) mx = fmaxf(mx, part_stat[((size_t)r * nseg + s) * 2]);
   mx = wave_max(mx);
@@ -813,7 +813,30 @@ __global__ void greedy_step_kernel(DecodeState st) {
     st.pos[w] = pos + 1;
     return;
   }
-  const int tok = st.cand_tok[w];
+  int tok = st.cand_tok[(size_t)w * st.top_k];
+  if (st.top_k > 1) {
+    // HF TopKLogitsWarper + TopPLogitsWarper + multinomial over the top_k processed logits (sorted, best first):
+    // candidate j survives the nucleus cut iff the probability mass of the candidates before it is < top_p
+    const float* cv = st.cand_val + (size_t)w * st.top_k;
+    const int* ct = st.cand_tok + (size_t)w * st.top_k;
+    float pr[MAX_CAND];
+    float z = 0.f;
+    for (int j = 0; j < st.top_k; ++j) { pr[j] = expf(cv[j] - cv[0]); z += pr[j]; }      // -inf -> 0
+    const bool cut = st.top_p > 0.f && st.top_p < 1.f;
+    float kept = 0.f, before = 0.f;
+    int n_keep = 0;
+    for (int j = 0; j < st.top_k; ++j) {
+      if (j > 0 && (pr[j] <= 0.f || (cut && before >= st.top_p * z))) break;
+      kept += pr[j]; before += pr[j]; ++n_keep;
+    }
+    // counter-based uniform in [0, 1): splitmix64 of (seed, window, position)
+    unsigned long long x = st.seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)st.win[w] * 4096ull + (unsigned long long)cur_len + 1ull);
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+    const float u = (float)(x >> 40) * (1.0f / 16777216.0f) * kept;
+    float acc = 0.f;
+    tok = ct[n_keep - 1];
+    for (int j = 0; j < n_keep; ++j) { acc += pr[j]; if (u < acc) { tok = ct[j]; break; } }
+  }
   st.run_seq[(size_t)w * L + cur_len] = tok;
   st.anc[(size_t)w * L + cur_len] = 0;
   st.tokens_in[w] = tok;
@@ -912,7 +935,7 @@ static void launch_topk_t(const DecodeState& st, const float* logits, float* pv,
   hipLaunchKernelGGL((row_topk_merge_kernel<KC>), dim3(R), dim3(64), 0, s, st, nseg, pv, pi, ps);
 }
 int launch_row_topk(const DecodeState& st, const float* logits, float* part_val, int* part_idx, float* part_stat, hipStream_t s) {
-  const int Kc = st.nb == 1 ? 1 : 2 * st.nb;
+  const int Kc = st.nb == 1 ? st.top_k : 2 * st.nb;
   if (Kc == 1) launch_topk_t<1>(st, logits, part_val, part_idx, part_stat, s);
   else if (Kc <= 4) launch_topk_t<4>(st, logits, part_val, part_idx, part_stat, s);
   else if (Kc <= 8) launch_topk_t<8>(st, logits, part_val, part_idx, part_stat, s);

@@ -454,6 +454,7 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
     set_error("bad suppress-token lists"); return WSEG_ERR_INVALID;
   }
   if (gp->n_slots < 0 || gp->refill_min < 0 || gp->lookahead < 0) { set_error("bad scheduler parameters"); return WSEG_ERR_INVALID; }
+  if (nb == 1 && gp->top_k > MAX_CAND) { set_error("top_k %d unsupported (sampling draws among at most %d candidates)", gp->top_k, MAX_CAND); return WSEG_ERR_INVALID; }
   const int S = gp->n_slots > 0 && gp->n_slots < n_windows ? gp->n_slots : n_windows;      // window slots
   const int G = gp->refill_min > 0 ? gp->refill_min : (S >= 16 ? S / 8 : 1);                // admit once this many slots are free
   const int K = gp->lookahead > 0 ? (gp->lookahead < PinnedRing::N - 2 ? gp->lookahead : PinnedRing::N - 2) : 1;
@@ -465,6 +466,9 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
   st.P = P; st.eos = gp->eos_token_id; st.pad = gp->pad_token_id; st.max_length = L; st.length_penalty = gp->length_penalty;
   for (int i = 0; i < 8; ++i) st.prompt[i] = i < P ? gp->prompt[i] : 0;
   st.win_max_length = gp->window_max_length;
+  st.top_k = (nb == 1 && gp->top_k > 1) ? gp->top_k : 1;
+  st.top_p = gp->top_p;
+  st.seed = gp->seed;
   WSEG_TRY(ring_prepare(m->ring_h2d, S));
   WSEG_TRY(ring_prepare(m->ring_status, S));
 
@@ -537,6 +541,7 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
     put(&base, sizeof(base)); put(&S, 4); put(&nb, 4); put(&L, 4);
     put(&st.P, 4); put(&st.eos, 4); put(&st.pad, 4); put(&st.length_penalty, 4); put(st.prompt, sizeof(st.prompt));
     put(&st.win_max_length, sizeof(st.win_max_length));
+    put(&st.top_k, 4); put(&st.top_p, 4); put(&st.seed, 8);
   }
   auto launch_step = [&]() -> int {
     // the first generated step of a call whose windows all start together is launched eagerly with the logits snapshot

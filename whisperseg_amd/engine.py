@@ -240,9 +240,10 @@ class Engine:
 
     def generate(self, feats, prompt, eos_token_id, pad_token_id, max_length=448, num_beams=4, length_penalty=1.0,
                  suppress_tokens=(), begin_suppress_tokens=(), return_first_logits=False, n_slots=None, refill_min=0,
-                 lookahead=0, window_max_length=None, encoder_output=None):
+                 lookahead=0, window_max_length=None, encoder_output=None, top_k=1, top_p=1.0, seed=0):
         """Greedy / beam-search decode of ALL windows of `feats` [N, 80, 1000] through `n_slots` window slots with
-        in-flight refill (a finished window's slot goes to the next queued window; wseg_generate).
+        in-flight refill (a finished window's slot goes to the next queued window; wseg_generate).  `top_k` in 2..16 with
+        num_beams == 1 samples (top-k, then nucleus `top_p`) with a counter-based generator keyed by `seed`.
         Returns (tokens int32 [N, max_length] on device, lengths int32 [N])."""
         feats = feats.to(device=self.device, dtype=torch.float32).contiguous()
         W = feats.shape[0]
@@ -261,6 +262,7 @@ class Engine:
         gp.suppress_tokens, gp.n_suppress = sup.data_ptr(), len(suppress_tokens)
         gp.begin_suppress_tokens, gp.n_begin_suppress = bsup.data_ptr(), len(begin_suppress_tokens)
         gp.n_slots, gp.refill_min, gp.lookahead = int(slots), int(refill_min), int(lookahead)
+        gp.top_k, gp.top_p, gp.seed = int(top_k), float(top_p), int(seed) & (2 ** 64 - 1)      # sampling: num_beams == 1 and top_k > 1
         wml = None
         if window_max_length is not None:      # per-window total-length caps (int32 [W])
             wml = torch.as_tensor(window_max_length, dtype=torch.int32).to(self.device).contiguous()

@@ -139,9 +139,15 @@ class SegmenterBase:
         (wseg_generate); `batch_size` is accepted for API compatibility and does not cap the concurrency (the engine bounds
         its slots by device memory; $WSEG_SLOTS overrides).  Calls are chunked at POOL_WINDOWS windows only to bound the
         stacked feature tensor."""
+        sample = {}
         if num_beams == 1 and top_k != 1:
-            raise NotImplementedError("sampling (num_beams=1 with top_k != 1) is not implemented; the reference's "
-                                      "default top_k=1 is the deterministic argmax")
+            # reference model.py:615-616 / 662-663: do_sample = (num_beams == 1), i.e. multinomial sampling among the top_k
+            # (then top_p) tokens.  The draw comes from the engine's counter-based generator, seeded from torch's global
+            # generator (torch.manual_seed makes a run reproducible; the stream is not HF's).
+            if not 2 <= int(top_k) <= 16:
+                raise NotImplementedError("sampling is implemented for top_k in 2..16 (top_k=1, the reference's default, "
+                                          "is the deterministic argmax)")
+            sample = dict(top_k=int(top_k), top_p=float(top_p), seed=int(torch.randint(0, 2 ** 62, ()).item()))
         prompt = tokenizer.convert_tokens_to_ids(PROMPT_TOKENS)
         out = []
         n = len(sliced)
@@ -150,7 +156,9 @@ class SegmenterBase:
             out.append(engine.generate(batch, prompt, tokenizer.eos_token_id, tokenizer.pad_token_id,
                                        max_length=max_length, num_beams=num_beams, length_penalty=length_penalty,
                                        suppress_tokens=self.suppress_tokens,
-                                       begin_suppress_tokens=self.begin_suppress_tokens))
+                                       begin_suppress_tokens=self.begin_suppress_tokens, **sample))
+            if sample:
+                sample["seed"] += 1
             if status_monitor is not None:
                 status_monitor["progress"] = int(100 * min(1, (pos + POOL_WINDOWS) / n))
         return out
