@@ -63,9 +63,10 @@ template <> struct H16<f16_t> {
   static __device__ __forceinline__ float lo(uint32_t w) { return (float)__builtin_bit_cast(hw_f16x2, w)[0]; }
   static __device__ __forceinline__ float hi(uint32_t w) { return (float)__builtin_bit_cast(hw_f16x2, w)[1]; }
   static __device__ __forceinline__ float one(f16_t v) { return (float)__builtin_bit_cast(_Float16, v.bits); }
-  // saturating (HF clamps fp16 encoder activations the same way: modeling_whisper.py, encoder layer)
+  // round to nearest even, IEEE overflow to infinity — as torch.float16 does.  The one tensor HF protects from that in
+  // half precision is the residual stream (the clamp in modeling_whisper.py's encoder layer), which is fp32 here.
   static __device__ __forceinline__ uint32_t pack(float l, float h) {
-    const hw_f32x2 v = {__builtin_amdgcn_fmed3f(l, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(h, -65504.f, 65504.f)};
+    const hw_f32x2 v = {l, h};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_f16x2));
   }
   static __device__ __forceinline__ f16_t from(float f) { f16_t r; r.bits = (uint16_t)(pack(f, 0.f) & 0xffffu); return r; }

@@ -5,6 +5,7 @@
 // Beam semantics follow HF generation/utils.py:3208-3510 (_beam_search) and helpers :3008-3206 literally,
 // including the float32 "+ -1e9" masking arithmetic; see oracle/whisper_ref.py for the CPU restatement.
 // These kernels are HBM/latency-bound integer + VALU work (no MFMA): reads are 128-byte rows.
+#include <type_traits>
 #include "wseg_dec.h"
 
 namespace wseg {
@@ -416,6 +417,19 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
       for (int e = 0; e < 8; ++e) qq[e][0][1] = 0.f;
     }
   }
+  // IEEE-half mode: the query is exactly representable in half (it was rounded to the storage type above), so the scores are
+  // taken with v_dot2c_f32_f16 straight on the packed K words — half the VALU work of unpack + FMA, fp32 accumulation.  (The
+  // bf16 path keeps the FMA chain: it is pinned bit-equal to dec_cross_attn_kernel.)
+  constexpr bool kDot2 = std::is_same<HT, f16_t>::value;
+  typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
+  hh2 qh[NB][4];
+  if constexpr (kDot2) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2)
+        qh[j][e2] = __builtin_bit_cast(hh2, H16<f16_t>::pack(qq[2 * e2][j >> 1][j & 1], qq[2 * e2 + 1][j >> 1][j & 1]));
+  }
   for (int t0 = 0; t0 < Tk; t0 += 32 * U) {
     raw16 kr[U];
 #pragma unroll
@@ -427,21 +441,30 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
     for (int u = 0; u < U; ++u) {
       const int t = t0 + u * 32 + wave * 8 + rowl;
       // scores: the fp32 FMA chain over the 8 dims of the kernel above (bit-equal), two beams per v_pk_fma_f32
-      float kv[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { kv[2 * e] = H16<HT>::lo(kr[u][e]); kv[2 * e + 1] = H16<HT>::hi(kr[u][e]); }
-      f2 a2[NP];
-#pragma unroll
-      for (int j2 = 0; j2 < NP; ++j2) a2[j2] = (f2){0.f, 0.f};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const f2 kk = {kv[e], kv[e]};
-#pragma unroll
-        for (int j2 = 0; j2 < NP; ++j2) a2[j2] = __builtin_elementwise_fma(qq[e][j2], kk, a2[j2]);
-      }
       float a[NB];
+      if constexpr (kDot2) {
 #pragma unroll
-      for (int j = 0; j < NB; ++j) a[j] = a2[j >> 1][j & 1];
+        for (int j = 0; j < NB; ++j) a[j] = 0.f;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) a[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(hh2, kr[u][e2]), qh[j][e2], a[j], false);
+      } else {
+        float kv[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { kv[2 * e] = H16<HT>::lo(kr[u][e]); kv[2 * e + 1] = H16<HT>::hi(kr[u][e]); }
+        f2 a2[NP];
+#pragma unroll
+        for (int j2 = 0; j2 < NP; ++j2) a2[j2] = (f2){0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const f2 kk = {kv[e], kv[e]};
+#pragma unroll
+          for (int j2 = 0; j2 < NP; ++j2) a2[j2] = __builtin_elementwise_fma(qq[e][j2], kk, a2[j2]);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) a[j] = a2[j >> 1][j & 1];
+      }
       // the three DPP steps beam-interleaved: a DPP read needs wait states after the write of its source
 #pragma unroll
       for (int j = 0; j < NB; ++j) a[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[j]), 0xB1, 0xF, 0xF, true));
