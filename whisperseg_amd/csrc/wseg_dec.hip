@@ -446,9 +446,11 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
 #pragma unroll
         for (int j = 0; j < NB; ++j) a[j] = 0.f;
 #pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2)
+        for (int e2 = 0; e2 < 4; ++e2) {
+          const unsigned kw = kr[u][e2];        // (a __builtin_bit_cast straight on the vector element picks the wrong lane)
 #pragma unroll
-          for (int j = 0; j < NB; ++j) a[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(hh2, kr[u][e2]), qh[j][e2], a[j], false);
+          for (int j = 0; j < NB; ++j) a[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(hh2, kw), qh[j][e2], a[j], false);
+        }
       } else {
         float kv[8];
 #pragma unroll
