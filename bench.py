@@ -485,6 +485,21 @@ def extra_lines(args, eng, step, main_in, make_extractor, device, W, slots):
     out["segment_api_1h_recording"] = {"audio_sec_per_s": 3600.0 / dt, "seconds": dt, "windows": 120, "segments": len(pred["onset"]),
                                        "note": "host numpy PCM -> WhisperSegmenterForEval.segment(): upload, log-mel, decode, "
                                                "tokenizer, parse; EOS suppressed, fixed decode length"}
+    # the same step in the other 16-bit mode (IEEE half is the API default, bf16 is what BASELINE.json names)
+    other = "f16" if args.dtype == "bf16" else "bf16"
+    if args.dtype != "f32":
+        from whisperseg_amd.engine import DTYPES, Engine
+        eng2 = Engine(eng.geo, {k: v.to(DTYPES[other][1]) for k, v in eng.weights.items()}, eng.device, other)
+        feats = ext.extract_windows(audio, st, wl)
+
+        def other_step():
+            return eng2.generate(feats, PROMPT, EOS, EOS, max_length=3 + args.gen_tokens, num_beams=args.beams, suppress_tokens=SUPPRESS,
+                                 begin_suppress_tokens=BEGIN_SUPPRESS, n_slots=slots)
+        dt, _ = timed(other_step)
+        out[other + "_mode"] = {"audio_sec_per_s": W * 1000 * args.spec_time_step / dt, "ms_per_step": dt * 1e3,
+                                "note": "log-mel features precomputed; engine.generate only (encoder + cross-K/V + decode)"}
+        del eng2
+        torch.cuda.empty_cache()
     # in-flight batching: 8 x W windows with per-window length caps drawn from a synthetic distribution through W slots
     rng = np.random.default_rng(3)
     reps = 8

@@ -46,4 +46,4 @@ def test_16_bit_modes_stay_inside_their_measured_envelope(gpu_lib, sweep, dtype)
 
 
 # runs (of 200) allowed outside "clusters exact, boundaries within +-1 frame"; set from the measured sweeps
-MAX_BAD_RUNS = {"f16": 8, "bf16": 40}
+MAX_BAD_RUNS = {"f16": 12, "bf16": 32}      # measured (profiles/r02_parity_sweep.json): f16 10, bf16 28

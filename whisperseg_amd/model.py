@@ -24,6 +24,10 @@ from .utils import RATIO_DECODING_TIME_STEP_TO_SPEC_TIME_STEP
 from .windows import shard_bounds, window_table
 
 PROMPT_TOKENS = ["<|startoftranscript|>", "<|en|>", "<|notimestamps|>"]   # reference model.py:656
+# Engine dtype when neither the constructor nor $WHISPERSEG_AMD_DTYPE names one: IEEE half — the 16-bit mode with the
+# better parity margin against the fp32 reference (profiles/README.md, parity table) and what the reference's own GPU fast
+# path computes in (CTranslate2 float16, reference model.py:691).  "bf16" is 3-5 % faster, "f32" is the exact-parity mode.
+DEFAULT_DTYPE = "f16"
 POOL_WINDOWS = 2048      # windows per engine call / per pooled group of files (655 MB of log-mel features)
 
 
@@ -330,7 +334,7 @@ class WhisperSegmenter(SegmenterBase):
         super().__init__()
         self.device_list = _resolve_devices(device, device_ids)
         model_dir = resolve_model_dir(model_path)
-        dtype = dtype or os.environ.get("WHISPERSEG_AMD_DTYPE", "bf16")
+        dtype = dtype or os.environ.get("WHISPERSEG_AMD_DTYPE", DEFAULT_DTYPE)
         self.model_list = [Engine.from_pretrained(model_dir, device=dev, dtype=dtype) for dev in self.device_list]
         self.tokenizer_list = [WhisperSegTokenizer.from_pretrained(model_dir, language="english") for _ in self.device_list]
         hf_config = _read_json(os.path.join(model_dir, "config.json"))
@@ -355,7 +359,7 @@ class WhisperSegmenterFast(WhisperSegmenter):
     def __init__(self, model_path, device=None, device_ids=[0, ]):
         model_dir = resolve_model_dir(model_path)
         checkpoint_files(model_dir)      # raises FileNotFoundError for a CTranslate2-only directory
-        super().__init__(model_path, device=device, device_ids=device_ids, dtype="f16")
+        super().__init__(model_path, device=device, device_ids=device_ids, dtype=os.environ.get("WHISPERSEG_AMD_DTYPE", "f16"))
 
 
 class WhisperSegmenterForEval(SegmenterBase):
@@ -366,7 +370,7 @@ class WhisperSegmenterForEval(SegmenterBase):
 
     def __init__(self, model_path=None, device=None, model=None, tokenizer=None, dtype=None):
         super().__init__()
-        dtype = dtype or os.environ.get("WHISPERSEG_AMD_DTYPE", "bf16")
+        dtype = dtype or os.environ.get("WHISPERSEG_AMD_DTYPE", DEFAULT_DTYPE)
         if model_path is not None:
             self.device_list = _resolve_devices(device, [0]) if device is None or str(device) in ("cuda", "cpu") \
                 else _resolve_devices("cuda", [torch.device(device).index or 0])
