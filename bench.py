@@ -357,6 +357,10 @@ def main(argv=None, backend=make_backend):
             "end_to_end_frac": windows_per_s / world * (enc_f + ckv_f + dec_f) / MFMA_PEAK_BF16,
             "roofline": roofline, "cpu_baseline": cpu, "check": check, "extra": extra,
         }
+        try:      # libraries (RCCL's version banner) write to C stdio: flush it first so that the JSON line is the last line
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if distributed:
         torch.distributed.barrier()
