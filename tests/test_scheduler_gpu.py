@@ -159,3 +159,31 @@ def test_segment_with_sampling_is_seeded_by_torch(gpu_lib):
     assert a == b and set(a) == {"onset", "offset", "cluster"}
     with pytest.raises(NotImplementedError):
         seg.segment(audio, TM.SR, num_beams=1, top_k=50)
+
+
+def test_lookahead_and_eager_steps_give_the_same_tokens(gpu_lib):
+    """The host may run 1..6 steps ahead of the device (statuses are consumed behind events), and WSEG_NO_GRAPH=1 launches
+    every step eagerly instead of replaying the captured graph: neither may change a token."""
+    import subprocess
+    import sys
+    import tempfile
+    from conftest import ROOT
+    eng = tiny_engine("f32")
+    x = tiny_feats(11, seed0=1200)
+    ref_t, ref_l = gen(eng, x, 4, n_slots=4)
+    for la in (1, 3, 6, 50):
+        t, l = gen(eng, x, 4, n_slots=4, lookahead=la)
+        assert torch.equal(t, ref_t) and torch.equal(l, ref_l), la
+    code = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[2]); sys.path.insert(0, sys.argv[2] + "/tests")
+import test_scheduler_gpu as T
+eng = T.tiny_engine("f32")
+x = T.tiny_feats(11, seed0=1200)
+torch.save(T.gen(eng, x, 4, n_slots=4), sys.argv[1])
+'''
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "eager.pt")
+        subprocess.check_call([sys.executable, "-c", code, path, ROOT], env={**os.environ, "WSEG_NO_GRAPH": "1"})
+        t, l = torch.load(path)
+    assert torch.equal(t, ref_t) and torch.equal(l, ref_l)
