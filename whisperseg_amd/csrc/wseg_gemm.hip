@@ -183,7 +183,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 // SPLIT: write fp32 partials [z][m_pad][n] (epilogue applied later by splitk_reduce_kernel).
 template <typename HT, int BM, int BN, int WM, int WN, int EPI, bool SPLIT, int NST = 2>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_h16_kernel(const HT* __restrict__ A, int lda,
+__global__ __launch_bounds__(WM * WN * 64, (BM <= 128 && BN <= 64 && WM * WN == 4) ? 3 : 1) void gemm_h16_kernel(const HT* __restrict__ A, int lda,
                                                         const HT* __restrict__ W, int ldw,
                                                         int M, int N, int k_len, EpiParams ep,
                                                         float* __restrict__ part, int m_pad, int ntm) {
