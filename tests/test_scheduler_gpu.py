@@ -8,7 +8,9 @@ window slots, refilling a slot as soon as its window ends.  Properties checked h
   * a trained model that emits EOS after 10-40 tokens with max_length = 448 executes about as many decode steps as its
     longest window needs, not 445 (device-side idle flags + bounded host look-ahead);
   * per-window length caps behave exactly like separate calls with that max_length;
-  * the scheduler statistics add up (every window decoded once, occupancy within (0, 1])."""
+  * the scheduler statistics add up (every window decoded once, occupancy within (0, 1]);
+  * several lanes (independent slot groups stepping side by side on their own streams and host threads, one shared
+    window queue) give the tokens of one lane with the same slot count."""
 import json
 import os
 
@@ -44,6 +46,7 @@ def tiny_feats(n_recordings, seed0=300):
 
 
 def gen(eng, x, nb=4, ml=448, **kw):
+    kw.setdefault("n_lanes", 1)      # the single-lane scheduler unless a test asks for lanes (None: the engine's default)
     t, l = eng.generate(x, TM.PROMPT, TM.EOT, TM.EOT, max_length=ml, num_beams=nb, suppress_tokens=TM.SUPPRESS,
                         begin_suppress_tokens=TM.BEGIN_SUPPRESS, **kw)
     return t.cpu(), l.cpu()
@@ -71,6 +74,52 @@ def test_slot_refill_gives_the_same_tokens(gpu_lib, dtype, nb):
     for lo in range(0, 18, 6):
         tb, lb = gen(eng, x[lo:lo + 6], nb, n_slots=6)
         assert torch.equal(tb, t6[lo:lo + 6]) and torch.equal(lb, l6[lo:lo + 6]), (dtype, lo)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_lanes_give_the_same_tokens(gpu_lib, dtype):
+    eng = tiny_engine(dtype)
+    x = tiny_feats(23)
+    ref_t, ref_l = gen(eng, x, 4, n_slots=5)             # one lane of 5 slots
+    assert eng.last_stats()["n_lanes"] == 1
+    for lanes in (2, 3, 4):
+        t, l = gen(eng, x, 4, n_slots=5, n_lanes=lanes)
+        st = eng.last_stats()
+        assert st["n_lanes"] == lanes and st["n_slots"] == 5 * lanes and st["n_windows"] == 23
+        assert 0 < st["occupancy"] <= 1.0 and st["n_admissions"] >= lanes
+        assert torch.equal(l, ref_l) and torch.equal(t, ref_t), lanes
+        assert eng.last_timing()[3] == st["n_steps"]
+    # a queue shorter than the lanes' slots is split evenly: 23 windows over 2 lanes of up to 16 slots -> 12 slots each
+    t, l = gen(eng, x, 4, n_slots=16, n_lanes=2)
+    st = eng.last_stats()
+    assert st["n_slots"] == 24 and st["n_admissions"] == 2
+    one_t, one_l = gen(eng, x, 4, n_slots=12)
+    assert torch.equal(l, one_l) and torch.equal(t, one_t)
+    # the engine's default: as many full lanes as the queue fills (up to DEFAULT_MAX_LANES)
+    from whisperseg_amd.engine import DEFAULT_MAX_LANES
+    t, l = gen(eng, x, 4, n_slots=8, n_lanes=None)
+    assert eng.last_stats()["n_lanes"] == min(DEFAULT_MAX_LANES, 23 // 8)
+    one_t, one_l = gen(eng, x, 4, n_slots=8)
+    assert torch.equal(l, one_l) and torch.equal(t, one_t)
+    # on a caller stream that is not the default one, results are ordered behind the call
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        t, l = eng.generate(x.clone(), TM.PROMPT, TM.EOT, TM.EOT, max_length=448, num_beams=4, suppress_tokens=TM.SUPPRESS,
+                            begin_suppress_tokens=TM.BEGIN_SUPPRESS, n_slots=5, n_lanes=3)
+        t, l = t.cpu(), l.cpu()
+    assert torch.equal(l, ref_l) and torch.equal(t, ref_t)
+
+
+def test_lanes_reject_bad_requests(gpu_lib):
+    from whisperseg_amd import _lib
+    eng = tiny_engine("f32")
+    x = tiny_feats(3)
+    with pytest.raises(_lib.WsegError):
+        gen(eng, x, 4, n_slots=2, n_lanes=5)             # more than WSEG_MAX_LANES
+    t, l = gen(eng, x, 4, n_slots=2, n_lanes=4)          # more lanes than windows: clamped
+    assert eng.last_stats()["n_lanes"] == 3
+    ref_t, ref_l = gen(eng, x, 4)
+    assert torch.equal(l, ref_l) and torch.equal(t, ref_t)
 
 
 def test_early_stop_executes_few_steps(gpu_lib):

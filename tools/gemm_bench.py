@@ -11,6 +11,7 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--encoder-only", action="store_true")
 ap.add_argument("--decoder-only", action="store_true")
 ap.add_argument("--rotate", type=int, default=1, help="cycle through this many weight copies (cold weights, as in a decode step)")
+ap.add_argument("--vs-torch", action="store_true", help="also time torch's F.linear (hipBLASLt) on the same operands: calibration of what the box can do, never a product path")
 ap.add_argument("--shapes", default="", help="custom list 'M,N,K,epi;M,N,K,epi;...' (epi 0 bias, 1 bias+gelu, 2 bias+residual)")
 a = ap.parse_args()
 lib = _lib.load(require_device=True)
@@ -56,4 +57,15 @@ for name, m, n, k, epi in shapes:
     if epi == 2: ref = ref + res[:m].float()
     err = (out[:m].float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-9)
     gb = (m * k + n * k + m * n * (2 if epi == 2 else 1)) * 2 / 1e9
-    print(f"{name:16s} M={m:6d} N={n:6d} K={k:5d}: {us:8.1f} us  {2*m*n*k/us/1e6:7.1f} TFLOP/s  {gb/us*1e6/1e3:6.2f} TB/s  relerr {err:.1e}", flush=True)
+    lt = ""
+    if a.vs_torch:
+        Am = A[:m]
+        for _ in range(3):
+            torch.nn.functional.linear(Am, W, bias)
+        torch.cuda.synchronize(); e0.record()
+        for i in range(a.iters):
+            torch.nn.functional.linear(Am, Ws[i % len(Ws)], bias)
+        e1.record(); torch.cuda.synchronize()
+        ut = e0.elapsed_time(e1) / a.iters * 1e3
+        lt = f"  | torch F.linear (bias only) {ut:8.1f} us {2*m*n*k/ut/1e6:7.1f} TFLOP/s"
+    print(f"{name:16s} M={m:6d} N={n:6d} K={k:5d}: {us:8.1f} us  {2*m*n*k/us/1e6:7.1f} TFLOP/s  {gb/us*1e6/1e3:6.2f} TB/s  relerr {err:.1e}{lt}", flush=True)

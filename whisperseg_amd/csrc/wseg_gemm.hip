@@ -13,6 +13,7 @@
 // Both paths share one epilogue (epi_apply), also used by the split-K reduction kernel.
 #include <stdlib.h>
 #include <mutex>
+
 #include <vector>
 #include "wseg_kernels.h"
 
@@ -181,6 +182,14 @@ __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, f
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Barrier that closes the fragment reads of an LDS stage: every ds_read this wave has issued must have RETURNED before
+// the wave signals that the stage may be refilled.  A bare s_barrier only orders instruction issue; the compiler is
+// free to (and did) leave the last fragment reads in flight across it, and an LDS-DMA write of the next K tile issued by
+// another wave right after the barrier can then land before those reads execute.  On an otherwise idle chip the reads
+// win by a wide margin; with load-heavy work sharing the CU (a second stream, or this kernel's own fp32-residual
+// epilogue in a co-resident workgroup) they lost about once per 10^4 K tiles (tools/concurrency_stress.py).
+__device__ __forceinline__ void lds_reads_done_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // SPLIT: write fp32 partials [z][m_pad][n] (epilogue applied later by splitk_reduce_kernel).
 template <typename HT, int BM, int BN, int WM, int WN, int EPI, bool SPLIT, int NST = 2>
 __global__ __launch_bounds__(WM * WN * 64, (BM <= 128 && BN <= 64 && WM * WN == 4) ? 3 : 1) void gemm_h16_kernel(const HT* __restrict__ A, int lda,
@@ -279,6 +288,9 @@ __global__ __launch_bounds__(WM * WN * 64, (BM <= 128 && BN <= 64 && WM * WN == 
     for (int i = 0; i < NI; ++i) {
       bf16x8 wnxt = wcur;
       if (i + 1 < NI) wnxt = ldw(1, i + 1);
+      // every fragment of this K tile has been requested: retire the reads and release the stage, then multiply the last
+      // group (which needs the retired reads anyway) while the other waves arrive
+      if (i == NI - 1) lds_reads_done_barrier();
 #pragma unroll
       for (int j = 0; j < MI; ++j) acc[i][j] = H16<HT>::mfma16(wcur, af1[j], acc[i][j]);
       wcur = wnxt;
@@ -308,8 +320,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM <= 128 && BN <= 64 && WM * WN == 
       wait_vmcnt<NLD*(NST - 1)>();
     }
     __builtin_amdgcn_s_barrier();
-    compute(buf);
-    __builtin_amdgcn_s_barrier();
+    compute(buf);                                   // ends with lds_reads_done_barrier(): the stage may be refilled
   }
 
   // epilogue: lane holds n = nb + i*16 + fg*4 + {0..3}, m = mb + j*16 + fr
@@ -554,11 +565,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h16_persist_kernel(const HT
       for (int i = 0; i < NI; ++i) {
         bf16x8 wnxt = wcur;
         if (i + 1 < NI) wnxt = ldw_f(1, i + 1);
+        if (i == NI - 1) lds_reads_done_barrier();  // all fragment reads retired: the stage may be refilled
 #pragma unroll
         for (int j = 0; j < MI; ++j) acc[i][j] = H16<HT>::mfma16(wcur, af1[j], acc[i][j]);
         wcur = wnxt;
       }
-      __builtin_amdgcn_s_barrier();
     }
     g += nk;
     // LDS-staged epilogue in the stage consumed last ((g-1)&1); the other stage is receiving the next tile

@@ -6,7 +6,10 @@
 // kernels on the caller's stream; all decoding state lives in the caller-provided workspace.
 #include <algorithm>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "wseg_dec.h"
 
@@ -48,6 +51,22 @@ struct PinnedRing {
   int next = 0;
 };
 
+// One decode lane of wseg_generate: the scheduler state that survives between calls (pinned staging rings, timing
+// events, the captured step graph).  Lane 0 runs on the caller's stream in the caller's thread; lanes 1.. own a stream.
+struct Lane {
+  hipStream_t own_stream = nullptr;
+  hipEvent_t ev_sync = nullptr;        // fork (caller's stream -> lanes) / join (lane -> caller's stream)
+  std::vector<hipEvent_t> ev_pool;     // timing events: pairs around every encoder / cross-K/V pass
+  size_t ev_used = 0;
+  std::vector<int> ev_enc, ev_ckv;     // indices of (begin, end) pairs in ev_pool
+  PinnedRing ring_h2d, ring_status;
+  // decode-step graph (hipGraph): captured once per (workspace, geometry, parameters), replayed per step
+  hipGraphExec_t step_graph = nullptr;
+  hipStream_t cap_stream = nullptr;    // capture happens on a private stream (the legacy NULL stream cannot capture)
+  std::vector<unsigned char> step_graph_key;
+  wseg_generate_stats stats = {};
+};
+
 }  // namespace
 
 struct wseg_model {
@@ -59,19 +78,12 @@ struct wseg_model {
   const void *dec_tok, *dec_pos, *dec_ln_g, *dec_ln_b;
   std::vector<EncLayer> enc;
   std::vector<DecLayer> dec;
-  // per-stage timing of the last wseg_generate call: event pairs around every encoder / cross-K/V pass + the whole call
-  std::vector<hipEvent_t> ev_pool;
-  size_t ev_used = 0;
-  std::vector<int> ev_enc, ev_ckv;     // indices of (begin, end) pairs in ev_pool
+  std::vector<std::unique_ptr<Lane>> lanes;
+  // last wseg_generate call: whole-call event pair (in lane 0's pool), geometry, merged scheduler statistics
   int ev_total[2] = {-1, -1};
   bool timing_valid = false;
-  int last_W = 0, last_nb = 0, last_L = 0;
+  int last_W = 0, last_nb = 0, last_L = 0, last_lanes = 0;
   wseg_generate_stats stats = {};
-  PinnedRing ring_h2d, ring_status;
-  // decode-step graph (hipGraph): captured once per (workspace, geometry, parameters), replayed per step
-  hipGraphExec_t step_graph = nullptr;
-  hipStream_t cap_stream = nullptr;   // capture happens on a private stream (the legacy NULL stream cannot capture)
-  std::vector<unsigned char> step_graph_key;
 };
 
 namespace {
@@ -342,11 +354,16 @@ static void ring_free(PinnedRing& r) {
 
 extern "C" void wseg_model_destroy(wseg_model* m) {
   if (!m) return;
-  for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
-  if (m->step_graph) (void)hipGraphExecDestroy(m->step_graph);
-  if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
-  ring_free(m->ring_h2d);
-  ring_free(m->ring_status);
+  for (auto& lp : m->lanes) {
+    Lane& ln = *lp;
+    for (hipEvent_t e : ln.ev_pool) (void)hipEventDestroy(e);
+    if (ln.ev_sync) (void)hipEventDestroy(ln.ev_sync);
+    if (ln.step_graph) (void)hipGraphExecDestroy(ln.step_graph);
+    if (ln.cap_stream) (void)hipStreamDestroy(ln.cap_stream);
+    if (ln.own_stream) (void)hipStreamDestroy(ln.own_stream);
+    ring_free(ln.ring_h2d);
+    ring_free(ln.ring_status);
+  }
   delete m;
 }
 
@@ -412,55 +429,64 @@ static int ring_acquire(PinnedRing& r, int* idx) {
   *idx = i;
   return WSEG_OK;
 }
-static int h2d_list(wseg_model* m, const int* vals, int n, int* dev, hipStream_t s) {
+static int h2d_list(Lane& ln, const int* vals, int n, int* dev, hipStream_t s) {
   int i;
-  WSEG_TRY(ring_acquire(m->ring_h2d, &i));
-  int* h = m->ring_h2d.host + (size_t)i * m->ring_h2d.cap;
+  WSEG_TRY(ring_acquire(ln.ring_h2d, &i));
+  int* h = ln.ring_h2d.host + (size_t)i * ln.ring_h2d.cap;
   memcpy(h, vals, (size_t)n * sizeof(int));
   WSEG_HIP_CHECK(hipMemcpyAsync(dev, h, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
-  WSEG_HIP_CHECK(hipEventRecord(m->ring_h2d.ev[i], s));
-  m->ring_h2d.used[i] = true;
+  WSEG_HIP_CHECK(hipEventRecord(ln.ring_h2d.ev[i], s));
+  ln.ring_h2d.used[i] = true;
   return WSEG_OK;
 }
-static int timing_event(wseg_model* m, hipStream_t s, int* idx) {
-  if (m->ev_used == m->ev_pool.size()) { hipEvent_t e; WSEG_HIP_CHECK(hipEventCreate(&e)); m->ev_pool.push_back(e); }
-  *idx = (int)m->ev_used++;
-  WSEG_HIP_CHECK(hipEventRecord(m->ev_pool[*idx], s));
+static int timing_event(Lane& ln, hipStream_t s, int* idx) {
+  if (ln.ev_used == ln.ev_pool.size()) { hipEvent_t e; WSEG_HIP_CHECK(hipEventCreate(&e)); ln.ev_pool.push_back(e); }
+  *idx = (int)ln.ev_used++;
+  WSEG_HIP_CHECK(hipEventRecord(ln.ev_pool[*idx], s));
   return WSEG_OK;
 }
 
-// Decode of n_windows windows through n_slots window slots with in-flight refill (continuous batching).
+namespace {
+// The queue of windows still waiting for a slot, shared by the lanes of one wseg_generate call.
+struct WindowQueue {
+  std::mutex mu;
+  int next = 0, total = 0;
+  // Claims up to min(n_free, cap) windows for a lane under the refill rule (enough free slots, or the rest of the queue,
+  // or a lane with nothing to do).  Returns the count, *start = first claimed window, *drained = queue empty afterwards.
+  int claim(int n_free, int cap, int refill_min, bool lane_idle, int* start, bool* drained) {
+    std::lock_guard<std::mutex> lk(mu);
+    const int rem = total - next;
+    int n = rem < n_free ? rem : n_free;
+    if (n > cap) n = cap;
+    if (n > 0 && (n >= refill_min || n == rem || lane_idle)) { *start = next; next += n; }
+    else n = 0;
+    *drained = next == total;
+    return n;
+  }
+};
+}  // namespace
+
+// One lane of a wseg_generate call: decodes windows claimed from `wq` through S window slots laid out at `base`, on
+// stream s, until the queue is empty and its own slots have drained.
 //
 // The reference decodes batch by batch (model.py:653): a batch runs until its slowest window has finished.  Here a
 // finished window's slot is retired and handed to the next queued window while the other slots keep decoding: every
 // slot has its own position, every per-step kernel skips idle slots (so they cost no K/V traffic), and the captured
-// step graph never changes.  Windows are independent, so the tokens of a window do not depend on which slot it ran in
-// or on what ran beside it (row-independent kernels, fixed row count => fixed tile / split-K plan).
+// step graph never changes.  Windows are independent, so the tokens of a window do not depend on which slot (or lane)
+// it ran in or on what ran beside it (row-independent kernels, fixed row count => fixed tile / split-K plan).
 // The host runs at most `lookahead` steps ahead of the device: the per-step status mirror (done flag of every slot)
 // is read behind an event, which both bounds the wasted steps after the last window finishes and tells the scheduler
 // which slots to retire / refill.
-extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_windows, const wseg_generate_params* gp,
-                             void* workspace, size_t workspace_bytes, int32_t* out_tokens, int32_t* out_lengths,
-                             void* stream_) {
-  hipStream_t s = (hipStream_t)stream_;
-  if (!m || !gp || (!feats && !gp->encoder_output) || !workspace || !out_tokens || !out_lengths) { set_error("wseg_generate: null argument"); return WSEG_ERR_INVALID; }
-  WSEG_TRY(wseg_model_ready(m));
-  if (n_windows <= 0) return WSEG_OK;
+static int generate_lane(wseg_model* m, Lane& ln, int n_lanes, const float* feats, WindowQueue& wq,
+                         const wseg_generate_params* gp, char* base, int S, int first_cap, int32_t* out_tokens,
+                         int32_t* out_lengths, hipStream_t s) {
   const wseg_model_config& c = m->cfg;
   const int nb = gp->num_beams, P = gp->prompt_len, L = gp->max_length;
-  if (nb < 1 || nb > MAX_BEAMS) { set_error("num_beams %d unsupported (1..%d)", nb, MAX_BEAMS); return WSEG_ERR_INVALID; }
-  if (P < 1 || P > 8 || L <= P || L > c.dec_positions) { set_error("prompt_len %d / max_length %d unsupported", P, L); return WSEG_ERR_INVALID; }
-  if (gp->n_suppress < 0 || gp->n_begin_suppress < 0 || (gp->n_suppress && !gp->suppress_tokens) || (gp->n_begin_suppress && !gp->begin_suppress_tokens)) {
-    set_error("bad suppress-token lists"); return WSEG_ERR_INVALID;
-  }
-  if (gp->n_slots < 0 || gp->refill_min < 0 || gp->lookahead < 0) { set_error("bad scheduler parameters"); return WSEG_ERR_INVALID; }
-  if (nb == 1 && gp->top_k > MAX_CAND) { set_error("top_k %d unsupported (sampling draws among at most %d candidates)", gp->top_k, MAX_CAND); return WSEG_ERR_INVALID; }
-  const int S = gp->n_slots > 0 && gp->n_slots < n_windows ? gp->n_slots : n_windows;      // window slots
+  const int n_windows = wq.total;
   const int G = gp->refill_min > 0 ? gp->refill_min : (S >= 16 ? S / 8 : 1);                // admit once this many slots are free
   const int K = gp->lookahead > 0 ? (gp->lookahead < PinnedRing::N - 2 ? gp->lookahead : PinnedRing::N - 2) : 1;
   Plan p;
-  make_plan(m, S, nb, L, aligned_base(workspace), p);
-  if (p.total + 256 > workspace_bytes) { set_error("workspace too small: need %zu, have %zu", p.total + 256, workspace_bytes); return WSEG_ERR_STATE; }
+  make_plan(m, S, nb, L, base, p);
   DecPlan& q = p.dec;
   DecodeState& st = q.st;
   st.P = P; st.eos = gp->eos_token_id; st.pad = gp->pad_token_id; st.max_length = L; st.length_penalty = gp->length_penalty;
@@ -469,14 +495,9 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
   st.top_k = (nb == 1 && gp->top_k > 1) ? gp->top_k : 1;
   st.top_p = gp->top_p;
   st.seed = gp->seed;
-  WSEG_TRY(ring_prepare(m->ring_h2d, S));
-  WSEG_TRY(ring_prepare(m->ring_status, S));
-
-  m->timing_valid = false;
-  m->ev_used = 0; m->ev_enc.clear(); m->ev_ckv.clear();
-  m->stats = wseg_generate_stats();
-  m->stats.n_windows = n_windows; m->stats.n_slots = S;
-  WSEG_TRY(timing_event(m, s, &m->ev_total[0]));
+  WSEG_TRY(ring_prepare(ln.ring_h2d, S));
+  WSEG_TRY(ring_prepare(ln.ring_status, S));
+  ln.stats = wseg_generate_stats();
   WSEG_TRY(launch_build_suppress_mask((unsigned char*)q.mask, c.vocab, gp->suppress_tokens, gp->n_suppress,
                                       gp->begin_suppress_tokens, gp->n_begin_suppress, s));
   WSEG_TRY(launch_decode_reset(st, s));
@@ -489,35 +510,36 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
   std::vector<int> slot_win(S, -1), slot_from(S, 0);   // window in the slot (-1 = free), first step whose status counts for it
   std::vector<int> free_slots, tmp_a, tmp_b;
   for (int i = S - 1; i >= 0; --i) free_slots.push_back(i);   // popped from the back: lowest slot first
-  int next_win = 0, in_flight = 0, t = 0;
+  int in_flight = 0, t = 0;
+  bool drained = false;                                  // no window left in the queue (for any lane)
 
-  // encoder + cross-K/V of the next `n` queued windows into `n` free slots; their decode state starts at position 0
-  auto admit = [&](int n) -> int {
+  // encoder + cross-K/V of windows [w0, w0 + n) into n free slots; their decode state starts at position 0
+  auto admit = [&](int w0, int n) -> int {
     tmp_a.clear(); tmp_b.clear();
     for (int i = 0; i < n; ++i) {
       const int sl = free_slots.back(); free_slots.pop_back();
-      tmp_a.push_back(sl); tmp_b.push_back(next_win + i);
-      slot_win[sl] = next_win + i; slot_from[sl] = t;
+      tmp_a.push_back(sl); tmp_b.push_back(w0 + i);
+      slot_win[sl] = w0 + i; slot_from[sl] = t;
     }
-    WSEG_TRY(h2d_list(m, tmp_a.data(), n, q.adm_slots, s));
-    WSEG_TRY(h2d_list(m, tmp_b.data(), n, q.adm_wins, s));
+    WSEG_TRY(h2d_list(ln, tmp_a.data(), n, q.adm_slots, s));
+    WSEG_TRY(h2d_list(ln, tmp_b.data(), n, q.adm_wins, s));
     int e0, e1, e2;
-    WSEG_TRY(timing_event(m, s, &e0));
+    WSEG_TRY(timing_event(ln, s, &e0));
     const char* enc_rows = p.enc_out;
-    if (gp->encoder_output) enc_rows = (const char*)gp->encoder_output + (size_t)next_win * Tk * d * m->es;
-    else WSEG_TRY(run_encoder(m, feats + (size_t)next_win * feat_stride, n, p, p.enc_out, s));
-    WSEG_TRY(timing_event(m, s, &e1));
+    if (gp->encoder_output) enc_rows = (const char*)gp->encoder_output + (size_t)w0 * Tk * d * m->es;
+    else WSEG_TRY(run_encoder(m, feats + (size_t)w0 * feat_stride, n, p, p.enc_out, s));
+    WSEG_TRY(timing_event(ln, s, &e1));
     for (int l = 0; l < c.dec_layers; ++l) {     // cross-attention K/V of every decoder layer, once per window (shared by its beams)
       EpiParams e;
       e.bias = m->dec[l].ckv_b; e.k = q.ck + l * cross_stride; e.v = q.cv + l * cross_stride;
       e.d_model = d; e.t_len = Tk; e.n_heads = H; e.slot_map = q.adm_slots;
       WSEG_TRY(gemm(m, EPI_KV_CROSS, enc_rows, d, m->dec[l].ckv_w, d, n * Tk, 2 * d, d, e, nullptr, s));
     }
-    WSEG_TRY(timing_event(m, s, &e2));
-    m->ev_enc.push_back(e0); m->ev_enc.push_back(e1); m->ev_ckv.push_back(e1); m->ev_ckv.push_back(e2);
+    WSEG_TRY(timing_event(ln, s, &e2));
+    ln.ev_enc.push_back(e0); ln.ev_enc.push_back(e1); ln.ev_ckv.push_back(e1); ln.ev_ckv.push_back(e2);
     WSEG_TRY(launch_decode_admit(st, q.adm_slots, q.adm_wins, n, s));
-    next_win += n; in_flight += n;
-    m->stats.n_admissions += 1;
+    in_flight += n;
+    ln.stats.n_admissions += 1;
     return WSEG_OK;
   };
 
@@ -532,36 +554,36 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
     return WSEG_OK;
   };
   // The step reads every step-dependent value (positions, tokens, ancestry, idle flags) from device memory, so ONE
-  // captured graph serves all steps and later calls: replay costs ~1.6 us per kernel instead of ~5 us per eager launch.
+  // captured graph per lane serves all steps and later calls: replay costs ~1.6 us per kernel instead of ~5 us per
+  // eager launch.
   static const bool use_graph = getenv("WSEG_NO_GRAPH") == nullptr;
   std::vector<unsigned char> key;
   {
     auto put = [&](const void* ptr, size_t n) { const unsigned char* b = (const unsigned char*)ptr; key.insert(key.end(), b, b + n); };
-    void* base = aligned_base(workspace);
     put(&base, sizeof(base)); put(&S, 4); put(&nb, 4); put(&L, 4);
     put(&st.P, 4); put(&st.eos, 4); put(&st.pad, 4); put(&st.length_penalty, 4); put(st.prompt, sizeof(st.prompt));
     put(&st.win_max_length, sizeof(st.win_max_length));
     put(&st.top_k, 4); put(&st.top_p, 4); put(&st.seed, 8);
   }
   auto launch_step = [&]() -> int {
-    // the first generated step of a call whose windows all start together is launched eagerly with the logits snapshot
-    // (wseg_debug_first_logits); every other step replays the graph
-    const bool snap = t == P - 1 && n_windows <= S;
+    // the first generated step of a single-lane call whose windows all start together is launched eagerly with the
+    // logits snapshot (wseg_debug_first_logits); every other step replays the graph
+    const bool snap = n_lanes == 1 && t == P - 1 && n_windows <= S;
     if (snap || !use_graph) return enqueue_step(snap, s);
-    if (!m->step_graph || m->step_graph_key != key) {
-      if (m->step_graph) { (void)hipGraphExecDestroy(m->step_graph); m->step_graph = nullptr; }
+    if (!ln.step_graph || ln.step_graph_key != key) {
+      if (ln.step_graph) { (void)hipGraphExecDestroy(ln.step_graph); ln.step_graph = nullptr; }
       hipGraph_t graph = nullptr;
-      if (!m->cap_stream) WSEG_HIP_CHECK(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
-      WSEG_HIP_CHECK(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
-      const int rc = enqueue_step(false, m->cap_stream);
-      const hipError_t ec = hipStreamEndCapture(m->cap_stream, &graph);
+      if (!ln.cap_stream) WSEG_HIP_CHECK(hipStreamCreateWithFlags(&ln.cap_stream, hipStreamNonBlocking));
+      WSEG_HIP_CHECK(hipStreamBeginCapture(ln.cap_stream, hipStreamCaptureModeThreadLocal));
+      const int rc = enqueue_step(false, ln.cap_stream);
+      const hipError_t ec = hipStreamEndCapture(ln.cap_stream, &graph);
       if (rc != WSEG_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
       if (ec != hipSuccess) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ec)); return WSEG_ERR_HIP; }
-      WSEG_HIP_CHECK(hipGraphInstantiate(&m->step_graph, graph, nullptr, nullptr, 0));
+      WSEG_HIP_CHECK(hipGraphInstantiate(&ln.step_graph, graph, nullptr, nullptr, 0));
       (void)hipGraphDestroy(graph);
-      m->step_graph_key = key;
+      ln.step_graph_key = key;
     }
-    WSEG_HIP_CHECK(hipGraphLaunch(m->step_graph, s));
+    WSEG_HIP_CHECK(hipGraphLaunch(ln.step_graph, s));
     return WSEG_OK;
   };
 
@@ -570,9 +592,9 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
   bool step_queued[PinnedRing::N];             // were windows still waiting in the queue when the step was launched?
   auto consume_status = [&](int u) -> int {      // retire every slot that step u left finished
     const int ri = status_idx[u % PinnedRing::N];
-    WSEG_HIP_CHECK(hipEventSynchronize(m->ring_status.ev[ri]));
-    m->ring_status.used[ri] = false;
-    const int* done = m->ring_status.host + (size_t)ri * m->ring_status.cap;
+    WSEG_HIP_CHECK(hipEventSynchronize(ln.ring_status.ev[ri]));
+    ln.ring_status.used[ri] = false;
+    const int* done = ln.ring_status.host + (size_t)ri * ln.ring_status.cap;
     tmp_a.clear();
     int active = 0;
     for (int sl = 0; sl < S; ++sl) {
@@ -580,14 +602,14 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
       if (done[sl]) { tmp_a.push_back(sl); slot_win[sl] = -1; }
       else ++active;
     }
-    m->stats.slot_steps_active += active + (int64_t)tmp_a.size();
+    ln.stats.slot_steps_active += active + (int64_t)tmp_a.size();
     if (step_queued[u % PinnedRing::N]) {
-      m->stats.queued_slot_steps_active += active + (int64_t)tmp_a.size();
-      m->stats.queued_slot_steps_total += S;
+      ln.stats.queued_slot_steps_active += active + (int64_t)tmp_a.size();
+      ln.stats.queued_slot_steps_total += S;
     }
     if (!tmp_a.empty()) {
       const int n = (int)tmp_a.size();
-      WSEG_TRY(h2d_list(m, tmp_a.data(), n, q.ret_slots, s));
+      WSEG_TRY(h2d_list(ln, tmp_a.data(), n, q.ret_slots, s));
       WSEG_TRY(launch_finalize(st, q.ret_slots, n, out_tokens, out_lengths, s));
       for (int sl : tmp_a) free_slots.push_back(sl);
       std::sort(free_slots.begin(), free_slots.end(), [](int a, int b) { return a > b; });
@@ -597,12 +619,17 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
   };
 
   int consumed = 0;                               // statuses of steps [0, consumed) have been processed
+  bool first = true;
   while (true) {
-    const int remaining = n_windows - next_win, n_free = (int)free_slots.size();
-    const int n_adm = remaining < n_free ? remaining : n_free;
-    if (n_adm > 0 && (n_adm >= G || n_adm == remaining || in_flight == 0)) WSEG_TRY(admit(n_adm));
+    if (!drained) {
+      // a lane's first claim is capped at its even share of a short queue, so that the lanes start balanced
+      int w0 = 0;
+      const int n_adm = wq.claim((int)free_slots.size(), first ? first_cap : S, G, in_flight == 0, &w0, &drained);
+      first = false;
+      if (n_adm > 0) WSEG_TRY(admit(w0, n_adm));
+    }
     if (in_flight == 0) break;
-    if (remaining == n_adm) {     // nothing left to admit later: stop launching once every window in flight must have ended
+    if (drained) {                // nothing left to admit later: stop launching once every window in flight must have ended
       bool may_run = false;       // (a window admitted before step f feeds its last position, L - 2, at step f + L - 2)
       for (int sl = 0; sl < S && !may_run; ++sl) may_run = slot_win[sl] >= 0 && t < slot_from[sl] + L - 1;
       if (!may_run) break;
@@ -610,24 +637,108 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
     WSEG_TRY(launch_step());
     {   // mirror the idle flags of this step
       int ri;
-      WSEG_TRY(ring_acquire(m->ring_status, &ri));
-      WSEG_HIP_CHECK(hipMemcpyAsync(m->ring_status.host + (size_t)ri * m->ring_status.cap, st.done, (size_t)S * sizeof(int),
+      WSEG_TRY(ring_acquire(ln.ring_status, &ri));
+      WSEG_HIP_CHECK(hipMemcpyAsync(ln.ring_status.host + (size_t)ri * ln.ring_status.cap, st.done, (size_t)S * sizeof(int),
                                     hipMemcpyDeviceToHost, s));
-      WSEG_HIP_CHECK(hipEventRecord(m->ring_status.ev[ri], s));
-      m->ring_status.used[ri] = true;
+      WSEG_HIP_CHECK(hipEventRecord(ln.ring_status.ev[ri], s));
+      ln.ring_status.used[ri] = true;
       status_idx[t % PinnedRing::N] = ri;
-      step_queued[t % PinnedRing::N] = next_win < n_windows;
+      step_queued[t % PinnedRing::N] = !drained;
     }
     ++t;
-    m->stats.slot_steps_total += S;
+    ln.stats.slot_steps_total += S;
     // stay at most K steps ahead of the device
     while (consumed < t - K) WSEG_TRY(consume_status(consumed++));
   }
   while (consumed < t) WSEG_TRY(consume_status(consumed++));
   if (in_flight != 0) { set_error("scheduler ended with %d windows in flight", in_flight); return WSEG_ERR_STATE; }
-  WSEG_TRY(timing_event(m, s, &m->ev_total[1]));
-  m->stats.n_steps = t;
-  m->last_W = S; m->last_nb = nb; m->last_L = L;
+  ln.stats.n_steps = t;
+  return WSEG_OK;
+}
+
+// Decode of n_windows windows: n_lanes lanes of n_slots window slots each, all claiming windows from one queue.
+// Lanes are independent decode loops on separate streams (lane 0: the caller's stream and thread; lanes 1..: a stream
+// and a host thread of their own for the duration of the call).  A decode step alternates short latency-bound GEMM
+// launches with HBM-bound attention launches, so two or three lanes stepping side by side fill each other's gaps
+// (profiles/README.md: 2 x 256 slots decode 512 windows 13 % faster than one lane of 256 or of 512 slots).
+extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_windows, const wseg_generate_params* gp,
+                             void* workspace, size_t workspace_bytes, int32_t* out_tokens, int32_t* out_lengths,
+                             void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (!m || !gp || (!feats && !gp->encoder_output) || !workspace || !out_tokens || !out_lengths) { set_error("wseg_generate: null argument"); return WSEG_ERR_INVALID; }
+  WSEG_TRY(wseg_model_ready(m));
+  if (n_windows <= 0) return WSEG_OK;
+  const wseg_model_config& c = m->cfg;
+  const int nb = gp->num_beams, P = gp->prompt_len, L = gp->max_length;
+  if (nb < 1 || nb > MAX_BEAMS) { set_error("num_beams %d unsupported (1..%d)", nb, MAX_BEAMS); return WSEG_ERR_INVALID; }
+  if (P < 1 || P > 8 || L <= P || L > c.dec_positions) { set_error("prompt_len %d / max_length %d unsupported", P, L); return WSEG_ERR_INVALID; }
+  if (gp->n_suppress < 0 || gp->n_begin_suppress < 0 || (gp->n_suppress && !gp->suppress_tokens) || (gp->n_begin_suppress && !gp->begin_suppress_tokens)) {
+    set_error("bad suppress-token lists"); return WSEG_ERR_INVALID;
+  }
+  if (gp->n_slots < 0 || gp->refill_min < 0 || gp->lookahead < 0 || gp->n_lanes < 0 || gp->n_lanes > WSEG_MAX_LANES) {
+    set_error("bad scheduler parameters"); return WSEG_ERR_INVALID;
+  }
+  if (nb == 1 && gp->top_k > MAX_CAND) { set_error("top_k %d unsupported (sampling draws among at most %d candidates)", gp->top_k, MAX_CAND); return WSEG_ERR_INVALID; }
+  int NL = gp->n_lanes > 1 ? gp->n_lanes : 1;
+  if (NL > n_windows) NL = n_windows;
+  const int share = (n_windows + NL - 1) / NL;                                               // even split of a short queue
+  const int S = gp->n_slots > 0 && gp->n_slots < share ? gp->n_slots : share;               // window slots per lane
+  Plan p;
+  make_plan(m, S, nb, L, nullptr, p);
+  const size_t lane_bytes = p.total;                                                         // a multiple of 256
+  if (lane_bytes * NL + 256 > workspace_bytes) {
+    set_error("workspace too small: need %d x %zu + 256, have %zu", NL, lane_bytes, workspace_bytes); return WSEG_ERR_STATE;
+  }
+  while ((int)m->lanes.size() < NL) m->lanes.emplace_back(new Lane());
+  int dev = 0;
+  WSEG_HIP_CHECK(hipGetDevice(&dev));
+  for (int g = 0; g < NL; ++g) {
+    Lane& ln = *m->lanes[g];
+    ln.ev_used = 0; ln.ev_enc.clear(); ln.ev_ckv.clear();
+    if (!ln.ev_sync) WSEG_HIP_CHECK(hipEventCreateWithFlags(&ln.ev_sync, hipEventDisableTiming));
+    if (g > 0 && !ln.own_stream) WSEG_HIP_CHECK(hipStreamCreateWithFlags(&ln.own_stream, hipStreamNonBlocking));
+  }
+  m->timing_valid = false;
+  Lane& l0 = *m->lanes[0];
+  WSEG_TRY(timing_event(l0, s, &m->ev_total[0]));
+  if (NL > 1) {     // the other lanes start behind everything already queued on the caller's stream
+    WSEG_HIP_CHECK(hipEventRecord(l0.ev_sync, s));
+    for (int g = 1; g < NL; ++g) WSEG_HIP_CHECK(hipStreamWaitEvent(m->lanes[g]->own_stream, l0.ev_sync, 0));
+  }
+  WindowQueue wq;
+  wq.total = n_windows;
+  char* base = aligned_base(workspace);
+  std::vector<int> rc(NL, WSEG_OK);
+  std::vector<std::string> err(NL);
+  std::vector<std::thread> threads;
+  for (int g = 1; g < NL; ++g)
+    threads.emplace_back([&, g]() {
+      if (hipSetDevice(dev) != hipSuccess) { rc[g] = WSEG_ERR_HIP; err[g] = "hipSetDevice failed in a lane thread"; return; }
+      rc[g] = generate_lane(m, *m->lanes[g], NL, feats, wq, gp, base + (size_t)g * lane_bytes, S, share, out_tokens, out_lengths,
+                            m->lanes[g]->own_stream);
+      if (rc[g] != WSEG_OK) err[g] = wseg_last_error();
+    });
+  rc[0] = generate_lane(m, l0, NL, feats, wq, gp, base, S, share, out_tokens, out_lengths, s);
+  if (rc[0] != WSEG_OK) err[0] = wseg_last_error();
+  for (std::thread& th : threads) th.join();
+  for (int g = 1; g < NL; ++g) {   // the caller's stream continues behind every lane
+    WSEG_HIP_CHECK(hipEventRecord(m->lanes[g]->ev_sync, m->lanes[g]->own_stream));
+    WSEG_HIP_CHECK(hipStreamWaitEvent(s, m->lanes[g]->ev_sync, 0));
+  }
+  for (int g = 0; g < NL; ++g)
+    if (rc[g] != WSEG_OK) { set_error("%s", err[g].c_str()); return rc[g]; }
+  WSEG_TRY(timing_event(l0, s, &m->ev_total[1]));
+  wseg_generate_stats& T = m->stats;
+  T = wseg_generate_stats();
+  T.n_windows = n_windows; T.n_slots = S * NL; T.n_lanes = NL;
+  for (int g = 0; g < NL; ++g) {
+    const wseg_generate_stats& a = m->lanes[g]->stats;
+    T.n_steps = a.n_steps > T.n_steps ? a.n_steps : T.n_steps;
+    T.n_admissions += a.n_admissions;
+    T.slot_steps_active += a.slot_steps_active; T.slot_steps_total += a.slot_steps_total;
+    T.queued_slot_steps_active += a.queued_slot_steps_active; T.queued_slot_steps_total += a.queued_slot_steps_total;
+  }
+  m->last_W = S; m->last_nb = nb; m->last_L = L; m->last_lanes = NL;
   m->timing_valid = true;
   return WSEG_OK;
 }
@@ -635,7 +746,7 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
 extern "C" int wseg_debug_first_logits(wseg_model* m, void* workspace, float* out, int32_t n_rows, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   if (!m || !workspace || !out || n_rows <= 0) { set_error("wseg_debug_first_logits: bad argument"); return WSEG_ERR_INVALID; }
-  if (m->last_W <= 0 || n_rows > m->last_W * m->last_nb || m->stats.n_windows > m->stats.n_slots) {
+  if (m->last_W <= 0 || m->last_lanes != 1 || n_rows > m->last_W * m->last_nb || m->stats.n_windows > m->stats.n_slots) {
     set_error("no matching wseg_generate call (all windows must have started together)"); return WSEG_ERR_STATE;
   }
   Plan p;
@@ -648,20 +759,28 @@ extern "C" int wseg_debug_first_logits(wseg_model* m, void* workspace, float* ou
 extern "C" int wseg_last_timing(const wseg_model* m, float out[4]) {
   if (!m || !out) { set_error("wseg_last_timing: null argument"); return WSEG_ERR_INVALID; }
   if (!m->timing_valid) { set_error("no completed wseg_generate call to time"); return WSEG_ERR_STATE; }
-  WSEG_HIP_CHECK(hipEventSynchronize(m->ev_pool[m->ev_total[1]]));
-  auto sum_pairs = [&](const std::vector<int>& v, float* acc) -> int {
+  const std::vector<hipEvent_t>& pool0 = m->lanes[0]->ev_pool;
+  WSEG_HIP_CHECK(hipEventSynchronize(pool0[m->ev_total[1]]));
+  // Sum of the event pairs of every lane, divided by the lane count: with one lane the stage times add up to the call;
+  // with several lanes (which overlap in time) they are per-lane averages.
+  auto sum_pairs = [&](bool enc, float* acc) -> int {
     *acc = 0.f;
-    for (size_t i = 0; i + 1 < v.size(); i += 2) {
-      float ms = 0.f;
-      WSEG_HIP_CHECK(hipEventElapsedTime(&ms, m->ev_pool[v[i]], m->ev_pool[v[i + 1]]));
-      *acc += ms;
+    for (int g = 0; g < m->last_lanes; ++g) {
+      const Lane& ln = *m->lanes[g];
+      const std::vector<int>& v = enc ? ln.ev_enc : ln.ev_ckv;
+      for (size_t i = 0; i + 1 < v.size(); i += 2) {
+        float ms = 0.f;
+        WSEG_HIP_CHECK(hipEventElapsedTime(&ms, ln.ev_pool[v[i]], ln.ev_pool[v[i + 1]]));
+        *acc += ms;
+      }
     }
+    *acc /= (float)m->last_lanes;
     return WSEG_OK;
   };
   float total = 0.f;
-  WSEG_TRY(sum_pairs(m->ev_enc, &out[0]));
-  WSEG_TRY(sum_pairs(m->ev_ckv, &out[1]));
-  WSEG_HIP_CHECK(hipEventElapsedTime(&total, m->ev_pool[m->ev_total[0]], m->ev_pool[m->ev_total[1]]));
+  WSEG_TRY(sum_pairs(true, &out[0]));
+  WSEG_TRY(sum_pairs(false, &out[1]));
+  WSEG_HIP_CHECK(hipEventElapsedTime(&total, pool0[m->ev_total[0]], pool0[m->ev_total[1]]));
   out[2] = total - out[0] - out[1];
   out[3] = (float)m->stats.n_steps;
   return WSEG_OK;
