@@ -511,25 +511,49 @@ def extra_lines(args, eng, step, main_in, make_extractor, device, W, slots):
     lens = rng.integers(4, 2 * args.gen_tokens + 1, size=nq).astype(np.int32) + 3
     audio_q = torch.cat([audio] * reps)
     st_q = (torch.arange(nq, dtype=torch.int64) * wl).to(device)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    tk, ln, _ = step(audio=audio_q, win_starts=st_q, gen_tokens=2 * args.gen_tokens, window_max_length=lens)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    stats = eng.last_stats()
+    def queued(**kw):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = step(audio=audio_q, win_starts=st_q, gen_tokens=2 * args.gen_tokens, window_max_length=lens, **kw)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, r, eng.last_stats()
+    queued(n_lanes=2)                                   # graph capture / workspace growth of the second lane
+    dt1, (tk, ln, _), stats = queued(n_lanes=1)        # one lane of W slots
+    dt2, (tk2, ln2, _), stats2 = queued(n_lanes=2)     # two lanes of W slots stepping side by side (the engine's default here)
     # the same windows decoded batch by batch as the reference does (model.py:653): every batch runs to its longest window
     t0 = time.perf_counter()
-    resb = [step(audio=audio_q, win_starts=st_q[lo:lo + W], gen_tokens=2 * args.gen_tokens, window_max_length=lens[lo:lo + W])
+    resb = [step(audio=audio_q, win_starts=st_q[lo:lo + W], gen_tokens=2 * args.gen_tokens, window_max_length=lens[lo:lo + W], n_lanes=1)
             for lo in range(0, nq, W)]
     torch.cuda.synchronize()
     dtb = time.perf_counter() - t0
     same = all(np.array_equal(r[0], tk[i * W:(i + 1) * W]) and np.array_equal(r[1], ln[i * W:(i + 1) * W]) for i, r in enumerate(resb))
-    out["inflight_batching"] = {"windows": nq, "slots": slots, "length_caps": f"uniform 4..{2 * args.gen_tokens} generated tokens",
-                                "audio_sec_per_s": nq * 1000 * args.spec_time_step / dt,
+    same2 = bool(np.array_equal(tk, tk2) and np.array_equal(ln, ln2))
+    asec = nq * 1000 * args.spec_time_step
+    out["inflight_batching"] = {"windows": nq, "slots_per_lane": slots, "length_caps": f"uniform 4..{2 * args.gen_tokens} generated tokens",
+                                "audio_sec_per_s": asec / dt2, "lanes": stats2["n_lanes"],
+                                "one_lane_audio_sec_per_s": asec / dt1,
                                 "occupancy_while_windows_are_queued": stats["steady_occupancy"], "occupancy_overall": stats["occupancy"],
                                 "steps": stats["n_steps"], "admissions": stats["n_admissions"],
-                                "batch_by_batch_audio_sec_per_s": nq * 1000 * args.spec_time_step / dtb,
-                                "tokens_identical_to_batch_by_batch": bool(same)}
+                                "two_lanes": {"occupancy_while_windows_are_queued": stats2["steady_occupancy"], "steps": stats2["n_steps"],
+                                              "admissions": stats2["n_admissions"]},
+                                "batch_by_batch_audio_sec_per_s": asec / dtb,
+                                "tokens_identical_to_batch_by_batch": bool(same), "two_lanes_tokens_identical_to_one_lane": same2}
+    # lanes on a plain queue: 4 x W windows, fixed decode length, one lane against two
+    audio_4 = torch.cat([audio] * 4)
+    st_4 = (torch.arange(4 * W, dtype=torch.int64) * wl).to(device)
+    res = {}
+    for lanes in (1, 2):
+        step(audio=audio_4, win_starts=st_4, n_lanes=lanes)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = step(audio=audio_4, win_starts=st_4, n_lanes=lanes)
+        torch.cuda.synchronize()
+        res[lanes] = (time.perf_counter() - t0, r)
+    out["decode_lanes"] = {"windows": 4 * W, "slots_per_lane": slots,
+                           "one_lane_audio_sec_per_s": 4 * W * 1000 * args.spec_time_step / res[1][0],
+                           "two_lanes_audio_sec_per_s": 4 * W * 1000 * args.spec_time_step / res[2][0],
+                           "tokens_identical": bool(np.array_equal(res[1][1][0], res[2][1][0]) and np.array_equal(res[1][1][1], res[2][1][1])),
+                           "note": "two independent slot groups stepping on their own streams fill each other's launch gaps"}
     return out
 
 
