@@ -116,6 +116,35 @@ def test_two_layer_256_windows_1024_rows_vs_oracle(gpu_lib, two_layer):
     assert agree >= 0.9, agree
 
 
+def test_two_layer_1024_windows_4096_rows(gpu_lib, two_layer):
+    """The engine's default slot count (1024 windows x 4 beams = 4096 decode rows): the decoder-step GEMMs then run on the
+    large-tile kernels (q|k|v and fc1 on the 256x256 ping-pong kernel with their decode epilogues) instead of the split-K
+    stream family of the 1024-row test.  First-step logits of all 4096 rows against the exact-parity f32 mode (run 256
+    windows at a time: it does not depend on the slot count) and against the same 16-bit engine at 256 slots."""
+    cfg, rc, sd, engines = two_layer
+    x = feats(1024, seed=11)
+    ref_logits, ref_tok = [], []
+    for lo in range(0, 1024, 256):
+        t, l, g = gen(engines["f32"], x[lo:lo + 256], 4, 8, return_first_logits=True, n_slots=256)
+        ref_logits.append(g.cpu()); ref_tok.append(t.cpu())
+    g32, t32 = torch.cat(ref_logits), torch.cat(ref_tok)
+    for dt, cos_min in (("bf16", 0.999), ("f16", 0.99999)):
+        t, l, g = gen(engines[dt], x, 4, 8, return_first_logits=True, n_slots=1024, n_lanes=1)
+        assert engines[dt].last_stats()["n_slots"] == 1024
+        g, t = g.cpu(), t.cpu()
+        assert torch.nn.functional.cosine_similarity(g, g32, dim=1).min().item() > cos_min, dt
+        assert torch.equal(g[0::4], g[2::4])                      # the beams of a window are identical at the first step
+        assert float((t[:, 3] == t32[:, 3]).float().mean()) >= (0.9 if dt == "bf16" else 0.97), dt
+        small = []
+        for lo in range(0, 1024, 256):
+            small.append(gen(engines[dt], x[lo:lo + 256], 4, 8, return_first_logits=True, n_slots=256, n_lanes=1)[2].cpu())
+        small = torch.cat(small)
+        assert torch.nn.functional.cosine_similarity(g, small, dim=1).min().item() > (0.9999 if dt == "bf16" else 0.999999), dt
+        # run to run identical at this row count
+        t2, l2 = gen(engines[dt], x, 4, 8, n_slots=1024, n_lanes=1)
+        assert torch.equal(t2.cpu(), t) and torch.equal(l2.cpu(), l.cpu())
+
+
 @pytest.fixture(scope="module")
 def full_large():
     from whisperseg_amd.engine import Engine

@@ -9,6 +9,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="large"); ap.add_argument("--windows", type=int, default=8)
 ap.add_argument("--gen", type=int, default=32); ap.add_argument("--beams", type=int, default=4)
 ap.add_argument("--iters", type=int, default=3); ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--slots", type=int, default=0, help="window slots (default: one per window, single lane)")
 a = ap.parse_args()
 g = GEO[a.model]
 cfg = dict(d_model=g["d"], encoder_attention_heads=g["h"], decoder_attention_heads=g["h"], encoder_layers=g["L"], decoder_layers=g["L"],
@@ -18,7 +19,8 @@ feats = torch.randn(a.windows, 80, 1000, device="cuda") * 0.5
 prompt, eos = [50258, 50259, 50363], 50257
 for it in range(a.iters):
     torch.cuda.synchronize(); t0 = time.time()
-    toks, lens = eng.generate(feats, prompt, eos, eos, max_length=3 + a.gen, num_beams=a.beams, suppress_tokens=[eos, 1, 2], begin_suppress_tokens=[220])
+    toks, lens = eng.generate(feats, prompt, eos, eos, max_length=3 + a.gen, num_beams=a.beams, suppress_tokens=[eos, 1, 2], begin_suppress_tokens=[220],
+                                n_slots=a.slots or a.windows, n_lanes=1)
     torch.cuda.synchronize(); dt = time.time() - t0
     enc, ckv, dec, steps = eng.last_timing()
     print(f"iter {it}: total {dt*1e3:.1f} ms | enc {enc:.1f} ckv {ckv:.1f} dec {dec:.1f} ms over {int(steps)} steps ({dec/max(steps,1):.3f} ms/step) | {a.windows/dt:.1f} windows/s", flush=True)

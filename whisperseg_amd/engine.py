@@ -25,9 +25,12 @@ DEFAULT_SUPPRESS_TOKENS = [
     18956, 20075, 21675, 22520, 26130, 26161, 26435, 28279, 29464, 31650, 32302, 32470, 36865, 42863, 47425, 49870,
     50254, 50258, 50358, 50359, 50360, 50361, 50362]
 DEFAULT_BEGIN_SUPPRESS_TOKENS = [220, 50257]
-DEFAULT_SLOTS = 256     # window slots decoded concurrently per lane (in-flight batching; include/wseg.h)
+# Window slots decoded concurrently (in-flight batching; include/wseg.h).  Throughput grows with the concurrency until
+# ~1024 windows (whisperseg-large, 4 beams: 14.2 / 15.9 / 17.0 k audio-sec/s at 256 / 512 / 1024 slots — more GEMM rows per
+# weight pass, less launch tail in the attention streams); 1024 slots are a 154 GB workspace, sized for 288 GB of HBM.
+DEFAULT_SLOTS = 1024
 MAX_LANES = 4           # WSEG_MAX_LANES
-DEFAULT_MAX_LANES = 2   # lanes used by default when the queue fills them (each with DEFAULT_SLOTS slots)
+DEFAULT_MAX_LANES = 1   # lanes are equivalent to the same total slot count in one lane (profiles/README.md): off by default
 
 
 def _round_up(v, a):
@@ -220,8 +223,8 @@ class Engine:
 
     def pick_slots(self, n_windows, num_beams, max_length, n_slots=None, n_lanes=None):
         """(slots per lane, lanes) for a generate call.  Slots: min(n_windows, cap) where cap is `n_slots`, else
-        $WSEG_SLOTS, else 256.  Lanes: `n_lanes`, else $WSEG_LANES, else as many full lanes as the queue fills, up to
-        DEFAULT_MAX_LANES (lanes only pay when each steps a full set of slots: profiles/README.md).  Lanes are dropped,
+        $WSEG_SLOTS, else DEFAULT_SLOTS.  Lanes: `n_lanes`, else $WSEG_LANES, else as many full lanes as the queue fills, up
+        to DEFAULT_MAX_LANES (1: lanes measure the same as one lane with their total slot count).  Lanes are dropped,
         then slots halved, until the workspace (cross-K/V + encoder activations, ~150 MB per slot for whisperseg-large)
         fits in 80 % of the free device memory (plus what this engine's current workspace already holds)."""
         cap = int(n_slots or os.environ.get("WSEG_SLOTS", 0) or DEFAULT_SLOTS)

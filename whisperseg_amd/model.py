@@ -28,7 +28,7 @@ PROMPT_TOKENS = ["<|startoftranscript|>", "<|en|>", "<|notimestamps|>"]   # refe
 # better parity margin against the fp32 reference (profiles/README.md, parity table) and what the reference's own GPU fast
 # path computes in (CTranslate2 float16, reference model.py:691).  "bf16" is 3-5 % faster, "f32" is the exact-parity mode.
 DEFAULT_DTYPE = "f16"
-POOL_WINDOWS = 2048      # windows per engine call / per pooled group of files (655 MB of log-mel features)
+POOL_WINDOWS = 8192      # windows per engine call / per pooled group of files (2.6 GB of log-mel features)
 
 
 def _read_json(path, default=None):
