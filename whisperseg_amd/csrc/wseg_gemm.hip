@@ -1011,7 +1011,14 @@ static int launch_h16(const GemmArgs& g, hipStream_t s) {
     // windows: 4 beats 2 by 2-8 % on the K = 1280 shapes, 6 and 8 lose on K = 5120.
     static const int group_m = getenv("WSEG_GEMM_GROUP_M") ? atoi(getenv("WSEG_GEMM_GROUP_M")) : 4;
     const int n_cu = device_cu_count();
-    if (big256 && g.N % 256 == 0 && (long)cdiv(g.M, 256) * (g.N / 256) >= 192) {
+    // 256x256 tiles need whole rounds of the chip: with fewer than 4 rounds, a last round that leaves more than a fifth of
+    // the CUs idle costs more than the smaller tile's lower arithmetic intensity (decoder fc1 at 4096 rows: 320 tiles =
+    // 1.25 rounds, 118 us against 1280 tiles of 128x128 in 2.5 rounds of 512 workgroups).
+    const long nt256 = (long)cdiv(g.M, 256) * (g.N / 256);
+    const long rounds256 = (nt256 + n_cu - 1) / n_cu;
+    static const bool quant_rule = getenv("WSEG_GEMM_NO_QUANT_RULE") == nullptr;   // tuning knob
+    const bool ragged256 = quant_rule && rounds256 < 4 && nt256 * 5 < rounds256 * n_cu * 4;
+    if (big256 && g.N % 256 == 0 && nt256 >= 192 && !ragged256) {
       const int ntm = cdiv(g.M, 256), ntiles = ntm * (g.N / 256);
       static const bool pingpong = getenv("WSEG_GEMM_NO_PP") == nullptr;   // ping-pong kernel by default (tuning knob)
       if (pingpong && g.K >= 128) {
@@ -1104,7 +1111,10 @@ int launch_gemm_resid_ln(int dtype, const GemmArgs& g0, const void* gamma, const
   if (dtype != WSEG_F32 && !big && g.splitk_ws && d % 8 == 0 && d <= 2048 && g.ep.bias && g.ep.resid == g.ep.out && g.ep.ldc == d &&
       g.K % 64 == 0 && g.N % 64 == 0) {
     SkinnyPlan sp = plan_skinny(g);
-    if ((size_t)sp.splits * sp.m_pad * g.N * sizeof(float) <= g.splitk_ws_bytes) {
+    static const bool fuse_unsplit = getenv("WSEG_RESID_LN_ALWAYS_PARTIAL") == nullptr;   // tuning knob
+    // K not split (enough row tiles to fill the chip, 2048+ rows): the fp32 partial round trip buys nothing; the GEMM adds
+    // the residual in its own epilogue and a LayerNorm launch follows (2048 rows: 21.6 + ~6 us against 26.7 + 8.9 us)
+    if ((sp.splits > 1 || !fuse_unsplit) && (size_t)sp.splits * sp.m_pad * g.N * sizeof(float) <= g.splitk_ws_bytes) {
       if (dtype == WSEG_BF16) {
         WSEG_TRY_(launch_skinny_partial<bf16_t>(g, sp, s));
         hipLaunchKernelGGL(splitk_reduce_resid_ln_kernel<bf16_t>, dim3(g.M), dim3(256), 0, s, g.splitk_ws, sp.splits, sp.m_pad, g.M, d,
