@@ -331,10 +331,17 @@ def main(argv=None, backend=make_backend):
         check = self_check(args, eng, step, main_in, hashes, W)
     extra = None
     if on_gpu and rank == 0 and world == 1 and not args.no_extra and args.model == "large":
-        extra = extra_lines(args, eng, step, main_in, make_extractor, device, W, slots)
+        try:      # supplementary lines must never cost the contract line
+            extra = extra_lines(args, eng, step, main_in, make_extractor, device, W, slots)
+        except Exception as exc:
+            extra = {"error": f"{type(exc).__name__}: {exc}"[:500]}
+            torch.cuda.synchronize()
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, sr, sts, win_len)
+        try:
+            cpu = cpu_baseline(args, sr, sts, win_len)
+        except Exception as exc:
+            cpu = {"error": f"{type(exc).__name__}: {exc}"[:500]}
 
     failed = bool(check and not check["ok"])
     if rank == 0:
@@ -505,59 +512,65 @@ def extra_lines(args, eng, step, main_in, make_extractor, device, W, slots):
                                 "note": "log-mel features precomputed; engine.generate only (encoder + cross-K/V + decode)"}
         del eng2
         torch.cuda.empty_cache()
-    # in-flight batching: 16 x W windows with per-window length caps drawn from a synthetic distribution
-    rng = np.random.default_rng(3)
-    reps = 16
-    nq = reps * W
-    lens = rng.integers(4, 2 * args.gen_tokens + 1, size=nq).astype(np.int32) + 3
-    audio_q = torch.cat([audio] * reps)
-    st_q = (torch.arange(nq, dtype=torch.int64) * wl).to(device)
-    from whisperseg_amd.engine import DEFAULT_SLOTS
+    def big_queues():
+        # in-flight batching: 16 x W windows with per-window length caps drawn from a synthetic distribution
+        rng = np.random.default_rng(3)
+        reps = 16
+        nq = reps * W
+        lens = rng.integers(4, 2 * args.gen_tokens + 1, size=nq).astype(np.int32) + 3
+        audio_q = torch.cat([audio] * reps)
+        st_q = (torch.arange(nq, dtype=torch.int64) * wl).to(device)
+        from whisperseg_amd.engine import DEFAULT_SLOTS
 
-    def queued(**kw):
-        torch.cuda.synchronize()
+        def queued(**kw):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = step(audio=audio_q, win_starts=st_q, gen_tokens=2 * args.gen_tokens, window_max_length=lens, **kw)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, r, eng.last_stats()
+        queued(n_slots=DEFAULT_SLOTS, n_lanes=1)                                # graph capture / workspace growth
+        dtd, (tkd, lnd, _), statsd = queued(n_slots=DEFAULT_SLOTS, n_lanes=1)   # the engine's default slot count
+        dt1, (tk, ln, _), stats = queued(n_slots=W, n_lanes=1)                  # W slots, as in the timed step
+        # the same windows decoded batch by batch as the reference does (model.py:653): every batch runs to its longest window
         t0 = time.perf_counter()
-        r = step(audio=audio_q, win_starts=st_q, gen_tokens=2 * args.gen_tokens, window_max_length=lens, **kw)
+        resb = [step(audio=audio_q, win_starts=st_q[lo:lo + W], gen_tokens=2 * args.gen_tokens, window_max_length=lens[lo:lo + W], n_lanes=1)
+                for lo in range(0, nq, W)]
         torch.cuda.synchronize()
-        return time.perf_counter() - t0, r, eng.last_stats()
-    queued(n_slots=DEFAULT_SLOTS, n_lanes=1)                                # graph capture / workspace growth
-    dtd, (tkd, lnd, _), statsd = queued(n_slots=DEFAULT_SLOTS, n_lanes=1)   # the engine's default slot count
-    dt1, (tk, ln, _), stats = queued(n_slots=W, n_lanes=1)                  # W slots, as in the timed step
-    # the same windows decoded batch by batch as the reference does (model.py:653): every batch runs to its longest window
-    t0 = time.perf_counter()
-    resb = [step(audio=audio_q, win_starts=st_q[lo:lo + W], gen_tokens=2 * args.gen_tokens, window_max_length=lens[lo:lo + W], n_lanes=1)
-            for lo in range(0, nq, W)]
-    torch.cuda.synchronize()
-    dtb = time.perf_counter() - t0
-    same = all(np.array_equal(r[0], tk[i * W:(i + 1) * W]) and np.array_equal(r[1], ln[i * W:(i + 1) * W]) for i, r in enumerate(resb))
-    asec = nq * 1000 * args.spec_time_step
-    agree = float(np.mean([np.array_equal(tkd[i, :lnd[i]], tk[i, :ln[i]]) for i in range(nq)]))
-    out["inflight_batching"] = {"windows": nq, "length_caps": f"uniform 4..{2 * args.gen_tokens} generated tokens",
-                                "audio_sec_per_s": asec / dtd, "slots": statsd["n_slots"],
-                                "occupancy_while_windows_are_queued": statsd["steady_occupancy"], "occupancy_overall": statsd["occupancy"],
-                                "steps": statsd["n_steps"], "admissions": statsd["n_admissions"],
-                                f"with_{W}_slots": {"audio_sec_per_s": asec / dt1, "occupancy_while_windows_are_queued": stats["steady_occupancy"],
-                                                    "occupancy_overall": stats["occupancy"], "steps": stats["n_steps"],
-                                                    "admissions": stats["n_admissions"],
-                                                    "tokens_identical_to_batch_by_batch": bool(same)},
-                                "batch_by_batch_audio_sec_per_s": asec / dtb, "batch": W,
-                                "windows_with_tokens_identical_across_slot_counts": agree,
-                                "note": "in the 16-bit modes a window's tokens may depend on the slot COUNT (GEMM plans follow the row "
-                                        "count), never on its neighbours; identical in f32 mode (tests/test_scheduler_gpu.py)"}
-    # concurrency: 4 x W windows of fixed decode length through W, 2W, 4W slots (one lane) and as two lanes of 2W slots
-    audio_4 = torch.cat([audio] * 4)
-    st_4 = (torch.arange(4 * W, dtype=torch.int64) * wl).to(device)
-    conc = {}
-    for name, kw in ((f"{W}_slots", dict(n_slots=W, n_lanes=1)), (f"{2 * W}_slots", dict(n_slots=2 * W, n_lanes=1)),
-                     (f"{4 * W}_slots", dict(n_slots=4 * W, n_lanes=1)), (f"2_lanes_of_{2 * W}_slots", dict(n_slots=2 * W, n_lanes=2))):
-        step(audio=audio_4, win_starts=st_4, **dict(kw))
+        dtb = time.perf_counter() - t0
+        same = all(np.array_equal(r[0], tk[i * W:(i + 1) * W]) and np.array_equal(r[1], ln[i * W:(i + 1) * W]) for i, r in enumerate(resb))
+        asec = nq * 1000 * args.spec_time_step
+        agree = float(np.mean([np.array_equal(tkd[i, :lnd[i]], tk[i, :ln[i]]) for i in range(nq)]))
+        out["inflight_batching"] = {"windows": nq, "length_caps": f"uniform 4..{2 * args.gen_tokens} generated tokens",
+                                    "audio_sec_per_s": asec / dtd, "slots": statsd["n_slots"],
+                                    "occupancy_while_windows_are_queued": statsd["steady_occupancy"], "occupancy_overall": statsd["occupancy"],
+                                    "steps": statsd["n_steps"], "admissions": statsd["n_admissions"],
+                                    f"with_{W}_slots": {"audio_sec_per_s": asec / dt1, "occupancy_while_windows_are_queued": stats["steady_occupancy"],
+                                                        "occupancy_overall": stats["occupancy"], "steps": stats["n_steps"],
+                                                        "admissions": stats["n_admissions"],
+                                                        "tokens_identical_to_batch_by_batch": bool(same)},
+                                    "batch_by_batch_audio_sec_per_s": asec / dtb, "batch": W,
+                                    "windows_with_tokens_identical_across_slot_counts": agree,
+                                    "note": "in the 16-bit modes a window's tokens may depend on the slot COUNT (GEMM plans follow the row "
+                                            "count), never on its neighbours; identical in f32 mode (tests/test_scheduler_gpu.py)"}
+        # concurrency: 4 x W windows of fixed decode length through W, 2W, 4W slots (one lane) and as two lanes of 2W slots
+        audio_4 = torch.cat([audio] * 4)
+        st_4 = (torch.arange(4 * W, dtype=torch.int64) * wl).to(device)
+        conc = {}
+        for name, kw in ((f"{W}_slots", dict(n_slots=W, n_lanes=1)), (f"{2 * W}_slots", dict(n_slots=2 * W, n_lanes=1)),
+                         (f"{4 * W}_slots", dict(n_slots=4 * W, n_lanes=1)), (f"2_lanes_of_{2 * W}_slots", dict(n_slots=2 * W, n_lanes=2))):
+            step(audio=audio_4, win_starts=st_4, **dict(kw))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            step(audio=audio_4, win_starts=st_4, **dict(kw))
+            torch.cuda.synchronize()
+            conc[name] = {"audio_sec_per_s": 4 * W * 1000 * args.spec_time_step / (time.perf_counter() - t0)}
+        out["concurrency"] = dict(conc, windows=4 * W, note="whole step() incl. log-mel and the CPU epilogue; lanes = independent slot groups "
+                                                            "on their own streams: equivalent to one lane with their total slot count")
+    try:      # the two long-queue lines need the 1024-slot workspace (154 GB): report instead of failing when it does not fit
+        big_queues()
+    except Exception as exc:
+        out["big_queues_error"] = f"{type(exc).__name__}: {exc}"[:500]
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        step(audio=audio_4, win_starts=st_4, **dict(kw))
-        torch.cuda.synchronize()
-        conc[name] = {"audio_sec_per_s": 4 * W * 1000 * args.spec_time_step / (time.perf_counter() - t0)}
-    out["concurrency"] = dict(conc, windows=4 * W, note="whole step() incl. log-mel and the CPU epilogue; lanes = independent slot groups "
-                                                        "on their own streams: equivalent to one lane with their total slot count")
     return out
 
 
