@@ -110,6 +110,25 @@ def test_lanes_give_the_same_tokens(gpu_lib, dtype):
     assert torch.equal(l, ref_l) and torch.equal(t, ref_t)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_default_slot_count_with_a_long_queue(gpu_lib, dtype):
+    """1 100 windows (23 distinct recordings repeated) through the engine's default 1 024 slots: copies of a window give the
+    same tokens wherever they ran (first batch, refilled slot, drain), in every mode; in f32 mode they also equal the
+    one-slot-per-window result of the 23 originals."""
+    from whisperseg_amd.engine import DEFAULT_SLOTS
+    eng = tiny_engine(dtype)
+    base = tiny_feats(23)
+    x = base.repeat(48, 1, 1)[:1100]
+    t, l = gen(eng, x, 4, n_slots=None)
+    st = eng.last_stats()
+    assert st["n_slots"] == min(DEFAULT_SLOTS, 1100) and st["n_windows"] == 1100 and st["n_lanes"] == 1
+    for i in range(23, 1100):
+        assert int(l[i]) == int(l[i % 23]) and torch.equal(t[i], t[i % 23]), (dtype, i)
+    if dtype == "f32":
+        ref_t, ref_l = gen(eng, base, 4)
+        assert torch.equal(l[:23], ref_l) and torch.equal(t[:23], ref_t)
+
+
 def test_lanes_reject_bad_requests(gpu_lib):
     from whisperseg_amd import _lib
     eng = tiny_engine("f32")
