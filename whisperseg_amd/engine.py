@@ -27,7 +27,9 @@ DEFAULT_SUPPRESS_TOKENS = [
 DEFAULT_BEGIN_SUPPRESS_TOKENS = [220, 50257]
 # Window slots decoded concurrently (in-flight batching; include/wseg.h).  Throughput grows with the concurrency until
 # ~1024 windows (whisperseg-large, 4 beams: 14.2 / 15.9 / 17.0 k audio-sec/s at 256 / 512 / 1024 slots — more GEMM rows per
-# weight pass, less launch tail in the attention streams); 1024 slots are a 154 GB workspace, sized for 288 GB of HBM.
+# weight pass, less launch tail in the attention streams); the workspace is 118 MiB per slot at 35
+# decode positions and 376 MiB at max_length 448 (self-attention cache for the longest allowed sequence), so pick_slots ends at
+# 1024 slots for short decodes and 512 for segment()'s default max_length on a 288 GB part.
 DEFAULT_SLOTS = 1024
 MAX_LANES = 4           # WSEG_MAX_LANES
 DEFAULT_MAX_LANES = 1   # lanes are equivalent to the same total slot count in one lane (profiles/README.md): off by default
@@ -225,7 +227,8 @@ class Engine:
         """(slots per lane, lanes) for a generate call.  Slots: min(n_windows, cap) where cap is `n_slots`, else
         $WSEG_SLOTS, else DEFAULT_SLOTS.  Lanes: `n_lanes`, else $WSEG_LANES, else as many full lanes as the queue fills, up
         to DEFAULT_MAX_LANES (1: lanes measure the same as one lane with their total slot count).  Lanes are dropped,
-        then slots halved, until the workspace (cross-K/V + encoder activations, ~150 MB per slot for whisperseg-large)
+        then slots halved, until the workspace (whisperseg-large, 4 beams: 82 MiB of cross-K/V + 0.58 MiB of self-K/V per position + 16 MiB of
+        activations per slot)
         fits in 80 % of the free device memory (plus what this engine's current workspace already holds)."""
         cap = int(n_slots or os.environ.get("WSEG_SLOTS", 0) or DEFAULT_SLOTS)
         s = max(1, min(int(n_windows), cap))
