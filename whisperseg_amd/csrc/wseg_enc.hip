@@ -127,8 +127,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 // Encoder attention, bf16 MFMA.
 // ------------------------------------------------------------------------------------------------
-// __launch_bounds__(256, 4): 128 registers (no spill) instead of 166, i.e. 4 instead of 3 workgroups per CU: 847 -> 767 us per
-// layer at 256 windows; 5 per CU spills.  (Fewer VALU instructions at 2 per CU measured SLOWER: the kernel lives on occupancy.)
+// __launch_bounds__(256, 4): at most 128 registers, i.e. 4 instead of 3 workgroups per CU (847 -> 767 us per layer at 256
+// windows; fewer VALU instructions at 2 per CU measured SLOWER: the kernel lives on occupancy).  Under that cap the
+// register-prefetched K chunks were spilled to scratch directly behind their loads (PMC WRITE_SIZE showed 3.9x the
+// algorithmic output bytes); with K prefetched by LDS-DMA instead the kernel has no scratch: 767 -> 571 us per layer.
 template <typename HT>
 __global__ __launch_bounds__(256, 4) void enc_attention_h16_kernel(const HT* __restrict__ Q, const HT* __restrict__ K,
                                                                 const HT* __restrict__ Vt, HT* __restrict__ out,
@@ -136,9 +138,10 @@ __global__ __launch_bounds__(256, 4) void enc_attention_h16_kernel(const HT* __r
   // [key][64 hd], 16-B slots XOR ((key >> 1) & 7): a 32-row MFMA fragment read (lane = row + 32*half) is serviced in the
   // lane groups {0-3,12-15,20-27}, ... and needs 16 distinct (row & 1, slot) pairs per group — XOR (key & 7), right for
   // 16-row fragments, was 2-way conflicted here (SQ_LDS_BANK_CONFLICT 44 % of LDS cycles)
-  __shared__ __attribute__((aligned(16))) HT sK[64 * 64];
+  __shared__ __attribute__((aligned(16))) HT sK[2][64 * 64];   // double-buffered: filled by LDS-DMA, no registers in between
   __shared__ __attribute__((aligned(16))) HT sV[64 * 64];   // [hd][64 keys], 8-B granules XOR ((hd >> 1) & 15)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const int qi = lane & 31, g2 = lane >> 5;
@@ -156,30 +159,44 @@ __global__ __launch_bounds__(256, 4) void enc_attention_h16_kernel(const HT* __r
   float m_run = -1.0e30f, l_run = 0.f;
 
   const int n_tiles = (T + 63) / 64;
-  // K tile and V^T tile (each 8 KiB): 512 16-byte chunks per tile, 2 per thread; the NEXT tile's chunks are loaded into
-  // registers while the current tile is multiplied (rows are padded to Tp, so a tile is always readable)
-  uint4 kreg[2], vreg[2];
+  // K tile and V^T tile (each 8 KiB = 512 16-byte chunks, 2 per thread; rows are padded to Tp, so a tile is always readable).
+  // The NEXT tile is requested while the current one is multiplied: K by LDS-DMA straight into the other sK buffer (the
+  // swizzle is applied on the source side: LDS slot c holds global slot (c & 7) ^ ((row >> 1) & 7) of its row), V^T into 8
+  // registers (its 8-byte-granule swizzle is finer than a DMA element).  Keeping the K chunks in registers as well made the
+  // compiler spill them right behind their loads (a scratch store that waits for the load: the prefetch was serialised).
+  uint4 v0, v1;
   auto fetch = [&](int kt) {
+    const HT* ksrc = Kb + (size_t)(kt * 64) * 64;
+    HT* kdst = sK[kt & 1];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int c = tid + i * 256, row = c >> 3, sl = c & 7;
-      kreg[i] = *(const uint4*)(Kb + (size_t)(kt * 64 + row) * 64 + sl * 8);
-      vreg[i] = *(const uint4*)(Vb + (size_t)row * Tp + kt * 64 + sl * 8);
+      const int c = tid + i * 256, row = c >> 3, sl = (c & 7) ^ ((row >> 1) & 7);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + row * 64 + sl * 8),
+                                       (__attribute__((address_space(3))) void*)(kdst + (i * 256 + wave * 64) * 8), 16, 0, 0);
+    }
+    {
+      const int r0 = tid >> 3, sl = tid & 7;
+      v0 = *(const uint4*)(Vb + (size_t)r0 * Tp + kt * 64 + sl * 8);
+      v1 = *(const uint4*)(Vb + (size_t)(r0 + 32) * Tp + kt * 64 + sl * 8);
     }
   };
   fetch(0);
   for (int kt = 0; kt < n_tiles; ++kt) {
-    __syncthreads();
+    const HT* cK = sK[kt & 1];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's K chunks have landed in LDS, its V chunks in v0 / v1
+    __syncthreads();                                      // ... everyone's; and every wave is done with sV of the last tile
+    {
+      const int r0 = tid >> 3, sl = tid & 7;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + i * 256, row = c >> 3, sl = c & 7;
-      *(uint4*)(sK + row * 64 + ((sl ^ ((row >> 1) & 7)) << 3)) = kreg[i];
-      const int sw = (row >> 1) & 15;
-      *(uint2*)(sV + row * 64 + (((2 * sl) ^ sw) << 2)) = make_uint2(vreg[i].x, vreg[i].y);
-      *(uint2*)(sV + row * 64 + (((2 * sl + 1) ^ sw) << 2)) = make_uint2(vreg[i].z, vreg[i].w);
+      for (int i = 0; i < 2; ++i) {
+        const int row = r0 + i * 32, sw = (row >> 1) & 15;
+        const uint4 vv = i == 0 ? v0 : v1;
+        *(uint2*)(sV + row * 64 + (((2 * sl) ^ sw) << 2)) = make_uint2(vv.x, vv.y);
+        *(uint2*)(sV + row * 64 + (((2 * sl + 1) ^ sw) << 2)) = make_uint2(vv.z, vv.w);
+      }
     }
     __syncthreads();
-    if (kt + 1 < n_tiles) fetch(kt + 1);
+    if (kt + 1 < n_tiles) fetch(kt + 1);                  // the other sK buffer was last read two barriers ago
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       const int key_base = kt * 64 + sub * 32;
@@ -191,7 +208,7 @@ __global__ __launch_bounds__(256, 4) void enc_attention_h16_kernel(const HT* __r
       const int krow = sub * 32 + qi;
 #pragma unroll
       for (int hs = 0; hs < 4; ++hs) {
-        const bf16x8 kf = *(const bf16x8*)(sK + krow * 64 + (((hs * 2 + g2) ^ ((krow >> 1) & 7)) << 3));
+        const bf16x8 kf = *(const bf16x8*)(cK + krow * 64 + (((hs * 2 + g2) ^ ((krow >> 1) & 7)) << 3));
         s = H16<HT>::mfma32(kf, qf[hs], s);
       }
       if (key_base + 32 > T) {
