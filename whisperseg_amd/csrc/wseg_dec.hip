@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
 // reads 8 consecutive rows = 1 KiB fully coalesced per instruction and 4 rows are in flight per lane.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int NB>
-__global__ __launch_bounds__(256, 5) void dec_cross_attn_kernel(DecodeState st, const T* __restrict__ q, const T* __restrict__ ck,
+__global__ __launch_bounds__(256, 4) void dec_cross_attn_kernel(DecodeState st, const T* __restrict__ q, const T* __restrict__ ck,
                                                              const T* __restrict__ cv, T* __restrict__ out, int H, int Tk, int d,
                                                              PartialInfo pi, const T* __restrict__ q_bias, float scale) {
   __shared__ float sc[NB][512];
