@@ -82,3 +82,48 @@ def test_pingpong_gemm_matches_torch(gpu_lib, M, N, K, epi):
             ref = ref + res[lo:hi].float()
         worst = max(worst, (outs[0][lo:hi].float() - ref).abs().max().item())
     assert worst <= 2e-2, worst                                # O(1) outputs rounded to bf16 (2^-9 relative)
+
+
+F32_BIG_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[2])
+from whisperseg_amd import _lib
+lib = _lib.load(require_device=True)
+outs = []
+for (M, N, K, epi) in ((8192, 1280, 1280, 0), (8100, 1280, 5120, 2), (33000, 640, 256, 1)):
+    g = torch.Generator(device="cuda").manual_seed(M + epi)
+    mp = (M + 255) // 256 * 256
+    A = torch.rand(mp, K, device="cuda", generator=g) * 2 - 1
+    W = torch.rand(N, K, device="cuda", generator=g) * 2 - 1
+    b = torch.rand(N, device="cuda", generator=g)
+    r = torch.rand(mp, N, device="cuda", generator=g)
+    o = torch.zeros(mp, N, device="cuda")
+    _lib.check(lib.wseg_debug_gemm(0, epi, M, N, K, A.data_ptr(), W.data_ptr(), b.data_ptr(), r.data_ptr(), o.data_ptr(), None, 0,
+                                   _lib.stream_ptr()))
+    ref = A[:M].double() @ W.double().T + b.double()
+    if epi == 1: ref = torch.nn.functional.gelu(ref)
+    if epi == 2: ref = ref + r[:M].double()
+    assert (o[:M].double() - ref).abs().max().item() < 2e-3, (M, N, K, epi)
+    assert float(o[M:].abs().max()) == 0.0 if mp > M else True          # rows past M are not written
+    outs.append(o[:M].cpu())
+torch.save(outs, sys.argv[1])
+"""
+
+
+def test_f32_big_tile_kernel_is_bit_identical_to_the_64x64_kernel(gpu_lib, tmp_path):
+    """The exact-parity mode's large problems run on a 128x128-tile kernel (8x8 outputs per thread); like the 64x64 kernel it
+    computes every output as one fmaf chain in k order, so the two must agree bit for bit (WSEG_F32_GEMM_64=1 forces the small
+    kernel; the knob is read once per process, hence the two child processes)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "f32big.py"
+    script.write_text(F32_BIG_SCRIPT)
+    outs = []
+    for name, env in (("big", {}), ("small", {"WSEG_F32_GEMM_64": "1"})):
+        out = tmp_path / f"{name}.pt"
+        subprocess.check_call([sys.executable, str(script), str(out), root], env={**os.environ, **env})
+        outs.append(torch.load(out))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -827,6 +827,75 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   }
 }
 
+// f32 exact kernel for large problems: 128x128 tile, 8x8 micro-tile per thread (twice the FMAs per LDS float of the 64x64
+// kernel, which is LDS-bound at ~30 % of the fp32 VALU peak), next K slab prefetched into registers under the FMAs.  Every
+// output element is still ONE fmaf chain over k = 0, 1, 2, ... — bit-identical to gemm_f32_kernel, whatever the tiling.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f32_big_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                              int M, int N, int K, EpiParams ep) {
+  constexpr int BK = 16, LD = 128 + 4;
+  __shared__ float sA[2][BK][LD];
+  __shared__ float sW[2][BK][LD];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  // loads: 128 rows x 16 k per operand = 512 float4, two per thread: rows lr and lr + 64, k offset lq
+  const int lr = tid >> 2, lq = (tid & 3) * 4;
+  const float* ap = A + (size_t)(m0 + lr) * lda + lq;
+  const float* wp = W + (size_t)(n0 + lr) * ldw + lq;
+  const size_t a64 = (size_t)64 * lda, w64 = (size_t)64 * ldw;
+  float4 ra0 = *(const float4*)ap, ra1 = *(const float4*)(ap + a64);
+  float4 rw0 = *(const float4*)wp, rw1 = *(const float4*)(wp + w64);
+  auto stage = [&](int b) {
+    sA[b][lq + 0][lr] = ra0.x; sA[b][lq + 1][lr] = ra0.y; sA[b][lq + 2][lr] = ra0.z; sA[b][lq + 3][lr] = ra0.w;
+    sA[b][lq + 0][lr + 64] = ra1.x; sA[b][lq + 1][lr + 64] = ra1.y; sA[b][lq + 2][lr + 64] = ra1.z; sA[b][lq + 3][lr + 64] = ra1.w;
+    sW[b][lq + 0][lr] = rw0.x; sW[b][lq + 1][lr] = rw0.y; sW[b][lq + 2][lr] = rw0.z; sW[b][lq + 3][lr] = rw0.w;
+    sW[b][lq + 0][lr + 64] = rw1.x; sW[b][lq + 1][lr + 64] = rw1.y; sW[b][lq + 2][lr + 64] = rw1.z; sW[b][lq + 3][lr + 64] = rw1.w;
+  };
+  stage(0);
+  __syncthreads();
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 acc2[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc2[i][j] = (f2){0.f, 0.f};
+  const int nk = K / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int b = kt & 1;
+    if (kt + 1 < nk) {
+      ra0 = *(const float4*)(ap + (kt + 1) * BK); ra1 = *(const float4*)(ap + a64 + (kt + 1) * BK);
+      rw0 = *(const float4*)(wp + (kt + 1) * BK); rw1 = *(const float4*)(wp + w64 + (kt + 1) * BK);
+    }
+#pragma unroll 2
+    for (int k = 0; k < BK; ++k) {          // (a full unroll hoists all 64 LDS reads and spills)
+      // rows ty*4 + {0..3} and 64 + ty*4 + {0..3}; columns tx*4 + {0..3} and 64 + tx*4 + {0..3}: 16-byte LDS reads
+      const float4 a0 = *(const float4*)&sA[b][k][ty * 4], a1 = *(const float4*)&sA[b][k][64 + ty * 4];
+      const float4 w0 = *(const float4*)&sW[b][k][tx * 4], w1 = *(const float4*)&sW[b][k][64 + tx * 4];
+      const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      const f2 w2[4] = {{w0.x, w0.y}, {w0.z, w0.w}, {w1.x, w1.y}, {w1.z, w1.w}};
+      // two columns per v_pk_fma_f32 (each half is an IEEE fma: same bits as fmaf)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f2 aa = {a[i], a[i]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc2[i][j] = __builtin_elementwise_fma(aa, w2[j], acc2[i][j]);
+      }
+    }
+    if (kt + 1 < nk) stage(b ^ 1);          // the other buffer was last read before the barrier that closed slab kt - 1
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + (i >> 2) * 64 + ty * 4 + (i & 3);
+    if (m < M) {
+      float v0[4] = {acc2[i][0][0], acc2[i][0][1], acc2[i][1][0], acc2[i][1][1]};
+      float v1[4] = {acc2[i][2][0], acc2[i][2][1], acc2[i][3][0], acc2[i][3][1]};
+      epi_apply<EPI, float>(ep, m, n0 + tx * 4, v0);
+      epi_apply<EPI, float>(ep, m, n0 + 64 + tx * 4, v1);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Live profiler of the dominant kernel (wseg_profile_begin / wseg_profile_end)
 // ------------------------------------------------------------------------------------------------
@@ -1076,6 +1145,14 @@ static int launch_h16(const GemmArgs& g, hipStream_t s) {
 template <int EPI>
 static int launch_f32(const GemmArgs& g, hipStream_t s) {
   if (g.K % 16 || g.N % 64) { set_error("gemm f32: K %d / N %d not tile multiples", g.K, g.N); return WSEG_ERR_INVALID; }
+  static const bool big_ok = getenv("WSEG_F32_GEMM_64") == nullptr;      // test knob: always the 64x64 kernel
+  if (big_ok && g.N % 128 == 0 && (long)cdiv(g.M, 128) * (g.N / 128) >= 2L * device_cu_count()) {
+    // (same results bit for bit: one fmaf chain in k order per output element in both kernels)
+    dim3 gridb(g.N / 128, cdiv(g.M, 128));
+    hipLaunchKernelGGL((gemm_f32_big_kernel<EPI>), gridb, dim3(256), 0, s, (const float*)g.A, g.lda, (const float*)g.W, g.ldw, g.M, g.N, g.K, g.ep);
+    WSEG_LAUNCH_CHECK();
+    return WSEG_OK;
+  }
   dim3 grid(g.N / 64, cdiv(g.M, 64));
   hipLaunchKernelGGL((gemm_f32_kernel<EPI>), grid, dim3(256), 0, s, (const float*)g.A, g.lda, (const float*)g.W, g.ldw, g.M, g.N, g.K, g.ep);
   WSEG_LAUNCH_CHECK();
