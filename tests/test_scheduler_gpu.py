@@ -85,14 +85,16 @@ def test_lanes_give_the_same_tokens(gpu_lib, dtype):
     for lanes in (2, 3, 4):
         t, l = gen(eng, x, 4, n_slots=5, n_lanes=lanes)
         st = eng.last_stats()
-        assert st["n_lanes"] == lanes and st["n_slots"] == 5 * lanes and st["n_windows"] == 23
-        assert 0 < st["occupancy"] <= 1.0 and st["n_admissions"] >= lanes
-        assert torch.equal(l, ref_l) and torch.equal(t, ref_t), lanes
+        assert st["n_lanes"] == lanes and st["n_slots"] == 5 * lanes and st["n_windows"] == 23, st
+        # every lane makes its first claim behind a start gate, so each of them admits at least once
+        assert 0 < st["occupancy"] <= 1.0 and st["n_admissions"] >= lanes, st
+        assert torch.equal(l, ref_l), (lanes, l.tolist(), ref_l.tolist())
+        assert torch.equal(t, ref_t), (lanes, (t != ref_t).any(1).nonzero().flatten().tolist())
         assert eng.last_timing()[3] == st["n_steps"]
     # a queue shorter than the lanes' slots is split evenly: 23 windows over 2 lanes of up to 16 slots -> 12 slots each
     t, l = gen(eng, x, 4, n_slots=16, n_lanes=2)
     st = eng.last_stats()
-    assert st["n_slots"] == 24 and st["n_admissions"] == 2
+    assert st["n_slots"] == 24 and st["n_admissions"] == 2, st
     one_t, one_l = gen(eng, x, 4, n_slots=12)
     assert torch.equal(l, one_l) and torch.equal(t, one_t)
     # the engine's default: as many full lanes as the queue fills (up to DEFAULT_MAX_LANES)

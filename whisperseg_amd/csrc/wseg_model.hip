@@ -5,6 +5,7 @@
 // greedy / beam-search decoding (HF generation/utils.py:3208-3510).  The host code below only enqueues
 // kernels on the caller's stream; all decoding state lives in the caller-provided workspace.
 #include <algorithm>
+#include <condition_variable>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -450,7 +451,20 @@ namespace {
 // The queue of windows still waiting for a slot, shared by the lanes of one wseg_generate call.
 struct WindowQueue {
   std::mutex mu;
+  std::condition_variable cv;
   int next = 0, total = 0;
+  int lanes = 1, arrived = 0;
+  // Every lane makes its first claim only once all lanes are running: a lane whose host thread starts late would otherwise
+  // find its even share of a short queue already taken by the others' refills.
+  void arrive() {                                        // (also called by a lane that fails before it can start)
+    std::lock_guard<std::mutex> lk(mu);
+    if (++arrived >= lanes) cv.notify_all();
+  }
+  void start_gate() {
+    std::unique_lock<std::mutex> lk(mu);
+    if (++arrived >= lanes) cv.notify_all();
+    else cv.wait(lk, [&] { return arrived >= lanes; });
+  }
   // Claims up to min(n_free, cap) windows for a lane under the refill rule (enough free slots, or the rest of the queue,
   // or a lane with nothing to do).  Returns the count, *start = first claimed window, *drained = queue empty afterwards.
   int claim(int n_free, int cap, int refill_min, bool lane_idle, int* start, bool* drained) {
@@ -480,6 +494,7 @@ struct WindowQueue {
 static int generate_lane(wseg_model* m, Lane& ln, int n_lanes, const float* feats, WindowQueue& wq,
                          const wseg_generate_params* gp, char* base, int S, int first_cap, int32_t* out_tokens,
                          int32_t* out_lengths, hipStream_t s) {
+  wq.start_gate();                                       // before anything that can fail: every lane passes exactly once
   const wseg_model_config& c = m->cfg;
   const int nb = gp->num_beams, P = gp->prompt_len, L = gp->max_length;
   const int n_windows = wq.total;
@@ -707,13 +722,14 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
   }
   WindowQueue wq;
   wq.total = n_windows;
+  wq.lanes = NL;
   char* base = aligned_base(workspace);
   std::vector<int> rc(NL, WSEG_OK);
   std::vector<std::string> err(NL);
   std::vector<std::thread> threads;
   for (int g = 1; g < NL; ++g)
     threads.emplace_back([&, g]() {
-      if (hipSetDevice(dev) != hipSuccess) { rc[g] = WSEG_ERR_HIP; err[g] = "hipSetDevice failed in a lane thread"; return; }
+      if (hipSetDevice(dev) != hipSuccess) { wq.arrive(); rc[g] = WSEG_ERR_HIP; err[g] = "hipSetDevice failed in a lane thread"; return; }
       rc[g] = generate_lane(m, *m->lanes[g], NL, feats, wq, gp, base + (size_t)g * lane_bytes, S, share, out_tokens, out_lengths,
                             m->lanes[g]->own_stream);
       if (rc[g] != WSEG_OK) err[g] = wseg_last_error();
