@@ -110,20 +110,22 @@ torch.save(outs, sys.argv[1])
 """
 
 
-def test_f32_big_tile_kernel_is_bit_identical_to_the_64x64_kernel(gpu_lib, tmp_path):
-    """The exact-parity mode's large problems run on a 128x128-tile kernel (8x8 outputs per thread); like the 64x64 kernel it
-    computes every output as one fmaf chain in k order, so the two must agree bit for bit (WSEG_F32_GEMM_64=1 forces the small
-    kernel; the knob is read once per process, hence the two child processes)."""
+def test_f32_gemm_kernels_are_bit_identical(gpu_lib, tmp_path):
+    """The exact-parity mode's GEMM runs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: 128x128 tiles for large problems,
+    64x64 otherwise).  That instruction is a k-ordered fmaf chain bit for bit, so the MFMA kernels must reproduce the two VALU
+    kernels (64x64 tile / 4x4 per thread; 128x128 tile / 8x8 per thread with packed FMAs) exactly.  WSEG_F32_GEMM selects the
+    kernel; the knob is read once per process, hence one child process per kernel."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = tmp_path / "f32big.py"
+    script = tmp_path / "f32gemm.py"
     script.write_text(F32_BIG_SCRIPT)
-    outs = []
-    for name, env in (("big", {}), ("small", {"WSEG_F32_GEMM_64": "1"})):
-        out = tmp_path / f"{name}.pt"
-        subprocess.check_call([sys.executable, str(script), str(out), root], env={**os.environ, **env})
-        outs.append(torch.load(out))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    outs = {}
+    for mode in ("mfma", "mfma64", "valu128", "valu64"):
+        out = tmp_path / f"{mode}.pt"
+        subprocess.check_call([sys.executable, str(script), str(out), root], env={**os.environ, "WSEG_F32_GEMM": mode})
+        outs[mode] = torch.load(out)
+    for mode in ("mfma64", "valu128", "valu64"):
+        for a, b in zip(outs["mfma"], outs[mode]):
+            assert torch.equal(a, b), mode

@@ -192,3 +192,34 @@ torch.save(out, sys.argv[1])
     for nb in (1, 2, 3, 4):
         for got, want in zip(res["pk"][nb], res["fma"][nb]):
             assert torch.equal(got, want), nb
+
+
+F32_ATTN_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[2])
+from whisperseg_amd.engine import Engine
+cfg = dict(d_model=256, encoder_attention_heads=4, decoder_attention_heads=4, encoder_layers=2, decoder_layers=1, encoder_ffn_dim=512,
+           decoder_ffn_dim=512, vocab_size=1280, num_mel_bins=80, max_source_positions=500, max_target_positions=448)
+eng = Engine.random(cfg, "cuda:0", "f32", seed=5)
+x = torch.randn(6, 80, 1000, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9)) * 0.7
+torch.save(eng.encode(x).cpu(), sys.argv[1])
+"""
+
+
+def test_f32_encoder_attention_kernels_are_bit_identical(gpu_lib, tmp_path):
+    """Exact-parity mode: the encoder attention on the fp32 matrix cores (k-ordered fmaf chains: scores over the head
+    dimension, probability sum and P·V over ascending keys, the row maximum from a first pass) against the one-thread-per-query
+    kernel it restates — the encoder outputs must be equal bit for bit (WSEG_F32_ATTN=naive selects the old kernel)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "f32attn.py"
+    script.write_text(F32_ATTN_SCRIPT)
+    outs = []
+    for env in ({}, {"WSEG_F32_ATTN": "naive"}):
+        out = tmp_path / f"o{len(outs)}.pt"
+        subprocess.check_call([sys.executable, str(script), str(out), root], env={**os.environ, **env})
+        outs.append(torch.load(out))
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])

@@ -8,6 +8,8 @@
 // (O^T = V^T P^T), so P never goes through LDS.  V^T is produced directly by the QKV GEMM epilogue
 // (EPI_QKV_ENC), K and V^T tiles (64 keys) are staged in LDS with XOR swizzles that keep the
 // ds_read_b128 / ds_read_b64 fragment reads conflict-free.
+#include <stdlib.h>
+#include <string.h>
 #include "wseg_kernels.h"
 
 namespace wseg {
@@ -311,6 +313,107 @@ __global__ __launch_bounds__(64) void enc_attention_f32_kernel(const float* __re
   for (int e = 0; e < 64; ++e) orow[e] = o[e] * inv;
 }
 
+// The same arithmetic on the fp32 matrix cores, bit for bit: v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain, so
+//   S^T[t][q] = sum_e K[t][e] Q[q][e]      (chain over e = 0..63, as the loop above)
+//   l[q]      = sum_t 1 * P^T[t][q]        (fma(1, p, l) == l + p: the ascending-t sum above)
+//   O^T[e][q] = sum_t V^T[e][t] P^T[t][q]  (chain over t ascending)
+// with the row maximum taken in a first pass over the keys exactly as above.  Keys past T get p = 0 exactly, which leaves
+// both chains unchanged (K / V^T pad rows are finite).  One wave per 32 queries, 4 waves per workgroup share the K / V^T
+// tiles of 32 keys in LDS; P^T goes through the wave's own LDS tile to reach the MFMA operand layout.
+__global__ __launch_bounds__(256) void enc_attention_f32_mfma_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                                     const float* __restrict__ Vt, float* __restrict__ out,
+                                                                     int H, int T, int Tp, int d) {
+  __shared__ float sK[32][65];          // [key][hd]
+  __shared__ float sV[64][33];          // [hd][key]
+  __shared__ float sP[4][32][33];       // per wave: [key][query]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 31, fk = lane >> 5;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const float* Qb = Q + (size_t)bh * Tp * 64;
+  const float* Kb = K + (size_t)bh * Tp * 64;
+  const float* Vb = Vt + (size_t)bh * 64 * Tp;
+  const int qrow = min(q0 + fi, Tp - 1);
+  float qf[32];                         // B operand of S^T = K Q^T: Q[q0 + fi][2 kk + fk]
+#pragma unroll
+  for (int kk = 0; kk < 32; ++kk) qf[kk] = Qb[(size_t)qrow * 64 + 2 * kk + fk];
+  const int n_tiles = (T + 31) / 32;
+  auto load_k = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 256, row = c >> 4, col = (c & 15) * 4;
+      const float4 v = *(const float4*)(Kb + (size_t)(kt * 32 + row) * 64 + col);
+      sK[row][col] = v.x; sK[row][col + 1] = v.y; sK[row][col + 2] = v.z; sK[row][col + 3] = v.w;
+    }
+  };
+  auto load_v = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 256, row = c >> 3, col = (c & 7) * 4;
+      const float4 v = *(const float4*)(Vb + (size_t)row * Tp + kt * 32 + col);
+      sV[row][col] = v.x; sV[row][col + 1] = v.y; sV[row][col + 2] = v.z; sV[row][col + 3] = v.w;
+    }
+  };
+  auto scores = [&](int kt, f32x16& sc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[fi][2 * kk + fk], qf[kk], sc, 0, 0, 0);
+  };
+  // pass 1: row maximum over the real keys
+  float mx = -3.0e38f;
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    __syncthreads();
+    load_k(kt);
+    __syncthreads();
+    f32x16 sc;
+    scores(kt, sc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + 8 * (r >> 2) + 4 * fk + (r & 3);
+      if (key < T) mx = fmaxf(mx, sc[r]);
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));       // the two lane halves hold the two key halves of a query
+  // pass 2: p = exp(s - max), l += p, O += p V — all in ascending key order
+  f32x16 o0, o1, la;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; la[r] = 0.f; }
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    __syncthreads();
+    load_k(kt);
+    load_v(kt);
+    __syncthreads();
+    f32x16 sc;
+    scores(kt, sc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kl = 8 * (r >> 2) + 4 * fk + (r & 3);
+      sP[wave][kl][fi] = (kt * 32 + kl < T) ? expf(sc[r] - mx) : 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the wave's own LDS writes, then its own reads
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float pb = sP[wave][2 * kk + fk][fi];
+      o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[fi][2 * kk + fk], pb, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[32 + fi][2 * kk + fk], pb, o1, 0, 0, 0);
+      la = __builtin_amdgcn_mfma_f32_32x32x2f32(1.0f, pb, la, 0, 0, 0);
+    }
+  }
+  const int q = q0 + fi;
+  if (q < T) {
+    const float inv = 1.0f / la[0];
+    float* orow = out + ((size_t)b * T + q) * d + h * 64;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int hd = 8 * g + 4 * fk;
+      *(float4*)(orow + hd) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+      *(float4*)(orow + 32 + hd) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------------
@@ -357,8 +460,14 @@ int launch_enc_attention(int dtype, const void* q, const void* k, const void* vt
     if (dtype == WSEG_BF16) hipLaunchKernelGGL(enc_attention_h16_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, T, Tp, d);
     else hipLaunchKernelGGL(enc_attention_h16_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)q, (const f16_t*)k, (const f16_t*)vt, (f16_t*)out, H, T, Tp, d);
   } else {
-    dim3 grid(cdiv(T, 64), B * H);
-    hipLaunchKernelGGL(enc_attention_f32_kernel, grid, dim3(64), 0, s, (const float*)q, (const float*)k, (const float*)vt, (float*)out, H, T, Tp, d);
+    static const bool naive = getenv("WSEG_F32_ATTN") && !strcmp(getenv("WSEG_F32_ATTN"), "naive");   // test knob: same bits either way
+    if (naive || Tp % 128 != 0) {
+      dim3 grid(cdiv(T, 64), B * H);
+      hipLaunchKernelGGL(enc_attention_f32_kernel, grid, dim3(64), 0, s, (const float*)q, (const float*)k, (const float*)vt, (float*)out, H, T, Tp, d);
+    } else {
+      dim3 grid(cdiv(T, 128), B * H);
+      hipLaunchKernelGGL(enc_attention_f32_mfma_kernel, grid, dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)vt, (float*)out, H, T, Tp, d);
+    }
   }
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
