@@ -512,6 +512,18 @@ def extra_lines(args, eng, step, main_in, make_extractor, device, W, slots):
                                 "note": "log-mel features precomputed; engine.generate only (encoder + cross-K/V + decode)"}
         del eng2
         torch.cuda.empty_cache()
+        # the exact-parity mode (fp32 storage, fp32 matrix cores: every dot product a k-ordered fmaf chain) on 64 of the windows
+        eng3 = Engine(eng.geo, {k: v.float() for k, v in eng.weights.items()}, eng.device, "f32")
+        n32 = min(64, W)
+
+        def f32_step():
+            return eng3.generate(feats[:n32], PROMPT, EOS, EOS, max_length=3 + args.gen_tokens, num_beams=args.beams,
+                                 suppress_tokens=SUPPRESS, begin_suppress_tokens=BEGIN_SUPPRESS, n_slots=n32)
+        dt, _ = timed(f32_step)
+        out["f32_mode"] = {"audio_sec_per_s": n32 * 1000 * args.spec_time_step / dt, "ms_per_step": dt * 1e3, "windows": n32,
+                           "note": "exact-parity mode, engine.generate only"}
+        del eng3
+        torch.cuda.empty_cache()
     def big_queues():
         # in-flight batching: 16 x W windows with per-window length caps drawn from a synthetic distribution
         rng = np.random.default_rng(3)
