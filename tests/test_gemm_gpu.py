@@ -90,7 +90,7 @@ sys.path.insert(0, sys.argv[2])
 from whisperseg_amd import _lib
 lib = _lib.load(require_device=True)
 outs = []
-for (M, N, K, epi) in ((8192, 1280, 1280, 0), (8100, 1280, 5120, 2), (33000, 640, 256, 1)):
+for (M, N, K, epi) in ((8192, 1280, 1280, 0), (8100, 1280, 5120, 2), (33000, 640, 256, 1), (200, 1280, 1280, 2), (7, 3840, 1280, 0), (1000, 1280, 5120, 1)):
     g = torch.Generator(device="cuda").manual_seed(M + epi)
     mp = (M + 255) // 256 * 256
     A = torch.rand(mp, K, device="cuda", generator=g) * 2 - 1
@@ -112,7 +112,7 @@ torch.save(outs, sys.argv[1])
 
 def test_f32_gemm_kernels_are_bit_identical(gpu_lib, tmp_path):
     """The exact-parity mode's GEMM runs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: 128x128 tiles for large problems,
-    64x64 otherwise).  That instruction is a k-ordered fmaf chain bit for bit, so the MFMA kernels must reproduce the two VALU
+    64x64 otherwise, 32x32 tiles of v_mfma_f32_16x16x4_f32 when those would not fill the chip).  That instruction is a k-ordered fmaf chain bit for bit, so the MFMA kernels must reproduce the two VALU
     kernels (64x64 tile / 4x4 per thread; 128x128 tile / 8x8 per thread with packed FMAs) exactly.  WSEG_F32_GEMM selects the
     kernel; the knob is read once per process, hence one child process per kernel."""
     import os

@@ -974,6 +974,45 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
   }
 }
 
+// The same for problems whose 64x64 tiles would not fill the chip (decoder steps, small encoders): 32x32 tile, 2 x 2 waves of
+// one v_mfma_f32_16x16x4_f32 accumulator each (also a k-ordered fmaf chain: same bits again).
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_mfma16_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
+                                                              int M, int N, int K, EpiParams ep) {
+  constexpr int BK = 16, LD = 32 + 4;
+  __shared__ float sA[2][BK][LD];
+  __shared__ float sW[2][BK][LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  // loads: 32 rows x 16 k per operand = 128 float4: threads 0-127 fetch A, 128-255 fetch W
+  const bool isw = tid >= 128;
+  const int lt = tid & 127, lr = lt >> 2, lq = (lt & 3) * 4;
+  const float* src = isw ? W + (size_t)(n0 + lr) * ldw + lq : A + (size_t)(m0 + lr) * lda + lq;
+  float4 rg = *(const float4*)src;
+  auto stage = [&](int b) {
+    float (*dst)[LD] = isw ? sW[b] : sA[b];
+    dst[lq + 0][lr] = rg.x; dst[lq + 1][lr] = rg.y; dst[lq + 2][lr] = rg.z; dst[lq + 3][lr] = rg.w;
+  };
+  stage(0);
+  __syncthreads();
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int nk = K / BK, fi = lane & 15, fk = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int b = kt & 1;
+    if (kt + 1 < nk) rg = *(const float4*)(src + (kt + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4)                   // lane group fk carries k = kk + fk: ascending k inside the instruction
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sW[b][kk + fk][wn * 16 + fi], sA[b][kk + fk][wm * 16 + fi], acc, 0, 0, 0);
+    if (kt + 1 < nk) stage(b ^ 1);
+    __syncthreads();
+  }
+  const int m = m0 + wm * 16 + fi;
+  if (m < M) {
+    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+    epi_apply<EPI, float>(ep, m, n0 + wn * 16 + 4 * fk, v);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Live profiler of the dominant kernel (wseg_profile_begin / wseg_profile_end)
 // ------------------------------------------------------------------------------------------------
@@ -1237,6 +1276,9 @@ static int launch_f32(const GemmArgs& g, hipStream_t s) {
     if (mode == 3 && big) {
       dim3 gridb(g.N / 128, cdiv(g.M, 128));
       hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, 2, 2>), gridb, dim3(256), 0, s, (const float*)g.A, g.lda, (const float*)g.W, g.ldw, g.M, g.N, g.K, g.ep);
+    } else if (mode == 3 && (long)cdiv(g.M, 64) * (g.N / 64) < device_cu_count()) {
+      dim3 gridt(g.N / 32, cdiv(g.M, 32));
+      hipLaunchKernelGGL((gemm_f32_mfma16_kernel<EPI>), gridt, dim3(256), 0, s, (const float*)g.A, g.lda, (const float*)g.W, g.ldw, g.M, g.N, g.K, g.ep);
     } else {
       dim3 grids(g.N / 64, cdiv(g.M, 64));
       hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, 1, 1>), grids, dim3(256), 0, s, (const float*)g.A, g.lda, (const float*)g.W, g.ldw, g.M, g.N, g.K, g.ep);
