@@ -568,6 +568,7 @@ __global__ __launch_bounds__(256) void row_topk_partial_kernel(DecodeState st, c
                                                                float* __restrict__ part_val, int* __restrict__ part_idx,
                                                                float* __restrict__ part_stat) {
   __shared__ float s_red[4];
+  __shared__ float s_thr[4];
   __shared__ float s_bv[4];
   __shared__ int s_bi[4];
   __shared__ int s_bt[4];
@@ -583,18 +584,36 @@ __global__ __launch_bounds__(256) void row_topk_partial_kernel(DecodeState st, c
   // the slice as [lo, a4) scalar head, [a4, b4) 16-byte groups (rows are 16-byte aligned: ldv % 4 == 0), [b4, hi) tail:
   // a row is 200 KB of fp32, one dword per lane per load left the scan latency-bound (0.66 TB/s at 1024 rows)
   const int a4 = min(hi, (lo + 3) & ~3), b4 = max(a4, hi & ~3);
-  float mx = -3.0e38f;
-  for (int i = lo + tid; i < a4; i += 256) mx = fmaxf(mx, x[i]);
+  // pass 1: the slice maximum of the raw logits (for the log-sum-exp) and, per thread, the maximum of the PROCESSED logits
+  // (suppressed ids -> -inf), from which a lower bound on the slice's KC-th best candidate follows
+  float mx = -3.0e38f, pm = -INFINITY;
+  auto seen = [&](float v, unsigned char sup) { mx = fmaxf(mx, v); if (!(sup & bits)) pm = fmaxf(pm, v); };
+  for (int i = lo + tid; i < a4; i += 256) seen(x[i], st.sup_mask[i]);
 #pragma unroll 8
   for (int i = a4 + tid * 4; i < b4; i += 1024) {          // unrolled: 8 independent 16-byte loads in flight per lane
     const float4 v = *(const float4*)(x + i);
-    mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    const uchar4 m4 = *(const uchar4*)(st.sup_mask + i);
+    seen(v.x, m4.x); seen(v.y, m4.y); seen(v.z, m4.z); seen(v.w, m4.w);
   }
-  for (int i = b4 + tid; i < hi; i += 256) mx = fmaxf(mx, x[i]);
+  for (int i = b4 + tid; i < hi; i += 256) seen(x[i], st.sup_mask[i]);
   mx = wave_max(mx);
-  if (lane == 0) s_red[wave] = mx;
+  // KC-th largest of the wave's 64 per-lane maxima: at least KC distinct elements of the slice are >= it, so nothing below it
+  // can be among the slice's KC best.  Without this filter the sorted insertion below runs for nearly every element: some
+  // lane of the wave beats its own KC-th best at almost every step, and the whole wave pays for it.
+  float thr = -INFINITY;
+  {
+    float cand = pm;
+#pragma unroll 1
+    for (int k = 0; k < KC; ++k) {
+      thr = wave_max(cand);
+      const unsigned long long hit = __builtin_amdgcn_ballot_w64(cand == thr);
+      if (lane == __ffsll((long long)hit) - 1) cand = -INFINITY;      // drop ONE instance
+    }
+  }
+  if (lane == 0) { s_red[wave] = mx; s_thr[wave] = thr; }
   __syncthreads();
   mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  thr = fmaxf(fmaxf(s_thr[0], s_thr[1]), fmaxf(s_thr[2], s_thr[3]));      // each wave's bound holds: take the tightest
   __syncthreads();
   float sum = 0.f;
   float tv[KC];
@@ -604,7 +623,7 @@ __global__ __launch_bounds__(256) void row_topk_partial_kernel(DecodeState st, c
   auto visit = [&](float v, int i, unsigned char sup) {
     sum += expf(v - mx);
     if (sup & bits) v = -INFINITY;
-    if (better(v, i, tv[KC - 1], ti[KC - 1])) {
+    if (v >= thr && better(v, i, tv[KC - 1], ti[KC - 1])) {
 #pragma unroll
       for (int j = KC - 1; j >= 0; --j) {
         const bool gt_prev = (j > 0) ? better(v, i, tv[j > 0 ? j - 1 : 0], ti[j > 0 ? j - 1 : 0]) : false;
