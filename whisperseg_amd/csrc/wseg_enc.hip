@@ -167,6 +167,9 @@ __global__ __launch_bounds__(256, 4) void enc_attention_h16_kernel(const HT* __r
   // registers (its 8-byte-granule swizzle is finer than a DMA element).  Keeping the K chunks in registers as well made the
   // compiler spill them right behind their loads (a scratch store that waits for the load: the prefetch was serialised).
   uint4 v0, v1;
+  // V^T row of this thread's two chunks: rows 4j + {0, 2, 1, 3} for consecutive 8-lane groups, so that the two rows sharing a
+  // 16-lane ds_write_b64 group have swizzles of different parity (rows 2k and 2k + 1 share theirs and collided 2-way)
+  const int vrow = ((tid >> 3) & ~3) | (((tid >> 3) & 1) << 1) | (((tid >> 3) >> 1) & 1);
   auto fetch = [&](int kt) {
     const HT* ksrc = Kb + (size_t)(kt * 64) * 64;
     HT* kdst = sK[kt & 1];
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256, 4) void enc_attention_h16_kernel(const HT* __r
                                        (__attribute__((address_space(3))) void*)(kdst + (i * 256 + wave * 64) * 8), 16, 0, 0);
     }
     {
-      const int r0 = tid >> 3, sl = tid & 7;
+      const int r0 = vrow, sl = tid & 7;
       v0 = *(const uint4*)(Vb + (size_t)r0 * Tp + kt * 64 + sl * 8);
       v1 = *(const uint4*)(Vb + (size_t)(r0 + 32) * Tp + kt * 64 + sl * 8);
     }
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256, 4) void enc_attention_h16_kernel(const HT* __r
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's K chunks have landed in LDS, its V chunks in v0 / v1
     __syncthreads();                                      // ... everyone's; and every wave is done with sV of the last tile
     {
-      const int r0 = tid >> 3, sl = tid & 7;
+      const int r0 = vrow, sl = tid & 7;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int row = r0 + i * 32, sw = (row >> 1) & 15;
