@@ -12,6 +12,7 @@ ap.add_argument("--lanes", default="1,2,3,4")
 ap.add_argument("--gen", type=int, default=32)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--decode-only", action="store_true", help="feed precomputed encoder states (times cross-K/V + decode)")
+ap.add_argument("--refill", type=int, default=0, help="refill_min (0: slots / 8)")
 ap.add_argument("--varied", action="store_true", help="per-window length caps 8..gen (exercises the refill)")
 a = ap.parse_args()
 cfg = dict(d_model=1280, encoder_attention_heads=20, decoder_attention_heads=20, encoder_layers=32, decoder_layers=32,
@@ -21,7 +22,7 @@ W = a.windows
 feats = torch.randn(W, 80, 1000, device="cuda") * 0.5
 enc = torch.cat([eng.encode(feats[i:i + 64]) for i in range(0, W, 64)]) if a.decode_only else None
 prompt, eos = [50258, 50259, 50363], 50257
-kw = dict(max_length=3 + a.gen, num_beams=4, suppress_tokens=[eos, 1, 2], begin_suppress_tokens=[220], n_slots=a.slots)
+kw = dict(max_length=3 + a.gen, num_beams=4, suppress_tokens=[eos, 1, 2], begin_suppress_tokens=[220], n_slots=a.slots, refill_min=a.refill)
 if a.varied:
     g = torch.Generator().manual_seed(0)
     kw["window_max_length"] = torch.randint(3 + 8, 3 + a.gen + 1, (W,), generator=g, dtype=torch.int32)
