@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define WSEG_ABI_VERSION 3
+#define WSEG_ABI_VERSION 4
 
 typedef enum {
   WSEG_OK = 0,
@@ -40,7 +40,15 @@ typedef enum {
 typedef enum {
   WSEG_F32 = 0,             /* exact-parity mode: fp32 storage, VALU GEMM with fmaf chains in k order */
   WSEG_BF16 = 1,            /* bfloat16 storage + MFMA, fp32 accumulation */
-  WSEG_F16 = 2              /* IEEE half storage + MFMA, fp32 accumulation (reference WhisperSegmenterFast: CT2 float16, model.py:691) */
+  WSEG_F16 = 2,             /* IEEE half storage + MFMA, fp32 accumulation (reference WhisperSegmenterFast: CT2 float16, model.py:691) */
+  /* Split-precision modes (the reference's own arithmetic is fp32 everywhere, model.py:655-666): fp32 storage and fp32
+   * arithmetic for everything but the GEMMs; GEMM operands (activations and weights) are carried as hi + lo 16-bit pairs
+   * and multiplied as hi*hi + hi*lo + lo*hi on the 16-bit matrix cores with fp32 accumulation (3 MFMAs per product,
+   * ~2^-16 (bf16) / ~2^-21 (half) relative operand error instead of 2^-8 / 2^-11).  Weight matrices ("*.w", "dec.tok")
+   * are attached pre-split: rows of 2K 16-bit words, every 32 logical columns as [32 hi | 32 lo]
+   * (whisperseg_amd/engine.py::split_operand); every other tensor is float32. */
+  WSEG_BF16X3 = 3,
+  WSEG_F16X3 = 4
 } wseg_dtype;
 
 int wseg_abi_version(void);

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     assert set(names) == set(_lib.SYMBOLS), set(names) ^ set(_lib.SYMBOLS)
     bound = _lib.load()
-    assert bound.wseg_abi_version() == 3
+    assert bound.wseg_abi_version() == 4
 
 
 def test_struct_layouts_match_header(tmp_path):

@@ -42,6 +42,55 @@ def test_gemm_matches_torch(gpu_lib, M, N, K, epi, dtype):
     assert torch.isnan(out[M:]).all() or M == Mp      # rows beyond M are never written
 
 
+X3_SHAPES = SHAPES + [(12800, 1280, 1280), (10000, 3840, 192), (30000, 5120, 1280), (4100, 1280, 5120), (2100, 3840, 1280), (700, 256, 96)]
+
+
+@pytest.mark.parametrize("M,N,K", X3_SHAPES)
+@pytest.mark.parametrize("epi", [0, 1, 2])
+@pytest.mark.parametrize("dtype", ["bf16x3", "f16x3"])
+def test_split_precision_gemm_matches_fp64(gpu_lib, M, N, K, epi, dtype):
+    """Split-precision GEMM (operands as hi + lo 16-bit pairs, hi*hi + hi*lo + lo*hi on the 16-bit matrix cores) against an fp64
+    product of the SAME fp32 operands: the error must be that of ~16 (bf16x3) / ~21 (f16x3) operand mantissa bits — 100x / 1000x
+    below the plain 16-bit modes — through the skinny split-K family, the persistent 128x128 kernel and the 256x256 ping-pong
+    kernel; EPI_STORE / EPI_GELU outputs are operand rows themselves (read back with unsplit_operand)."""
+    from whisperseg_amd import _lib
+    from whisperseg_amd.engine import DTYPES, SPLIT_BASE, split_operand, unsplit_operand
+    base = SPLIT_BASE[dtype]
+    g = torch.Generator(device="cuda").manual_seed(M * 31 + N * 7 + K + epi)
+    Mp = (M + 255) // 256 * 256
+    A = torch.rand(Mp, K, device="cuda", generator=g) * 2 - 1
+    W = (torch.rand(N, K, device="cuda", generator=g) * 2 - 1) * K ** -0.5
+    bias = torch.rand(N, device="cuda", generator=g) - 0.5
+    res = torch.rand(Mp, N, device="cuda", generator=g) - 0.5
+    As, Ws = split_operand(A, base), split_operand(W, base)
+    assert torch.equal(unsplit_operand(As, base), (A.to(base).float() + (A - A.to(base).float()).to(base).float()))
+    if epi == 2:
+        out = torch.full((Mp, N), float("nan"), device="cuda")
+    else:
+        out = torch.full((Mp, 2 * N), -1, device="cuda", dtype=torch.int16)      # 0xffff words: NaN in both 16-bit types
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    _lib.check(gpu_lib.wseg_debug_gemm(DTYPES[dtype][0], epi, M, N, K, As.data_ptr(), Ws.data_ptr(), bias.data_ptr(), res.data_ptr(),
+                                       out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+    got_all = out if epi == 2 else unsplit_operand(out, base)
+    assert torch.isnan(got_all[M:]).all() or M == Mp      # rows beyond M are never written
+    worst, scale = 0.0, 1.0
+    for lo in range(0, M, 8192):
+        hi = min(M, lo + 8192)
+        ref = A[lo:hi].double() @ W.double().T + bias.double()
+        if epi == 1:
+            ref = torch.nn.functional.gelu(ref)
+        if epi == 2:
+            ref = ref + res[lo:hi].double()
+        got = got_all[lo:hi].double()
+        assert torch.isfinite(got).all()
+        worst = max(worst, (got - ref).abs().max().item())
+        scale = max(scale, ref.abs().max().item())
+    # bf16x3: operands to 2^-17 relative (hi + lo) plus the dropped lo*lo term, outputs re-split (2^-17): a few 1e-5 on O(1) sums.
+    # f16x3: 2^-22 operands; what is left is fp32 accumulation order and the fast erf of the GELU epilogue (1.5e-7 absolute)
+    tol = {"bf16x3": 6e-5, "f16x3": 6e-6}[dtype]
+    assert worst <= tol * scale, (worst, scale)
+
+
 # Shapes that reach the 256x256 ping-pong kernel (N % 256 == 0, >= 192 tiles): fewer tiles than workgroups x 2,
 # several tiles per workgroup (the K-tile stream crosses output tiles and holds the prefetch back over the epilogue),
 # the minimum K (2 K tiles), an odd number of K tiles, M not a tile multiple, and the bench's own row count.

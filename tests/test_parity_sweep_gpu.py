@@ -32,6 +32,19 @@ def test_f32_mode_reproduces_every_row(gpu_lib, sweep):
     assert res["exact_runs"] == len(sweep), (res["structure_mismatch_runs"][:3], res["beyond_one_frame_runs"][:3])
 
 
+@pytest.mark.parametrize("dtype", ["bf16x3", "f16x3"])
+def test_split_precision_modes_meet_the_north_star_tolerance(gpu_lib, sweep, dtype):
+    """The fast parity mode (and the segmenter's default): GEMM operands as hi + lo 16-bit pairs, three MFMAs per product,
+    fp32 everywhere else.  North star: clusters exact, boundaries within +-1 mel frame — on EVERY recording of the sweep."""
+    from tools.parity_sweep import score
+    from whisperseg_amd.model import WhisperSegmenter
+    res = score(WhisperSegmenter(MODEL_DIR, device="cuda", device_ids=[0], dtype=dtype), sweep)
+    print(dtype, json.dumps({k: v for k, v in res.items() if not k.endswith("_runs") or isinstance(v, int)}))
+    assert res["structure_mismatch_runs"] == [] and res["beyond_one_frame_runs"] == [], (res["structure_mismatch_runs"][:3], res["beyond_one_frame_runs"][:3])
+    assert res["cluster_mismatch_rows"] == 0
+    assert res["within_tolerance_runs"] == len(sweep)
+
+
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 def test_16_bit_modes_stay_inside_their_measured_envelope(gpu_lib, sweep, dtype):
     """Clusters are always exact; the number of runs (of 200) with a row-count difference or a boundary more than one mel

@@ -5,7 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwseg.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class LogmelDesc(C.Structure):

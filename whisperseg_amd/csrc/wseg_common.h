@@ -102,6 +102,81 @@ template <> struct El<float> {
   static __device__ __forceinline__ float rnd(float v) { return v; }
 };
 
+// ------------------------------------------------------------------------------------------------------------------
+// Split-precision ("x3") modes WSEG_BF16X3 / WSEG_F16X3.  Everything outside the GEMMs is the fp32 code of the exact-parity
+// mode (fp32 Q / K / V, caches, softmax, LayerNorm, biases); a GEMM OPERAND value x — activations and weights — is carried as
+// two 16-bit halves  hi = rn16(x), lo = rn16(x - hi)  (hi + lo == x to ~16 mantissa bits in bf16, ~22 in half) and a product
+// sum is taken as  hi*hi + hi*lo + lo*hi  on the 16-bit matrix cores with fp32 accumulation (lo*lo, ~2^-16 / 2^-22 relative,
+// is dropped).  Layout of an operand row of K logical elements: 2K 16-bit words, every 32 logical columns stored as
+// [32 hi | 32 lo] (128 bytes).  A 64-word K tile of the 16-bit GEMM kernels is then exactly {hi, lo} of 32 logical columns,
+// its two 32-wide MFMA k-steps are the hi and the lo fragments, and the x3 product is three MFMAs on fragments the kernel
+// already holds: (W hi, A hi), (W hi, A lo), (W lo, A hi) — 3x the MFMAs and 2x the operand bytes of the plain 16-bit mode.
+// X3<HT> is the element-type TAG of these modes (never instantiated); IO<T> maps a tag to its plain parameter type.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename HT> struct X3 {};
+template <typename T> struct IO { typedef T P; typedef T H; static constexpr bool split = false; };
+template <typename HT> struct IO<X3<HT>> { typedef float P; typedef HT H; static constexpr bool split = true; };
+
+__host__ __device__ __forceinline__ int x3_col(int c) { return ((c >> 5) << 6) | (c & 31); }
+
+// 8 consecutive logical columns (c % 8 == 0) <-> the two 16-byte pieces of a split row
+template <typename HT> __device__ __forceinline__ void split8(const float v[8], uint4& hi, uint4& lo) {
+  hi = pack8<HT>(v);
+  float h[8], r[8];
+  unpack8<HT>(hi, h);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = v[e] - h[e];
+  lo = pack8<HT>(r);
+}
+// Operand stores / loads.  base: start of the operand matrix, ld: LOGICAL row length, c: logical column.
+template <typename T> struct Op {        // plain element types (float / 16-bit)
+  static __device__ __forceinline__ void st1(void* base, size_t row, int ld, int c, float v) { El<T>::st((T*)base + row * ld + c, v); }
+  static __device__ __forceinline__ float ld1(const void* base, size_t row, int ld, int c) { return El<T>::ld((const T*)base + row * ld + c); }
+};
+template <typename HT> struct Op<X3<HT>> {
+  static __device__ __forceinline__ void st1(void* base, size_t row, int ld, int c, float v) {
+    uint16_t* p = (uint16_t*)base + row * (size_t)(2 * ld) + x3_col(c);
+    const HT h = H16<HT>::from(v);
+    const HT l = H16<HT>::from(v - H16<HT>::one(h));
+    p[0] = __builtin_bit_cast(uint16_t, h);
+    p[32] = __builtin_bit_cast(uint16_t, l);
+  }
+  static __device__ __forceinline__ float ld1(const void* base, size_t row, int ld, int c) {
+    const uint16_t* p = (const uint16_t*)base + row * (size_t)(2 * ld) + x3_col(c);
+    return H16<HT>::one(__builtin_bit_cast(HT, p[0])) + H16<HT>::one(__builtin_bit_cast(HT, p[32]));
+  }
+};
+template <typename T> __device__ __forceinline__ void op_st8(void* base, size_t row, int ld, int c, const float v[8]) {
+  if constexpr (IO<T>::split) {
+    typedef typename IO<T>::H HT;
+    uint16_t* p = (uint16_t*)base + row * (size_t)(2 * ld) + x3_col(c);
+    uint4 hi, lo;
+    split8<HT>(v, hi, lo);
+    *(uint4*)p = hi;
+    *(uint4*)(p + 32) = lo;
+  } else if constexpr (sizeof(T) == 4) {
+    float* p = (float*)base + row * ld + c;
+    *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    *(uint4*)((T*)base + row * ld + c) = pack8<T>(v);
+  }
+}
+template <typename T> __device__ __forceinline__ void op_st4(void* base, size_t row, int ld, int c, const float v[4]) {
+  if constexpr (IO<T>::split) {
+    typedef typename IO<T>::H HT;
+    uint16_t* p = (uint16_t*)base + row * (size_t)(2 * ld) + x3_col(c);
+    uint2 hi = make_uint2(H16<HT>::pack(v[0], v[1]), H16<HT>::pack(v[2], v[3]));
+    const float r0 = v[0] - H16<HT>::lo(hi.x), r1 = v[1] - H16<HT>::hi(hi.x), r2 = v[2] - H16<HT>::lo(hi.y), r3 = v[3] - H16<HT>::hi(hi.y);
+    *(uint2*)p = hi;
+    *(uint2*)(p + 32) = make_uint2(H16<HT>::pack(r0, r1), H16<HT>::pack(r2, r3));
+  } else if constexpr (sizeof(T) == 4) {
+    *(float4*)((float*)base + row * ld + c) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    *(uint2*)((T*)base + row * ld + c) = make_uint2(H16<T>::pack(v[0], v[1]), H16<T>::pack(v[2], v[3]));
+  }
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // erf-GELU for the 16-bit paths: Abramowitz & Stegun 7.1.26 rational approximation of erf (|error| <= 1.5e-7, far

@@ -52,13 +52,16 @@ __global__ void suppress_mask_kernel(unsigned char* mask, int V, const int* sup,
   for (int i = threadIdx.x; i < n_bsup; i += blockDim.x) { const int t = bsup[i]; if (t >= 0 && t < V) atomicOr((unsigned int*)(mask + (t & ~3)), 2u << (8 * (t & 3))); }
 }
 
+// T: mode tag.  The token embedding is the LM head's weight matrix (a GEMM operand: hi | lo rows in the split-precision modes,
+// read back as hi + lo); the positional table is a plain parameter.
 template <typename T>
-__global__ __launch_bounds__(256) void embed_kernel(DecodeState st, const T* __restrict__ tok_emb, const T* __restrict__ pos_emb,
+__global__ __launch_bounds__(256) void embed_kernel(DecodeState st, const void* __restrict__ tok_emb, const typename IO<T>::P* __restrict__ pos_emb,
                                                     float* __restrict__ x, int d) {      // x: the fp32 residual stream
+  typedef typename IO<T>::P PT;
   const int r = blockIdx.x;
   const int tok = st.tokens_in[r], pos = st.pos[r / st.nb];
   for (int c = threadIdx.x; c < d; c += 256)
-    x[(size_t)r * d + c] = El<T>::ld(tok_emb + (size_t)tok * d + c) + El<T>::ld(pos_emb + (size_t)pos * d + c);
+    x[(size_t)r * d + c] = Op<T>::ld1(tok_emb, (size_t)tok, d, c) + El<PT>::ld(pos_emb + (size_t)pos * d + c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -130,9 +133,10 @@ __device__ __forceinline__ float row8_sum(float a) {
   return a;
 }
 
-template <typename T>
+// T: storage type of q / the K / V cache / the bias; TO: tag of the output (the o-proj GEMM's operand: T, or X3<HT> with T = float)
+template <typename T, typename TO>
 __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const T* __restrict__ q, T* __restrict__ kc,
-                                                           T* __restrict__ vc, T* __restrict__ out, int H, int d,
+                                                           T* __restrict__ vc, void* __restrict__ out, int H, int d,
                                                            PartialInfo pi, const T* __restrict__ qkv_bias, float scale) {
   __shared__ float sp[512];
   __shared__ int srow[512];
@@ -243,8 +247,10 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
   }
   if (rowl == 0) {
     const float inv = 1.0f / sum;
+    float o8[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) El<T>::st(out + (size_t)r * d + h * 64 + sub * 8 + e, acc[e] * inv);
+    for (int e = 0; e < 8; ++e) o8[e] = acc[e] * inv;
+    op_st8<TO>(out, (size_t)r, d, h * 64 + sub * 8, o8);
   }
 }
 
@@ -253,9 +259,9 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
 // HBM-bound (128 KiB of K/V per workgroup).  8 lanes cover one 128-byte K/V row (16 B each), so a wave
 // reads 8 consecutive rows = 1 KiB fully coalesced per instruction and 4 rows are in flight per lane.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NB>
+template <typename T, typename TO, int NB>
 __global__ __launch_bounds__(256, 4) void dec_cross_attn_kernel(DecodeState st, const T* __restrict__ q, const T* __restrict__ ck,
-                                                             const T* __restrict__ cv, T* __restrict__ out, int H, int Tk, int d,
+                                                             const T* __restrict__ cv, void* __restrict__ out, int H, int Tk, int d,
                                                              PartialInfo pi, const T* __restrict__ q_bias, float scale) {
   __shared__ float sc[NB][512];
   __shared__ float red[4][NB][64];
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_kernel(DecodeState st, 
   for (int i = tid; i < nb * 64; i += 256) {
     const int j = i >> 6, e = i & 63;
     const float o = ((red[0][j][e] + red[1][j][e]) + red[2][j][e]) + red[3][j][e];
-    El<T>::st(out + (size_t)(w * nb + j) * d + h * 64 + e, o * sinv[j]);
+    Op<TO>::st1(out, (size_t)(w * nb + j), d, h * 64 + e, o * sinv[j]);
   }
 }
 
@@ -923,9 +929,13 @@ int launch_build_suppress_mask(unsigned char* mask, int V, const int* sup, int n
 }
 int launch_embed(int dtype, const DecodeState& st, const void* tok_emb, const void* pos_emb, void* x, int d, hipStream_t s) {
   const int R = st.W * st.nb;
-  if (dtype == WSEG_BF16) hipLaunchKernelGGL((embed_kernel<bf16_t>), dim3(R), dim3(256), 0, s, st, (const bf16_t*)tok_emb, (const bf16_t*)pos_emb, (float*)x, d);
-  else if (dtype == WSEG_F16) hipLaunchKernelGGL((embed_kernel<f16_t>), dim3(R), dim3(256), 0, s, st, (const f16_t*)tok_emb, (const f16_t*)pos_emb, (float*)x, d);
-  else hipLaunchKernelGGL((embed_kernel<float>), dim3(R), dim3(256), 0, s, st, (const float*)tok_emb, (const float*)pos_emb, (float*)x, d);
+#define WSEG_EMB(T_) hipLaunchKernelGGL((embed_kernel<T_>), dim3(R), dim3(256), 0, s, st, tok_emb, (const typename IO<T_>::P*)pos_emb, (float*)x, d)
+  if (dtype == WSEG_BF16) WSEG_EMB(bf16_t);
+  else if (dtype == WSEG_F16) WSEG_EMB(f16_t);
+  else if (dtype == WSEG_BF16X3) WSEG_EMB(X3<bf16_t>);
+  else if (dtype == WSEG_F16X3) WSEG_EMB(X3<f16_t>);
+  else WSEG_EMB(float);
+#undef WSEG_EMB
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
@@ -935,20 +945,26 @@ int launch_dec_self_attn(int dtype, const DecodeState& st, const void* q, void* 
   const int R = st.W * st.nb;
   PartialInfo pi;
   if (qkv_part) pi = *qkv_part;
-  if (dtype == WSEG_BF16) hipLaunchKernelGGL((dec_self_attn_kernel<bf16_t>), dim3(R * H), dim3(64), 0, s, st, (const bf16_t*)q, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)out, H, d, pi, (const bf16_t*)qkv_bias, scale);
-  else if (dtype == WSEG_F16) hipLaunchKernelGGL((dec_self_attn_kernel<f16_t>), dim3(R * H), dim3(64), 0, s, st, (const f16_t*)q, (f16_t*)kc, (f16_t*)vc, (f16_t*)out, H, d, pi, (const f16_t*)qkv_bias, scale);
-  else hipLaunchKernelGGL((dec_self_attn_kernel<float>), dim3(R * H), dim3(64), 0, s, st, (const float*)q, (float*)kc, (float*)vc, (float*)out, H, d, pi, (const float*)qkv_bias, scale);
+#define WSEG_SA(T_, TO_) hipLaunchKernelGGL((dec_self_attn_kernel<T_, TO_>), dim3(R * H), dim3(64), 0, s, st, (const T_*)q, (T_*)kc, (T_*)vc, out, H, d, pi, (const T_*)qkv_bias, scale)
+  if (dtype == WSEG_BF16) WSEG_SA(bf16_t, bf16_t);
+  else if (dtype == WSEG_F16) WSEG_SA(f16_t, f16_t);
+  else if (dtype == WSEG_BF16X3) WSEG_SA(float, X3<bf16_t>);
+  else if (dtype == WSEG_F16X3) WSEG_SA(float, X3<f16_t>);
+  else WSEG_SA(float, float);
+#undef WSEG_SA
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
-template <typename T>
-static void launch_cross_t(const DecodeState& st, const T* q, const T* ck, const T* cv, T* out, int H, int Tk, int d,
-                           const PartialInfo& pi, const T* qb, float scale, hipStream_t s) {
+template <typename T, typename TO>
+static void launch_cross_t(const DecodeState& st, const void* q, const void* ck, const void* cv, void* out, int H, int Tk, int d,
+                           const PartialInfo& pi, const void* qb, float scale, hipStream_t s) {
   dim3 grid(st.W * H), block(256);
-  if (st.nb <= 1) hipLaunchKernelGGL((dec_cross_attn_kernel<T, 1>), grid, block, 0, s, st, q, ck, cv, out, H, Tk, d, pi, qb, scale);
-  else if (st.nb <= 2) hipLaunchKernelGGL((dec_cross_attn_kernel<T, 2>), grid, block, 0, s, st, q, ck, cv, out, H, Tk, d, pi, qb, scale);
-  else if (st.nb <= 4) hipLaunchKernelGGL((dec_cross_attn_kernel<T, 4>), grid, block, 0, s, st, q, ck, cv, out, H, Tk, d, pi, qb, scale);
-  else hipLaunchKernelGGL((dec_cross_attn_kernel<T, 8>), grid, block, 0, s, st, q, ck, cv, out, H, Tk, d, pi, qb, scale);
+#define WSEG_CA(NB_) hipLaunchKernelGGL((dec_cross_attn_kernel<T, TO, NB_>), grid, block, 0, s, st, (const T*)q, (const T*)ck, (const T*)cv, out, H, Tk, d, pi, (const T*)qb, scale)
+  if (st.nb <= 1) WSEG_CA(1);
+  else if (st.nb <= 2) WSEG_CA(2);
+  else if (st.nb <= 4) WSEG_CA(4);
+  else WSEG_CA(8);
+#undef WSEG_CA
 }
 int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const void* ck, const void* cv, void* out, int H, int Tk, int d,
                           const PartialInfo* q_part, const void* q_bias, float scale, hipStream_t s) {
@@ -956,15 +972,17 @@ int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const
   PartialInfo pi;
   if (q_part) pi = *q_part;
   static const bool deep = getenv("WSEG_CROSS_NO_PK") == nullptr;         // tuning knob: fp32-FMA kernel
-  if (dtype != WSEG_F32 && deep && Tk <= 512 && st.nb <= 4) {
+  if ((dtype == WSEG_BF16 || dtype == WSEG_F16) && deep && Tk <= 512 && st.nb <= 4) {
     dim3 grid(st.W * H), block(256);
 #define WSEG_PK(HT_, NB_) hipLaunchKernelGGL((dec_cross_attn_pk_kernel<HT_, NB_>), grid, block, 0, s, st, (const HT_*)q, (const HT_*)ck, (const HT_*)cv, (HT_*)out, H, Tk, d, pi, (const HT_*)q_bias, scale)
     if (dtype == WSEG_BF16) { if (st.nb <= 1) WSEG_PK(bf16_t, 1); else if (st.nb <= 2) WSEG_PK(bf16_t, 2); else WSEG_PK(bf16_t, 4); }
     else { if (st.nb <= 1) WSEG_PK(f16_t, 1); else if (st.nb <= 2) WSEG_PK(f16_t, 2); else WSEG_PK(f16_t, 4); }
 #undef WSEG_PK
-  } else if (dtype == WSEG_BF16) launch_cross_t<bf16_t>(st, (const bf16_t*)q, (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)out, H, Tk, d, pi, (const bf16_t*)q_bias, scale, s);
-  else if (dtype == WSEG_F16) launch_cross_t<f16_t>(st, (const f16_t*)q, (const f16_t*)ck, (const f16_t*)cv, (f16_t*)out, H, Tk, d, pi, (const f16_t*)q_bias, scale, s);
-  else launch_cross_t<float>(st, (const float*)q, (const float*)ck, (const float*)cv, (float*)out, H, Tk, d, pi, (const float*)q_bias, scale, s);
+  } else if (dtype == WSEG_BF16) launch_cross_t<bf16_t, bf16_t>(st, q, ck, cv, out, H, Tk, d, pi, q_bias, scale, s);
+  else if (dtype == WSEG_F16) launch_cross_t<f16_t, f16_t>(st, q, ck, cv, out, H, Tk, d, pi, q_bias, scale, s);
+  else if (dtype == WSEG_BF16X3) launch_cross_t<float, X3<bf16_t>>(st, q, ck, cv, out, H, Tk, d, pi, q_bias, scale, s);
+  else if (dtype == WSEG_F16X3) launch_cross_t<float, X3<f16_t>>(st, q, ck, cv, out, H, Tk, d, pi, q_bias, scale, s);
+  else launch_cross_t<float, float>(st, q, ck, cv, out, H, Tk, d, pi, q_bias, scale, s);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }

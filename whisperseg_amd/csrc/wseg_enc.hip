@@ -18,7 +18,7 @@ namespace wseg {
 // im2col for conv1 (k=3, pad 1): A1[b*cols + t][tap*C + c] = x[b][c][t + tap - 1]
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void im2col_conv1_kernel(const float* __restrict__ x, T* __restrict__ a1,
+__global__ __launch_bounds__(256) void im2col_conv1_kernel(const float* __restrict__ x, void* __restrict__ a1,
                                                            int C, int cols, int kp) {
   constexpr int TT = 32;  // time steps per block
   __shared__ float tile[96][TT + 2 + 1];
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void im2col_conv1_kernel(const float* __restri
       const int tap = k / C, c = k - tap * C;
       v = tile[c][tt + tap];
     }
-    El<T>::st(a1 + ((size_t)b * cols + t0 + tt) * kp + k, v);
+    Op<T>::st1(a1, (size_t)b * cols + t0 + tt, kp, k, v);
   }
 }
 
@@ -81,8 +81,9 @@ template <> struct VecIO<float> {
 };
 
 template <typename TO, int NIT>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const TO* __restrict__ g, const TO* __restrict__ bta,
-                                                        TO* __restrict__ y, int M, int d) {
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const typename IO<TO>::P* __restrict__ g,
+                                                        const typename IO<TO>::P* __restrict__ bta, void* __restrict__ y, int M, int d) {
+  typedef typename IO<TO>::P PT;
   constexpr int V = 8;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
@@ -117,11 +118,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int c = (it * 64 + lane) * V;
     if (c < d) {
       float gg[V], bb[V], o[V];
-      VecIO<TO>::ld(g + c, gg);
-      VecIO<TO>::ld(bta + c, bb);
+      VecIO<PT>::ld(g + c, gg);
+      VecIO<PT>::ld(bta + c, bb);
 #pragma unroll
       for (int j = 0; j < V; ++j) o[j] = (v[it][j] - mean) * rstd * gg[j] + bb[j];
-      VecIO<TO>::st(y + (size_t)row * d + c, o);
+      op_st8<TO>(y, (size_t)row, d, c, o);
     }
   }
 }
@@ -279,8 +280,9 @@ __global__ __launch_bounds__(256, 4) void enc_attention_h16_kernel(const HT* __r
 }
 
 // f32 exact-mode attention: one thread per query row (tests / tiny models only).
+template <typename TO>      // float, or X3<HT>: the output is the o-proj GEMM's operand
 __global__ __launch_bounds__(64) void enc_attention_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K,
-                                                               const float* __restrict__ Vt, float* __restrict__ out,
+                                                               const float* __restrict__ Vt, void* __restrict__ out,
                                                                int H, int T, int Tp, int d) {
   const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
   const int q = blockIdx.x * 64 + threadIdx.x;
@@ -310,10 +312,14 @@ __global__ __launch_bounds__(64) void enc_attention_f32_kernel(const float* __re
 #pragma unroll
     for (int e = 0; e < 64; ++e) o[e] = fmaf(p, vp[(size_t)e * Tp], o[e]);
   }
-  float* orow = out + ((size_t)b * T + q) * d + h * 64;
   const float inv = 1.0f / l;
 #pragma unroll
-  for (int e = 0; e < 64; ++e) orow[e] = o[e] * inv;
+  for (int e = 0; e < 64; e += 8) {
+    float v8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v8[u] = o[e + u] * inv;
+    op_st8<TO>(out, (size_t)b * T + q, d, h * 64 + e, v8);
+  }
 }
 
 // The same arithmetic on the fp32 matrix cores, bit for bit: v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain, so
@@ -323,8 +329,9 @@ __global__ __launch_bounds__(64) void enc_attention_f32_kernel(const float* __re
 // with the row maximum taken in a first pass over the keys exactly as above.  Keys past T get p = 0 exactly, which leaves
 // both chains unchanged (K / V^T pad rows are finite).  One wave per 32 queries, 4 waves per workgroup share the K / V^T
 // tiles of 32 keys in LDS; P^T goes through the wave's own LDS tile to reach the MFMA operand layout.
+template <typename TO>
 __global__ __launch_bounds__(256) void enc_attention_f32_mfma_kernel(const float* __restrict__ Q, const float* __restrict__ K,
-                                                                     const float* __restrict__ Vt, float* __restrict__ out,
+                                                                     const float* __restrict__ Vt, void* __restrict__ out,
                                                                      int H, int T, int Tp, int d) {
   __shared__ float sK[32][65];          // [key][hd]
   __shared__ float sV[64][33];          // [hd][key]
@@ -407,12 +414,13 @@ __global__ __launch_bounds__(256) void enc_attention_f32_mfma_kernel(const float
   const int q = q0 + fi;
   if (q < T) {
     const float inv = 1.0f / la[0];
-    float* orow = out + ((size_t)b * T + q) * d + h * 64;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int hd = 8 * g + 4 * fk;
-      *(float4*)(orow + hd) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-      *(float4*)(orow + 32 + hd) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+      const float a[4] = {o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+      const float c[4] = {o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+      op_st4<TO>(out, (size_t)b * T + q, d, h * 64 + hd, a);
+      op_st4<TO>(out, (size_t)b * T + q, d, h * 64 + 32 + hd, c);
     }
   }
 }
@@ -420,17 +428,72 @@ __global__ __launch_bounds__(256) void enc_attention_f32_mfma_kernel(const float
 // ------------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------------
+static bool is_x3(int dtype) { return dtype == WSEG_BF16X3 || dtype == WSEG_F16X3; }
+
+// Split-precision operand rows [M][2d words] <-> fp32 [M][d] (the C-ABI hands encoder states over as fp32 in these modes).
+template <typename HT>
+__global__ __launch_bounds__(256) void operand_to_f32_kernel(const uint16_t* __restrict__ op, float* __restrict__ out, size_t n8, int d) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / (d >> 3);
+    const int c = (int)(i - row * (d >> 3)) << 3;
+    const uint16_t* p = op + row * (size_t)(2 * d) + x3_col(c);
+    float h[8], l[8];
+    unpack8<HT>(*(const uint4*)p, h);
+    unpack8<HT>(*(const uint4*)(p + 32), l);
+    float* o = out + row * d + c;
+    *(float4*)o = make_float4(h[0] + l[0], h[1] + l[1], h[2] + l[2], h[3] + l[3]);
+    *(float4*)(o + 4) = make_float4(h[4] + l[4], h[5] + l[5], h[6] + l[6], h[7] + l[7]);
+  }
+}
+template <typename HT>
+__global__ __launch_bounds__(256) void f32_to_operand_kernel(const float* __restrict__ in, void* __restrict__ op, size_t n8, int d) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / (d >> 3);
+    const int c = (int)(i - row * (d >> 3)) << 3;
+    float v[8];
+    VecIO<float>::ld(in + row * d + c, v);
+    op_st8<X3<HT>>(op, row, d, c, v);
+  }
+}
+int launch_operand_to_f32(int dtype, const void* op, float* out, size_t M, int d, hipStream_t s) {
+  if (!is_x3(dtype) || d % 32) { set_error("operand_to_f32: dtype %d / d %d unsupported", dtype, d); return WSEG_ERR_INVALID; }
+  const size_t n8 = M * (size_t)(d >> 3);
+  if (n8 == 0) return WSEG_OK;
+  const int blocks = (int)((n8 + 255) / 256 < 16384 ? (n8 + 255) / 256 : 16384);
+  if (dtype == WSEG_BF16X3) hipLaunchKernelGGL(operand_to_f32_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const uint16_t*)op, out, n8, d);
+  else hipLaunchKernelGGL(operand_to_f32_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, (const uint16_t*)op, out, n8, d);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+int launch_f32_to_operand(int dtype, const float* in, void* op, size_t M, int d, hipStream_t s) {
+  if (!is_x3(dtype) || d % 32) { set_error("f32_to_operand: dtype %d / d %d unsupported", dtype, d); return WSEG_ERR_INVALID; }
+  const size_t n8 = M * (size_t)(d >> 3);
+  if (n8 == 0) return WSEG_OK;
+  const int blocks = (int)((n8 + 255) / 256 < 16384 ? (n8 + 255) / 256 : 16384);
+  if (dtype == WSEG_BF16X3) hipLaunchKernelGGL(f32_to_operand_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, in, op, n8, d);
+  else hipLaunchKernelGGL(f32_to_operand_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, in, op, n8, d);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+
 int launch_im2col_conv1(int dtype, const float* feats, void* a1, int B, int n_mels, int cols, int kp, hipStream_t s) {
   if (n_mels > 96 || 3 * n_mels > kp) { set_error("im2col_conv1: n_mels %d unsupported", n_mels); return WSEG_ERR_INVALID; }
   dim3 grid(cdiv(cols, 32), B);
-  if (dtype == WSEG_BF16) hipLaunchKernelGGL((im2col_conv1_kernel<bf16_t>), grid, dim3(256), 0, s, feats, (bf16_t*)a1, n_mels, cols, kp);
-  else if (dtype == WSEG_F16) hipLaunchKernelGGL((im2col_conv1_kernel<f16_t>), grid, dim3(256), 0, s, feats, (f16_t*)a1, n_mels, cols, kp);
-  else hipLaunchKernelGGL((im2col_conv1_kernel<float>), grid, dim3(256), 0, s, feats, (float*)a1, n_mels, cols, kp);
+#define WSEG_IC1(T_) hipLaunchKernelGGL((im2col_conv1_kernel<T_>), grid, dim3(256), 0, s, feats, a1, n_mels, cols, kp)
+  if (dtype == WSEG_BF16) WSEG_IC1(bf16_t);
+  else if (dtype == WSEG_F16) WSEG_IC1(f16_t);
+  else if (dtype == WSEG_BF16X3) WSEG_IC1(X3<bf16_t>);
+  else if (dtype == WSEG_F16X3) WSEG_IC1(X3<f16_t>);
+  else WSEG_IC1(float);
+#undef WSEG_IC1
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
 
 int launch_im2col_conv2(int dtype, const void* h1, void* a2, int B, int cols, int d, hipStream_t s) {
+  // split-precision rows are 2d 16-bit words per tap, and x3_col() is 32-column-blockwise (d % 32 == 0): the split image of
+  // A2 row [tap0 | tap1 | tap2] is the three split h1 rows back to back — the same 16-byte copy with d -> 2d
+  if (is_x3(dtype)) d *= 2;
   const size_t vec = dtype == WSEG_F32 ? 4 : 8;
   const size_t total = (size_t)B * (cols / 2) * 3 * (d / vec);
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
@@ -444,10 +507,12 @@ int launch_layernorm(int dtype, const float* x, const void* g, const void* b, vo
   if (M <= 0) return WSEG_OK;
   dim3 grid(cdiv(M, 4));
   if (d % 8 || d > 64 * 8 * 4) { set_error("layernorm: d %d unsupported", d); return WSEG_ERR_INVALID; }
-#define WSEG_LN(TO_, NIT_) hipLaunchKernelGGL((layernorm_kernel<TO_, NIT_>), grid, dim3(256), 0, s, x, (const TO_*)g, (const TO_*)b, (TO_*)y, M, d)
+#define WSEG_LN(TO_, NIT_) hipLaunchKernelGGL((layernorm_kernel<TO_, NIT_>), grid, dim3(256), 0, s, x, (const typename IO<TO_>::P*)g, (const typename IO<TO_>::P*)b, y, M, d)
 #define WSEG_LN3(TO_) do { if (d <= 512) WSEG_LN(TO_, 1); else if (d <= 1024) WSEG_LN(TO_, 2); else WSEG_LN(TO_, 4); } while (0)
   if (dtype == WSEG_BF16) WSEG_LN3(bf16_t);
   else if (dtype == WSEG_F16) WSEG_LN3(f16_t);
+  else if (dtype == WSEG_BF16X3) WSEG_LN3(X3<bf16_t>);
+  else if (dtype == WSEG_F16X3) WSEG_LN3(X3<f16_t>);
   else WSEG_LN3(float);
 #undef WSEG_LN3
 #undef WSEG_LN
@@ -455,23 +520,28 @@ int launch_layernorm(int dtype, const float* x, const void* g, const void* b, vo
   return WSEG_OK;
 }
 
+template <typename TO>
+static void launch_enc_attention_f32(const void* q, const void* k, const void* vt, void* out, int B, int H, int T, int Tp, int d, hipStream_t s) {
+  static const bool naive = getenv("WSEG_F32_ATTN") && !strcmp(getenv("WSEG_F32_ATTN"), "naive");   // test knob: same bits either way
+  if (naive || Tp % 128 != 0) {
+    dim3 grid(cdiv(T, 64), B * H);
+    hipLaunchKernelGGL(enc_attention_f32_kernel<TO>, grid, dim3(64), 0, s, (const float*)q, (const float*)k, (const float*)vt, out, H, T, Tp, d);
+  } else {
+    dim3 grid(cdiv(T, 128), B * H);
+    hipLaunchKernelGGL(enc_attention_f32_mfma_kernel<TO>, grid, dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)vt, out, H, T, Tp, d);
+  }
+}
+
 int launch_enc_attention(int dtype, const void* q, const void* k, const void* vt, void* out,
                          int B, int H, int T, int Tp, int d, hipStream_t s) {
-  if (dtype != WSEG_F32) {
+  if (dtype == WSEG_BF16 || dtype == WSEG_F16) {
     if (Tp % 128) { set_error("enc_attention: Tp %d %% 128", Tp); return WSEG_ERR_INVALID; }
     dim3 grid(cdiv(T, 128), B * H);
     if (dtype == WSEG_BF16) hipLaunchKernelGGL(enc_attention_h16_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, T, Tp, d);
     else hipLaunchKernelGGL(enc_attention_h16_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)q, (const f16_t*)k, (const f16_t*)vt, (f16_t*)out, H, T, Tp, d);
-  } else {
-    static const bool naive = getenv("WSEG_F32_ATTN") && !strcmp(getenv("WSEG_F32_ATTN"), "naive");   // test knob: same bits either way
-    if (naive || Tp % 128 != 0) {
-      dim3 grid(cdiv(T, 64), B * H);
-      hipLaunchKernelGGL(enc_attention_f32_kernel, grid, dim3(64), 0, s, (const float*)q, (const float*)k, (const float*)vt, (float*)out, H, T, Tp, d);
-    } else {
-      dim3 grid(cdiv(T, 128), B * H);
-      hipLaunchKernelGGL(enc_attention_f32_mfma_kernel, grid, dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)vt, (float*)out, H, T, Tp, d);
-    }
-  }
+  } else if (dtype == WSEG_BF16X3) launch_enc_attention_f32<X3<bf16_t>>(q, k, vt, out, B, H, T, Tp, d, s);
+  else if (dtype == WSEG_F16X3) launch_enc_attention_f32<X3<f16_t>>(q, k, vt, out, B, H, T, Tp, d, s);
+  else launch_enc_attention_f32<float>(q, k, vt, out, B, H, T, Tp, d, s);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }

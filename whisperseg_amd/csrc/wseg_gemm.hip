@@ -43,20 +43,24 @@ template <> struct Vec4<float> {
   static __device__ __forceinline__ void st(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
 };
 
+// T: element-type tag of the mode (float | bf16_t | f16_t | X3<HT>); PT: its plain parameter type (bias, positional table,
+// q / k / v storage: float in the split-precision modes).  Outputs that are the NEXT GEMM's operand (EPI_STORE, EPI_GELU) go
+// through op_st*, i.e. as hi | lo pairs in the split-precision modes.
 template <int EPI, typename T>
 __device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, float v[4]) {
+  typedef typename IO<T>::P PT;
   if (ep.bias) {
     float b[4];
-    Vec4<T>::ld((const T*)ep.bias + n0, b);
+    Vec4<PT>::ld((const PT*)ep.bias + n0, b);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] += b[i];
   }
   if constexpr (EPI == EPI_STORE) {
-    Vec4<T>::st((T*)ep.out + (size_t)m * ep.ldc + n0, v);
+    op_st4<T>(ep.out, (size_t)m, ep.ldc, n0, v);
   } else if constexpr (EPI == EPI_GELU) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = gelu_for<T>(v[i]);
-    Vec4<T>::st((T*)ep.out + (size_t)m * ep.ldc + n0, v);
+    op_st4<T>(ep.out, (size_t)m, ep.ldc, n0, v);
   } else if constexpr (EPI == EPI_RESID) {      // the residual stream is fp32 in every mode
     float r[4];
     Vec4<float>::ld((const float*)ep.resid + (size_t)m * ep.ldc + n0, r);
@@ -65,7 +69,7 @@ __device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, fl
     Vec4<float>::st((float*)ep.out + (size_t)m * ep.ldc + n0, v);
   } else if constexpr (EPI == EPI_GELU_POS) {   // conv2 -> residual stream (fp32)
     float p[4];
-    Vec4<T>::ld((const T*)ep.pos + (size_t)(m % ep.pos_rows) * ep.ldc + n0, p);
+    Vec4<PT>::ld((const PT*)ep.pos + (size_t)(m % ep.pos_rows) * ep.ldc + n0, p);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = gelu_for<T>(v[i]) + p[i];
     Vec4<float>::st((float*)ep.out + (size_t)m * ep.ldc + n0, v);
@@ -76,20 +80,20 @@ __device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, fl
     if (sec == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] *= ep.scale;
-      Vec4<T>::st((T*)ep.q + (bh * ep.t_pad + t) * 64 + e, v);
+      Vec4<PT>::st((PT*)ep.q + (bh * ep.t_pad + t) * 64 + e, v);
     } else if (sec == 1) {
-      Vec4<T>::st((T*)ep.k + (bh * ep.t_pad + t) * 64 + e, v);
+      Vec4<PT>::st((PT*)ep.k + (bh * ep.t_pad + t) * 64 + e, v);
     } else {
-      T* vt = (T*)ep.v + (bh * 64 + e) * ep.t_pad + t;
+      PT* vt = (PT*)ep.v + (bh * 64 + e) * ep.t_pad + t;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) El<T>::st(vt + (size_t)i * ep.t_pad, v[i]);
+      for (int i = 0; i < 4; ++i) El<PT>::st(vt + (size_t)i * ep.t_pad, v[i]);
     }
   } else if constexpr (EPI == EPI_KV_CROSS) {
     const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
     const int b = m / ep.t_len, t = m - b * ep.t_len;
     const int bs = ep.slot_map ? ep.slot_map[b] : b;
-    T* dst = (T*)(sec == 0 ? ep.k : ep.v) + (((size_t)bs * ep.n_heads + h) * ep.t_len + t) * 64 + e;
-    Vec4<T>::st(dst, v);
+    PT* dst = (PT*)(sec == 0 ? ep.k : ep.v) + (((size_t)bs * ep.n_heads + h) * ep.t_len + t) * 64 + e;
+    Vec4<PT>::st(dst, v);
   } else if constexpr (EPI == EPI_F32) {
     *(float4*)(ep.out_f32 + (size_t)m * ep.ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
   } else if constexpr (EPI == EPI_QKV_DEC) {
@@ -97,38 +101,52 @@ __device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, fl
     if (sec == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] *= ep.scale;
-      Vec4<T>::st((T*)ep.q + (size_t)m * d + nn, v);
+      Vec4<PT>::st((PT*)ep.q + (size_t)m * d + nn, v);
     } else {
       const int pos = ep.pos_ptr[m / ep.pos_div];
-      T* dst = (T*)(sec == 1 ? ep.k : ep.v) + (((size_t)m * ep.n_heads + h) * ep.t_pad + pos) * 64 + e;
-      Vec4<T>::st(dst, v);
+      PT* dst = (PT*)(sec == 1 ? ep.k : ep.v) + (((size_t)m * ep.n_heads + h) * ep.t_pad + pos) * 64 + e;
+      Vec4<PT>::st(dst, v);
     }
   } else if constexpr (EPI == EPI_SCALE) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] *= ep.scale;
-    Vec4<T>::st((T*)ep.out + (size_t)m * ep.ldc + n0, v);
+    Vec4<PT>::st((PT*)ep.out + (size_t)m * ep.ldc + n0, v);
   }
 }
 
-// 8 consecutive columns n0..n0+7 of row m (16-bit paths, LDS-staged epilogue): 16-byte loads / stores.
-template <typename HT> __device__ __forceinline__ void ld8_h(const HT* p, float v[8]) { unpack8<HT>(*(const uint4*)p, v); }
-template <typename HT> __device__ __forceinline__ void st8_h(HT* p, const float v[8]) { *(uint4*)p = pack8<HT>(v); }
+// 8 consecutive columns n0..n0+7 of row m (MFMA paths, LDS-staged epilogue): 16-byte loads / stores.
+template <typename PT> __device__ __forceinline__ void ld8_h(const PT* p, float v[8]) {
+  if constexpr (sizeof(PT) == 4) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+    unpack8<PT>(*(const uint4*)p, v);
+  }
+}
+template <typename PT> __device__ __forceinline__ void st8_h(PT* p, const float v[8]) {
+  if constexpr (sizeof(PT) == 4) {
+    *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    *(uint4*)p = pack8<PT>(v);
+  }
+}
 
-template <int EPI, typename HT>
+template <int EPI, typename T>
 __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, float v[8]) {
-  typedef HT T;
+  typedef typename IO<T>::P PT;
   if (ep.bias) {
     float b[8];
-    ld8_h<T>((const T*)ep.bias + n0, b);
+    ld8_h<PT>((const PT*)ep.bias + n0, b);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] += b[i];
   }
   if constexpr (EPI == EPI_STORE) {
-    st8_h<T>((T*)ep.out + (size_t)m * ep.ldc + n0, v);
+    op_st8<T>(ep.out, (size_t)m, ep.ldc, n0, v);
   } else if constexpr (EPI == EPI_GELU) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = gelu_for<T>(v[i]);
-    st8_h<T>((T*)ep.out + (size_t)m * ep.ldc + n0, v);
+    op_st8<T>(ep.out, (size_t)m, ep.ldc, n0, v);
   } else if constexpr (EPI == EPI_RESID) {      // the residual stream is fp32 in every mode
     const float* rp = (const float*)ep.resid + (size_t)m * ep.ldc + n0;
     const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
@@ -137,7 +155,7 @@ __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, f
     *(float4*)(o + 4) = make_float4(r1.x + v[4], r1.y + v[5], r1.z + v[6], r1.w + v[7]);
   } else if constexpr (EPI == EPI_GELU_POS) {   // conv2 -> residual stream (fp32)
     float p[8];
-    ld8_h<T>((const T*)ep.pos + (size_t)(m % ep.pos_rows) * ep.ldc + n0, p);
+    ld8_h<PT>((const PT*)ep.pos + (size_t)(m % ep.pos_rows) * ep.ldc + n0, p);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = gelu_for<T>(v[i]) + p[i];
     float* o = (float*)ep.out + (size_t)m * ep.ldc + n0;
@@ -150,20 +168,20 @@ __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, f
     if (sec == 0) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] *= ep.scale;
-      st8_h<T>((T*)ep.q + (bh * ep.t_pad + t) * 64 + e, v);
+      st8_h<PT>((PT*)ep.q + (bh * ep.t_pad + t) * 64 + e, v);
     } else if (sec == 1) {
-      st8_h<T>((T*)ep.k + (bh * ep.t_pad + t) * 64 + e, v);
+      st8_h<PT>((PT*)ep.k + (bh * ep.t_pad + t) * 64 + e, v);
     } else {
-      T* vt = (T*)ep.v + (bh * 64 + e) * ep.t_pad + t;
+      PT* vt = (PT*)ep.v + (bh * 64 + e) * ep.t_pad + t;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) vt[(size_t)i * ep.t_pad] = H16<T>::from(v[i]);
+      for (int i = 0; i < 8; ++i) El<PT>::st(vt + (size_t)i * ep.t_pad, v[i]);
     }
   } else if constexpr (EPI == EPI_KV_CROSS) {
     const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
     const int b = m / ep.t_len, t = m - b * ep.t_len;
     const int bs = ep.slot_map ? ep.slot_map[b] : b;
-    T* dst = (T*)(sec == 0 ? ep.k : ep.v) + (((size_t)bs * ep.n_heads + h) * ep.t_len + t) * 64 + e;
-    st8_h<T>(dst, v);
+    PT* dst = (PT*)(sec == 0 ? ep.k : ep.v) + (((size_t)bs * ep.n_heads + h) * ep.t_len + t) * 64 + e;
+    st8_h<PT>(dst, v);
   } else if constexpr (EPI == EPI_F32) {
     float* o = ep.out_f32 + (size_t)m * ep.ldc + n0;
     *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
@@ -192,11 +210,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 __device__ __forceinline__ void lds_reads_done_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // SPLIT: write fp32 partials [z][m_pad][n] (epilogue applied later by splitk_reduce_kernel).
-template <typename HT, int BM, int BN, int WM, int WN, int EPI, bool SPLIT, int NST = 2>
-__global__ __launch_bounds__(WM * WN * 64, (BM <= 128 && BN <= 64 && WM * WN == 4) ? 3 : 1) void gemm_h16_kernel(const HT* __restrict__ A, int lda,
-                                                        const HT* __restrict__ W, int ldw,
+// T = X3<HT> (split-precision modes): A / W rows are hi | lo pairs (wseg_common.h), lda / ldw / k_len count 16-bit words
+// (twice the logical K), and a K tile is multiplied as (W hi, A hi) + (W hi, A lo) + (W lo, A hi).
+template <typename T, int BM, int BN, int WM, int WN, int EPI, bool SPLIT, int NST = 2>
+__global__ __launch_bounds__(WM * WN * 64, (BM <= 128 && BN <= 64 && WM * WN == 4) ? 3 : 1) void gemm_h16_kernel(const typename IO<T>::H* __restrict__ A, int lda,
+                                                        const typename IO<T>::H* __restrict__ W, int ldw,
                                                         int M, int N, int k_len, EpiParams ep,
                                                         float* __restrict__ part, int m_pad, int ntm) {
+  typedef typename IO<T>::H HT;
+  constexpr bool X3M = IO<T>::split;
   constexpr int BK = 64;
   constexpr int TM = BM / WM, TN = BN / WN;      // wave tile
   constexpr int MI = TM / 16, NI = TN / 16;      // 16x16 MFMA tiles per wave
@@ -273,16 +295,24 @@ __global__ __launch_bounds__(WM * WN * 64, (BM <= 128 && BN <= 64 && WM * WN == 
     bf16x8 af0[MI], af1[MI];
 #pragma unroll
     for (int j = 0; j < MI; ++j) af0[j] = lda(0, j);
+    if constexpr (X3M) {                       // the lo halves of the activations are multiplied with the hi weights
+#pragma unroll
+      for (int j = 0; j < MI; ++j) af1[j] = lda(1, j);
+    }
     bf16x8 wcur = ldw(0, 0);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const bf16x8 wnxt = (i + 1 < NI) ? ldw(0, i + 1) : ldw(1, 0);
-      if (i == NI - 1) {
+      if (!X3M && i == NI - 1) {
 #pragma unroll
         for (int j = 0; j < MI; ++j) af1[j] = lda(1, j);
       }
 #pragma unroll
       for (int j = 0; j < MI; ++j) acc[i][j] = H16<HT>::mfma16(wcur, af0[j], acc[i][j]);
+      if constexpr (X3M) {
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = H16<HT>::mfma16(wcur, af1[j], acc[i][j]);
+      }
       wcur = wnxt;
     }
 #pragma unroll
@@ -293,7 +323,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM <= 128 && BN <= 64 && WM * WN == 
       // group (which needs the retired reads anyway) while the other waves arrive
       if (i == NI - 1) lds_reads_done_barrier();
 #pragma unroll
-      for (int j = 0; j < MI; ++j) acc[i][j] = H16<HT>::mfma16(wcur, af1[j], acc[i][j]);
+      for (int j = 0; j < MI; ++j) acc[i][j] = H16<HT>::mfma16(wcur, X3M ? af0[j] : af1[j], acc[i][j]);
       wcur = wnxt;
     }
   };
@@ -344,7 +374,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM <= 128 && BN <= 64 && WM * WN == 
         const float4 a = *(const float4*)(strip + r * LDT + cc), b = *(const float4*)(strip + r * LDT + cc + 4);
         float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
         const int m = m0 + wm * TM + j * 16 + r;
-        if (m < M) epi_apply8<EPI, HT>(ep, m, n0 + wn * TN + cc, v);
+        if (m < M) epi_apply8<EPI, T>(ep, m, n0 + wn * TN + cc, v);
       }
     }
   } else {
@@ -358,7 +388,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM <= 128 && BN <= 64 && WM * WN == 
         if constexpr (SPLIT) {
           *(float4*)(part + ((size_t)blockIdx.z * m_pad + m) * N + n) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-          if (m < M) epi_apply<EPI, HT>(ep, m, n, v);
+          if (m < M) epi_apply<EPI, T>(ep, m, n, v);
         }
       }
     }
@@ -372,16 +402,17 @@ __global__ __launch_bounds__(WM * WN * 64, (BM <= 128 && BN <= 64 && WM * WN == 
 // gfx9, so a load issued after a store cannot be consumed before that store has completed — a bias load per
 // output row made each of the 16 stores a full round trip (measured 16-42 % of a launch).
 // ------------------------------------------------------------------------------------------------
-template <typename HT, int EPI, int MI, int NI>
+template <typename T, int EPI, int MI, int NI>
 __device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NI][MI], float* stage, const EpiParams& ep, int M, int mb,
                                                 int nb, int lane, int wave) {
   static_assert(NI == 4, "64-column wave tiles");
+  typedef typename IO<T>::P PT;
   constexpr int LDT = 64 + 4;
   float* strip = stage + (size_t)wave * 16 * LDT;
   const int fr = lane & 15, fg = lane >> 4, rr = lane >> 3, cc = (lane & 7) * 8;
   const int nc = nb + cc;
   float bv[8];
-  if (ep.bias) ld8_h<HT>((const HT*)ep.bias + nc, bv);
+  if (ep.bias) ld8_h<PT>((const PT*)ep.bias + nc, bv);
   else {
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = 0.f;
@@ -440,9 +471,9 @@ __device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NI][MI], floa
       } else if constexpr (EPI == EPI_KV_CROSS) {
         int mm = m;
         if (ep.slot_map) { const int b = m / ep.t_len; mm = (b == kv_b0 ? kv_s0 : kv_s1) * ep.t_len + (m - b * ep.t_len); }
-        if (m < M) epi_apply8<EPI, HT>(ep2, mm, nc, v);
+        if (m < M) epi_apply8<EPI, T>(ep2, mm, nc, v);
       } else {
-        if (m < M) epi_apply8<EPI, HT>(ep2, m, nc, v);
+        if (m < M) epi_apply8<EPI, T>(ep2, m, nc, v);
       }
     }
   }
@@ -456,10 +487,12 @@ __device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NI][MI], floa
 // Tile order: XCD x (workgroup id % 8, observed dispatch, speed only) owns a contiguous run of the m-fastest /
 // 8-row-group tile order; its workgroups interleave over that run, so tiles in flight on one L2 are neighbours.
 // ------------------------------------------------------------------------------------------------
-template <typename HT, int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_h16_persist_kernel(const HT* __restrict__ A, int lda,
-                                                                         const HT* __restrict__ W, int ldw, int M, int N,
+template <typename T, int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_h16_persist_kernel(const typename IO<T>::H* __restrict__ A, int lda,
+                                                                         const typename IO<T>::H* __restrict__ W, int ldw, int M, int N,
                                                                          int K, EpiParams ep, int ntm, int GM) {
+  typedef typename IO<T>::H HT;
+  constexpr bool X3M = IO<T>::split;
   constexpr int BK = 64;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 16, NI = TN / 16;
@@ -550,16 +583,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h16_persist_kernel(const HT
       bf16x8 af0[MI], af1[MI];
 #pragma unroll
       for (int j = 0; j < MI; ++j) af0[j] = lda_f(0, j);
+      if constexpr (X3M) {
+#pragma unroll
+        for (int j = 0; j < MI; ++j) af1[j] = lda_f(1, j);
+      }
       bf16x8 wcur = ldw_f(0, 0);
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const bf16x8 wnxt = (i + 1 < NI) ? ldw_f(0, i + 1) : ldw_f(1, 0);
-        if (i == NI - 1) {
+        if (!X3M && i == NI - 1) {
 #pragma unroll
           for (int j = 0; j < MI; ++j) af1[j] = lda_f(1, j);
         }
 #pragma unroll
         for (int j = 0; j < MI; ++j) acc[i][j] = H16<HT>::mfma16(wcur, af0[j], acc[i][j]);
+        if constexpr (X3M) {
+#pragma unroll
+          for (int j = 0; j < MI; ++j) acc[i][j] = H16<HT>::mfma16(wcur, af1[j], acc[i][j]);
+        }
         wcur = wnxt;
       }
 #pragma unroll
@@ -568,13 +609,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h16_persist_kernel(const HT
         if (i + 1 < NI) wnxt = ldw_f(1, i + 1);
         if (i == NI - 1) lds_reads_done_barrier();  // all fragment reads retired: the stage may be refilled
 #pragma unroll
-        for (int j = 0; j < MI; ++j) acc[i][j] = H16<HT>::mfma16(wcur, af1[j], acc[i][j]);
+        for (int j = 0; j < MI; ++j) acc[i][j] = H16<HT>::mfma16(wcur, X3M ? af0[j] : af1[j], acc[i][j]);
         wcur = wnxt;
       }
     }
     g += nk;
     // LDS-staged epilogue in the stage consumed last ((g-1)&1); the other stage is receiving the next tile
-    staged_epilogue<HT, EPI, MI, NI>(acc, (float*)(smem + ((g - 1) & 1) * STAGE), ep, M, m0 + wm * TM, n0 + wn * TN, lane, wave);
+    staged_epilogue<T, EPI, MI, NI>(acc, (float*)(smem + ((g - 1) & 1) * STAGE), ep, M, m0 + wm * TM, n0 + wn * TN, lane, wave);
     if (!has_next) break;
     __builtin_amdgcn_s_barrier();                   // every wave is done with its strip before the stage is refilled
     m0 = nm0; n0 = nn0; idx = nidx;
@@ -610,9 +651,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h16_persist_kernel(const HT
 // leaves buffer e & 1 to the epilogue as its staging area: the B pair of K tile e+2 is held back to phase 1 of K tile
 // e+1, which both groups reach only after the barrier that closes the (shared) epilogue interval.
 // ------------------------------------------------------------------------------------------------
-template <typename HT, int EPI>
-__global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const HT* __restrict__ A, int lda, const HT* __restrict__ W,
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::H* __restrict__ A, int lda, const typename IO<T>::H* __restrict__ W,
                                                           int ldw, int M, int N, int K, EpiParams ep, int ntm, int GM) {
+  typedef typename IO<T>::H HT;
+  constexpr bool X3M = IO<T>::split;      // hi | lo K tiles: 24 instead of 16 MFMAs per phase, (W hi, A hi) (W hi, A lo) (W lo, A hi)
   constexpr int BM = 256, BN = 256, BK = 64, TM = 128, TN = 64, MI = 8, NI = 4;
   constexpr int HTILE = 128 * BK;                      // elements per half-tile (16 KB)
   constexpr int BUF = 4 * HTILE;                       // elements per K-tile buffer: [A0 | A1 | B0 | B1]
@@ -628,7 +671,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const HT* __restrict__
   const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   const int count = q + (xcd < r ? 1 : 0);
   if (loc >= count) return;
-  const int T = ((count - loc + bpx - 1) / bpx) * nk;      // K tiles this workgroup consumes
+  const int KT = ((count - loc + bpx - 1) / bpx) * nk;      // K tiles this workgroup consumes
   auto tile_coords = [&](int swz, int& m0, int& n0) {
     const int per_group = GM * ntn, grp = swz / per_group, rem = swz - grp * per_group;
     const int gm = min(GM, ntm - grp * GM);
@@ -682,7 +725,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const HT* __restrict__
 
   // prologue: K tile 0 complete, B pair of K tile 1 in flight
   issue_b(0); issue_b(1); issue_a(0); issue_a(1);
-  if (T > 1) { issue_b(0); issue_b(1); wait_vmcnt<4>(); }
+  if (KT > 1) { issue_b(0); issue_b(1); wait_vmcnt<4>(); }
   else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();          // stagger: group 1 runs one barrier behind group 0
@@ -698,10 +741,10 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const HT* __restrict__
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                                \
     __builtin_amdgcn_s_setprio(1);                                                                                    \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                                  \
+    _Pragma("unroll") for (int kk = 0; kk < (X3M ? 3 : 2); ++kk)                                                      \
       _Pragma("unroll") for (int i = 2 * (IB); i < 2 * (IB) + 2; ++i)                                                 \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
-          acc[i][4 * (JA) + j] = H16<HT>::mfma16(bfr[i][kk], afr[j][kk], acc[i][4 * (JA) + j]); \
+          acc[i][4 * (JA) + j] = H16<HT>::mfma16(bfr[i][X3M ? (kk >> 1) : kk], afr[j][X3M ? (kk & 1) : kk], acc[i][4 * (JA) + j]); \
     __builtin_amdgcn_s_setprio(0);                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                                \
   } while (0)
@@ -740,8 +783,8 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const HT* __restrict__
       bfr[i][0] = *(const bf16x8*)(cur + i * 16 * BK + fb0);
       bfr[i][1] = *(const bf16x8*)(cur + i * 16 * BK + fb1);
     }
-    if (first && g + 1 < T) { issue_b(0); issue_b(1); }        // B pair of K tile g+1, held back over the epilogue
-    if (g + 1 < T) { issue_a(0); issue_a(1); }                 // A pair of K tile g+1
+    if (first && g + 1 < KT) { issue_b(0); issue_b(1); }        // B pair of K tile g+1, held back over the epilogue
+    if (g + 1 < KT) { issue_a(0); issue_a(1); }                 // A pair of K tile g+1
     __builtin_amdgcn_sched_barrier(0);
     WSEG_PP_MFMA(0, 1);
     __builtin_amdgcn_s_barrier();
@@ -755,7 +798,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const HT* __restrict__
     WSEG_PP_MFMA(1, 1);
     __builtin_amdgcn_s_barrier();
     // ---- phase 3: quadrant (a1, b0); B pair of K tile g+2, retire K tile g+1 ----
-    if (!final && g + 2 < T) { issue_b(0); issue_b(1); wait_vmcnt<4>(); }      // B pair of K tile g+2
+    if (!final && g + 2 < KT) { issue_b(0); issue_b(1); wait_vmcnt<4>(); }      // B pair of K tile g+2
     else wait_vmcnt<0>();
     __builtin_amdgcn_sched_barrier(0);
     WSEG_PP_MFMA(1, 0);
@@ -768,7 +811,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const HT* __restrict__
   // is prefetched into that buffer before phase 1 of the next K tile, which both groups reach only after the barrier
   // below.  (Requesting group 0's residual rows before its idle interval measured no further gain.)
   if (wr == 0) __builtin_amdgcn_s_barrier();
-  staged_epilogue<HT, EPI, MI, NI>(acc, (float*)(smem + ((g - 1) & 1) * BUF), ep, M, m0 + wr * TM, n0 + wc * TN, lane, wave);
+  staged_epilogue<T, EPI, MI, NI>(acc, (float*)(smem + ((g - 1) & 1) * BUF), ep, M, m0 + wr * TM, n0 + wc * TN, lane, wave);
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();
   }
@@ -1084,8 +1127,9 @@ static SkinnyPlan plan_skinny(const GemmArgs& g) {
 }
 
 // fp32 partial sums [splits][m_pad][N] into g.splitk_ws (valid for splits == 1 too)
-template <typename HT>
+template <typename T>
 static int launch_skinny_partial(const GemmArgs& g, const SkinnyPlan& sp, hipStream_t s) {
+  typedef typename IO<T>::H HT;
   const HT* A = (const HT*)g.A;
   const HT* W = (const HT*)g.W;
   if (!g.splitk_ws || (size_t)sp.splits * sp.m_pad * g.N * sizeof(float) > g.splitk_ws_bytes) {
@@ -1102,7 +1146,7 @@ static int launch_skinny_partial(const GemmArgs& g, const SkinnyPlan& sp, hipStr
   // us): a K tile costs ~0.6 us of serialised issue -> land -> barrier -> fragment reads -> MFMA -> barrier per workgroup,
   // while a bare LDS-DMA stream of the same L2-resident data runs at 123 GB/s per CU (tools/probes/l2fill_probe.hip).
 #define WSEG_SKINNY_P(BM_, WM_, WN_)                                                                                     \
-  hipLaunchKernelGGL((gemm_h16_kernel<HT, BM_, 64, WM_, WN_, EPI_STORE, true, 2>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, \
+  hipLaunchKernelGGL((gemm_h16_kernel<T, BM_, 64, WM_, WN_, EPI_STORE, true, 2>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, \
                      g.N, sp.k_len, g.ep, g.splitk_ws, sp.m_pad, 0)
   if (sp.bm == 32) WSEG_SKINNY_P(32, 1, 4);
   else if (sp.bm == 64) WSEG_SKINNY_P(64, 1, 4);
@@ -1114,11 +1158,12 @@ static int launch_skinny_partial(const GemmArgs& g, const SkinnyPlan& sp, hipStr
 
 // x[m][:] += bias + sum_z part[z][m][:]  (x is the fp32 residual stream), then y[m][:] = LayerNorm(x[m][:]) in the model dtype.
 // One workgroup per row, one 8-element chunk per thread (d <= 2048), all split partials loaded up front.
-template <typename HT>
+template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_resid_ln_kernel(const float* __restrict__ part, int splits, int m_pad, int M,
-                                                                     int d, const HT* __restrict__ bias, float* __restrict__ x,
-                                                                     const HT* __restrict__ gam, const HT* __restrict__ bet,
-                                                                     HT* __restrict__ y) {
+                                                                     int d, const typename IO<T>::P* __restrict__ bias, float* __restrict__ x,
+                                                                     const typename IO<T>::P* __restrict__ gam, const typename IO<T>::P* __restrict__ bet,
+                                                                     void* __restrict__ y) {
+  typedef typename IO<T>::P PT;
   __shared__ float s_red[4];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = tid * 8;
@@ -1138,7 +1183,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_resid_ln_kernel(const float
     const float4 x0 = *(const float4*)xp, x1 = *(const float4*)(xp + 4);
     const float r[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
     float bb[8];
-    unpack8<HT>(*(const uint4*)(bias + c), bb);
+    ld8_h<PT>(bias + c, bb);
 #pragma unroll
     for (int j = 0; j < 8; ++j) { v[j] = r[j] + (a[j] + bb[j]); sum += v[j]; }
     *(float4*)xp = make_float4(v[0], v[1], v[2], v[3]);
@@ -1160,11 +1205,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_resid_ln_kernel(const float
   const float rstd = 1.0f / sqrtf(((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / (float)d + 1e-5f);
   if (act) {
     float gg[8], be[8], o[8];
-    unpack8<HT>(*(const uint4*)(gam + c), gg);
-    unpack8<HT>(*(const uint4*)(bet + c), be);
+    ld8_h<PT>(gam + c, gg);
+    ld8_h<PT>(bet + c, be);
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (v[j] - mean) * rstd * gg[j] + be[j];
-    *(uint4*)(y + (size_t)row * d + c) = pack8<HT>(o);
+    op_st8<T>(y, (size_t)row, d, c, o);
   }
 }
 
@@ -1177,18 +1222,27 @@ static bool big_tile_path(const GemmArgs& g) {
   return g.M > 128 && g.N % 128 == 0 && (long)cdiv(g.M, 128) * (g.N / 128) >= big_min;
 }
 
-template <int EPI, typename HT>
-static int launch_h16(const GemmArgs& g, hipStream_t s) {
+// Split-precision modes: the caller's K / lda / ldw are LOGICAL; the kernels see rows of 2K 16-bit words.
+template <typename T> static GemmArgs kernel_view(const GemmArgs& g0) {
+  GemmArgs g = g0;
+  if (IO<T>::split) { g.K *= 2; g.lda *= 2; g.ldw *= 2; }
+  return g;
+}
+
+template <int EPI, typename T>
+static int launch_h16(const GemmArgs& g0, hipStream_t s) {
+  typedef typename IO<T>::H HT;
+  const GemmArgs g = kernel_view<T>(g0);
   const HT* A = (const HT*)g.A;
   const HT* W = (const HT*)g.W;
-  if (g.K % 64 || g.N % 64) { set_error("gemm bf16: K %d / N %d not tile multiples", g.K, g.N); return WSEG_ERR_INVALID; }
+  if (g.K % 64 || g.N % 64) { set_error("gemm h16: K %d / N %d not tile multiples", g.K, g.N); return WSEG_ERR_INVALID; }
   if (big_tile_path(g)) {
     static const bool no_swz = getenv("WSEG_NO_XCD_SWIZZLE") != nullptr;
     static const bool big256 = getenv("WSEG_GEMM_128") == nullptr;   // 256x256 tiles by default where they fill the chip
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g_prof.on) {
       std::lock_guard<std::mutex> lk(g_prof.mu);
-      e0 = g_prof.get(); e1 = g_prof.get(); g_prof.flops.push_back(2.0 * g.M * g.N * g.K); (void)hipEventRecord(e0, s);
+      e0 = g_prof.get(); e1 = g_prof.get(); g_prof.flops.push_back(2.0 * g0.M * g0.N * g0.K); (void)hipEventRecord(e0, s);
     }
     static const bool persist = getenv("WSEG_GEMM_NO_PERSIST") == nullptr;
     // m-tiles per tile group of the persistent order: the 32 tiles in flight on one XCD then span ~4 activation tiles x 8
@@ -1210,15 +1264,15 @@ static int launch_h16(const GemmArgs& g, hipStream_t s) {
       if (pingpong && g.K >= 128) {
         int grid = ntiles < n_cu ? ntiles : n_cu;
         grid &= ~7;
-        hipLaunchKernelGGL((gemm_h16_pp_kernel<HT, EPI>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K, g.ep, ntm,
+        hipLaunchKernelGGL((gemm_h16_pp_kernel<T, EPI>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K, g.ep, ntm,
                            group_m);
       } else if (persist) {
         int grid = ntiles < n_cu ? ntiles : n_cu;
         grid &= ~7;
-        hipLaunchKernelGGL((gemm_h16_persist_kernel<HT, 256, 256, 2, 4, EPI>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
+        hipLaunchKernelGGL((gemm_h16_persist_kernel<T, 256, 256, 2, 4, EPI>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
                            g.K, g.ep, ntm, group_m);
       } else {
-        hipLaunchKernelGGL((gemm_h16_kernel<HT, 256, 256, 2, 4, EPI, false>), dim3(ntiles), dim3(512), 0, s, A, g.lda, W, g.ldw,
+        hipLaunchKernelGGL((gemm_h16_kernel<T, 256, 256, 2, 4, EPI, false>), dim3(ntiles), dim3(512), 0, s, A, g.lda, W, g.ldw,
                            g.M, g.N, g.K, g.ep, (float*)nullptr, 0, ntm);
       }
     } else {
@@ -1226,12 +1280,12 @@ static int launch_h16(const GemmArgs& g, hipStream_t s) {
       if (persist && !no_swz && ntiles >= 16) {
         int grid = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;
         grid &= ~7;
-        hipLaunchKernelGGL((gemm_h16_persist_kernel<HT, 128, 128, 2, 2, EPI>), dim3(grid), dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
+        hipLaunchKernelGGL((gemm_h16_persist_kernel<T, 128, 128, 2, 2, EPI>), dim3(grid), dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
                            g.K, g.ep, ntm, group_m);
       } else {
         dim3 grid(g.N / 128, ntm, 1);
         if (!no_swz) grid = dim3(ntiles, 1, 1);
-        hipLaunchKernelGGL((gemm_h16_kernel<HT, 128, 128, 2, 2, EPI, false>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
+        hipLaunchKernelGGL((gemm_h16_kernel<T, 128, 128, 2, 2, EPI, false>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
                            g.K, g.ep, (float*)nullptr, 0, no_swz ? 0 : ntm);
       }
     }
@@ -1243,7 +1297,7 @@ static int launch_h16(const GemmArgs& g, hipStream_t s) {
   if (sp.splits == 1) {
     dim3 grid(g.N / 64, sp.mt, 1);
 #define WSEG_SKINNY(BM_, WM_, WN_)                                                                                      \
-  hipLaunchKernelGGL((gemm_h16_kernel<HT, BM_, 64, WM_, WN_, EPI, false, 2>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, \
+  hipLaunchKernelGGL((gemm_h16_kernel<T, BM_, 64, WM_, WN_, EPI, false, 2>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, \
                      g.K, g.ep, (float*)nullptr, sp.m_pad, 0)
     if (sp.bm == 32) WSEG_SKINNY(32, 1, 4);
     else if (sp.bm == 64) WSEG_SKINNY(64, 1, 4);
@@ -1252,9 +1306,9 @@ static int launch_h16(const GemmArgs& g, hipStream_t s) {
     WSEG_LAUNCH_CHECK();
     return WSEG_OK;
   }
-  WSEG_TRY_(launch_skinny_partial<HT>(g, sp, s));
+  WSEG_TRY_(launch_skinny_partial<T>(g, sp, s));
   const int work = g.M * (g.N / 4);
-  hipLaunchKernelGGL((splitk_reduce_kernel<EPI, HT>), dim3(cdiv(work, 256)), dim3(256), 0, s, g.splitk_ws, sp.splits, sp.m_pad, g.M, g.N, g.ep);
+  hipLaunchKernelGGL((splitk_reduce_kernel<EPI, T>), dim3(cdiv(work, 256)), dim3(256), 0, s, g.splitk_ws, sp.splits, sp.m_pad, g.M, g.N, g.ep);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
@@ -1296,50 +1350,69 @@ template <int EPI>
 static int launch_any(int dtype, const GemmArgs& g, hipStream_t s) {
   if (dtype == WSEG_BF16) return launch_h16<EPI, bf16_t>(g, s);
   if (dtype == WSEG_F16) return launch_h16<EPI, f16_t>(g, s);
+  if (dtype == WSEG_BF16X3) return launch_h16<EPI, X3<bf16_t>>(g, s);
+  if (dtype == WSEG_F16X3) return launch_h16<EPI, X3<f16_t>>(g, s);
   return launch_f32<EPI>(g, s);
 }
 
-int launch_gemm_partial(int dtype, const GemmArgs& g, PartialInfo* info, bool* ok, hipStream_t s) {
-  *ok = false;
-  const bool big = big_tile_path(g);
-  if (dtype == WSEG_F32 || big || !g.splitk_ws || g.K % 64 || g.N % 64) return WSEG_OK;
+template <typename T>
+static int gemm_partial_t(const GemmArgs& g0, PartialInfo* info, bool* ok, hipStream_t s) {
+  const GemmArgs g = kernel_view<T>(g0);
+  if (big_tile_path(g) || !g.splitk_ws || g.K % 64 || g.N % 64) return WSEG_OK;
   SkinnyPlan sp = plan_skinny(g);
   if ((size_t)sp.splits * sp.m_pad * g.N * sizeof(float) > g.splitk_ws_bytes) return WSEG_OK;
-  if (dtype == WSEG_BF16) WSEG_TRY_(launch_skinny_partial<bf16_t>(g, sp, s));
-  else WSEG_TRY_(launch_skinny_partial<f16_t>(g, sp, s));
+  WSEG_TRY_(launch_skinny_partial<T>(g, sp, s));
   info->part = g.splitk_ws; info->splits = sp.splits; info->m_pad = sp.m_pad; info->n = g.N;
   *ok = true;
   return WSEG_OK;
 }
 
-// x = x + (A W^T + bias); y = LayerNorm(x) * gamma + beta.   bf16 decoder rows: split-K partials + ONE fused
-// reduction/residual/LayerNorm kernel; otherwise the generic GEMM (EPI_RESID) followed by launch_layernorm.
-int launch_gemm_resid_ln(int dtype, const GemmArgs& g0, const void* gamma, const void* beta, void* y, hipStream_t s) {
-  GemmArgs g = g0;
-  const int d = g.N;
-  const bool big = big_tile_path(g);
-  if (dtype != WSEG_F32 && !big && g.splitk_ws && d % 8 == 0 && d <= 2048 && g.ep.bias && g.ep.resid == g.ep.out && g.ep.ldc == d &&
-      g.K % 64 == 0 && g.N % 64 == 0) {
-    SkinnyPlan sp = plan_skinny(g);
-    static const bool fuse_unsplit = getenv("WSEG_RESID_LN_ALWAYS_PARTIAL") == nullptr;   // tuning knob
-    // K not split (enough row tiles to fill the chip, 2048+ rows): the fp32 partial round trip buys nothing; the GEMM adds
-    // the residual in its own epilogue and a LayerNorm launch follows (2048 rows: 21.6 + ~6 us against 26.7 + 8.9 us)
-    if ((sp.splits > 1 || !fuse_unsplit) && (size_t)sp.splits * sp.m_pad * g.N * sizeof(float) <= g.splitk_ws_bytes) {
-      if (dtype == WSEG_BF16) {
-        WSEG_TRY_(launch_skinny_partial<bf16_t>(g, sp, s));
-        hipLaunchKernelGGL(splitk_reduce_resid_ln_kernel<bf16_t>, dim3(g.M), dim3(256), 0, s, g.splitk_ws, sp.splits, sp.m_pad, g.M, d,
-                           (const bf16_t*)g.ep.bias, (float*)g.ep.out, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y);
-      } else {
-        WSEG_TRY_(launch_skinny_partial<f16_t>(g, sp, s));
-        hipLaunchKernelGGL(splitk_reduce_resid_ln_kernel<f16_t>, dim3(g.M), dim3(256), 0, s, g.splitk_ws, sp.splits, sp.m_pad, g.M, d,
-                           (const f16_t*)g.ep.bias, (float*)g.ep.out, (const f16_t*)gamma, (const f16_t*)beta, (f16_t*)y);
-      }
-      WSEG_LAUNCH_CHECK();
-      return WSEG_OK;
-    }
+int launch_gemm_partial(int dtype, const GemmArgs& g, PartialInfo* info, bool* ok, hipStream_t s) {
+  *ok = false;
+  switch (dtype) {
+    case WSEG_BF16: return gemm_partial_t<bf16_t>(g, info, ok, s);
+    case WSEG_F16: return gemm_partial_t<f16_t>(g, info, ok, s);
+    case WSEG_BF16X3: return gemm_partial_t<X3<bf16_t>>(g, info, ok, s);
+    case WSEG_F16X3: return gemm_partial_t<X3<f16_t>>(g, info, ok, s);
+    default: return WSEG_OK;      // exact-parity mode: no split-K (one k-ordered chain per output)
   }
+}
+
+// x = x + (A W^T + bias); y = LayerNorm(x) * gamma + beta.   MFMA decoder rows: split-K partials + ONE fused
+// reduction/residual/LayerNorm kernel; otherwise the generic GEMM (EPI_RESID) followed by launch_layernorm.
+template <typename T>
+static int gemm_resid_ln_t(const GemmArgs& g0, const void* gamma, const void* beta, void* y, bool* done, hipStream_t s) {
+  typedef typename IO<T>::P PT;
+  const GemmArgs g = kernel_view<T>(g0);
+  const int d = g.N;
+  if (big_tile_path(g) || !g.splitk_ws || d % 8 || d > 2048 || !g.ep.bias || g.ep.resid != g.ep.out || g.ep.ldc != d || g.K % 64 ||
+      g.N % 64)
+    return WSEG_OK;
+  SkinnyPlan sp = plan_skinny(g);
+  static const bool fuse_unsplit = getenv("WSEG_RESID_LN_ALWAYS_PARTIAL") == nullptr;   // tuning knob
+  // K not split (enough row tiles to fill the chip, 2048+ rows): the fp32 partial round trip buys nothing; the GEMM adds
+  // the residual in its own epilogue and a LayerNorm launch follows (2048 rows: 21.6 + ~6 us against 26.7 + 8.9 us)
+  if (!(sp.splits > 1 || !fuse_unsplit) || (size_t)sp.splits * sp.m_pad * g.N * sizeof(float) > g.splitk_ws_bytes) return WSEG_OK;
+  WSEG_TRY_(launch_skinny_partial<T>(g, sp, s));
+  hipLaunchKernelGGL(splitk_reduce_resid_ln_kernel<T>, dim3(g.M), dim3(256), 0, s, g.splitk_ws, sp.splits, sp.m_pad, g.M, d,
+                     (const PT*)g.ep.bias, (float*)g.ep.out, (const PT*)gamma, (const PT*)beta, y);
+  WSEG_LAUNCH_CHECK();
+  *done = true;
+  return WSEG_OK;
+}
+
+int launch_gemm_resid_ln(int dtype, const GemmArgs& g, const void* gamma, const void* beta, void* y, hipStream_t s) {
+  bool done = false;
+  switch (dtype) {
+    case WSEG_BF16: WSEG_TRY_(gemm_resid_ln_t<bf16_t>(g, gamma, beta, y, &done, s)); break;
+    case WSEG_F16: WSEG_TRY_(gemm_resid_ln_t<f16_t>(g, gamma, beta, y, &done, s)); break;
+    case WSEG_BF16X3: WSEG_TRY_(gemm_resid_ln_t<X3<bf16_t>>(g, gamma, beta, y, &done, s)); break;
+    case WSEG_F16X3: WSEG_TRY_(gemm_resid_ln_t<X3<f16_t>>(g, gamma, beta, y, &done, s)); break;
+    default: break;
+  }
+  if (done) return WSEG_OK;
   WSEG_TRY_(launch_gemm(dtype, EPI_RESID, g, s));
-  return launch_layernorm(dtype, (const float*)g.ep.out, gamma, beta, y, g.M, d, s);
+  return launch_layernorm(dtype, (const float*)g.ep.out, gamma, beta, y, g.M, g.N, s);
 }
 
 int launch_gemm(int dtype, EpiKind epi, const GemmArgs& g, hipStream_t s) {

@@ -51,8 +51,10 @@ struct GemmArgs {
   size_t splitk_ws_bytes = 0;
 };
 
-// dtype: WSEG_F32 (exact VALU kernel) or WSEG_BF16 (MFMA).  M may be any value as long as A has
-// round_up(M,256) readable rows; N % 128 == 0 rows of W readable; K % 64 == 0.
+// dtype: WSEG_F32 (exact kernels), WSEG_BF16 / WSEG_F16 (MFMA) or WSEG_BF16X3 / WSEG_F16X3 (split-precision MFMA: A and W
+// are hi | lo operand rows, K / lda / ldw stay LOGICAL, bias / q / k / v are fp32, EPI_STORE / EPI_GELU write operand rows).
+// M may be any value as long as A has round_up(M,256) readable rows; N % 128 == 0 rows of W readable; K % 64 == 0
+// (K % 32 == 0 in the split-precision modes).
 int launch_gemm(int dtype, EpiKind epi, const GemmArgs& g, hipStream_t s);
 // Split-K partial sums only (bf16 decoder rows): part[z][m_pad][N] fp32 in g.splitk_ws, no epilogue.  The consumer
 // kernel (decoder self-/cross-attention) finishes the reduction itself.  Returns false in *ok when the shape is not
@@ -74,6 +76,10 @@ int launch_layernorm(int dtype, const float* x, const void* g, const void* b, vo
 // Encoder self-attention over Q,K [B][H][Tp][64], Vt [B][H][64][Tp] (q pre-scaled) -> out [B*T][d].
 int launch_enc_attention(int dtype, const void* q, const void* k, const void* vt, void* out,
                          int B, int H, int T, int Tp, int d, hipStream_t s);
+
+// Split-precision modes only: operand rows (hi | lo pairs, wseg_common.h) [M][2d words] <-> fp32 [M][d], d % 32 == 0.
+int launch_operand_to_f32(int dtype, const void* op, float* out, size_t M, int d, hipStream_t s);
+int launch_f32_to_operand(int dtype, const float* in, void* op, size_t M, int d, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // Decoder-side kernels (wseg_dec.hip)

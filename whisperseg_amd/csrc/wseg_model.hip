@@ -73,6 +73,7 @@ struct Lane {
 struct wseg_model {
   wseg_model_config cfg;
   size_t es;                 // element size of the model dtype
+  bool x3 = false;           // split-precision mode (GEMM operands are hi | lo rows, everything else fp32)
   int kp1, vp, tp;           // conv1 K padded, vocab padded, encoder positions padded
   std::map<std::string, Slot> slots;
   const void *conv1_w, *conv1_b, *conv2_w, *conv2_b, *enc_pos, *enc_ln_g, *enc_ln_b;
@@ -170,7 +171,7 @@ int check_geometry(const wseg_model_config& c) {
   if (c.spec_cols != 2 * c.enc_positions || c.enc_positions > 512 || c.enc_positions < 128) { set_error("spec_cols %d / enc_positions %d unsupported", c.spec_cols, c.enc_positions); return WSEG_ERR_INVALID; }
   if (c.n_mels <= 0 || c.n_mels > 96) { set_error("n_mels %d unsupported", c.n_mels); return WSEG_ERR_INVALID; }
   if (c.dec_positions <= 0 || c.dec_positions > 512) { set_error("dec_positions %d unsupported", c.dec_positions); return WSEG_ERR_INVALID; }
-  if (c.dtype != WSEG_F32 && c.dtype != WSEG_BF16 && c.dtype != WSEG_F16) { set_error("dtype %d unsupported", c.dtype); return WSEG_ERR_INVALID; }
+  if (c.dtype < WSEG_F32 || c.dtype > WSEG_F16X3) { set_error("dtype %d unsupported", c.dtype); return WSEG_ERR_INVALID; }
   if (c.enc_layers <= 0 || c.dec_layers <= 0 || c.vocab <= 0) { set_error("bad layer/vocab counts"); return WSEG_ERR_INVALID; }
   return WSEG_OK;
 }
@@ -301,7 +302,10 @@ extern "C" int wseg_model_create(const wseg_model_config* cfg, wseg_model** out)
   WSEG_TRY(check_geometry(*cfg));
   wseg_model* m = new wseg_model();
   m->cfg = *cfg;
-  m->es = cfg->dtype == WSEG_F32 ? 4 : 2;
+  // bytes per element of weights, parameters and activations: 2 in the 16-bit modes; 4 in f32 AND in the split-precision
+  // modes, whose tensors are either fp32 or hi | lo pairs of 16-bit words
+  m->es = (cfg->dtype == WSEG_BF16 || cfg->dtype == WSEG_F16) ? 2 : 4;
+  m->x3 = cfg->dtype == WSEG_BF16X3 || cfg->dtype == WSEG_F16X3;
   m->kp1 = (int)align_up((size_t)3 * cfg->n_mels, 64);
   m->vp = (int)align_up((size_t)cfg->vocab, 128);
   m->tp = (int)align_up((size_t)cfg->enc_positions, 128);
@@ -405,8 +409,9 @@ extern "C" int wseg_encode(wseg_model* m, const float* feats, int32_t n_windows,
   make_plan(m, n_windows, 1, 8, aligned_base(workspace), p);
   if (p.total + 256 > workspace_bytes) { set_error("workspace too small: need %zu, have %zu", p.total + 256, workspace_bytes); return WSEG_ERR_STATE; }
   WSEG_TRY(run_encoder(m, feats, n_windows, p, p.enc_out, s));
-  const size_t bytes = (size_t)n_windows * m->cfg.enc_positions * m->cfg.d_model * m->es;
-  WSEG_HIP_CHECK(hipMemcpyAsync(enc_out, p.enc_out, bytes, hipMemcpyDeviceToDevice, s));
+  const size_t rows = (size_t)n_windows * m->cfg.enc_positions;
+  if (m->x3) return launch_operand_to_f32(m->cfg.dtype, p.enc_out, (float*)enc_out, rows, m->cfg.d_model, s);
+  WSEG_HIP_CHECK(hipMemcpyAsync(enc_out, p.enc_out, rows * m->cfg.d_model * m->es, hipMemcpyDeviceToDevice, s));
   return WSEG_OK;
 }
 
@@ -541,7 +546,9 @@ static int generate_lane(wseg_model* m, Lane& ln, int n_lanes, const float* feat
     int e0, e1, e2;
     WSEG_TRY(timing_event(ln, s, &e0));
     const char* enc_rows = p.enc_out;
-    if (gp->encoder_output) enc_rows = (const char*)gp->encoder_output + (size_t)w0 * Tk * d * m->es;
+    if (gp->encoder_output && m->x3)      // handed over as fp32: re-split into operand rows for the cross-K/V GEMMs
+      WSEG_TRY(launch_f32_to_operand(c.dtype, (const float*)gp->encoder_output + (size_t)w0 * Tk * d, p.enc_out, (size_t)n * Tk, d, s));
+    else if (gp->encoder_output) enc_rows = (const char*)gp->encoder_output + (size_t)w0 * Tk * d * m->es;
     else WSEG_TRY(run_encoder(m, feats + (size_t)w0 * feat_stride, n, p, p.enc_out, s));
     WSEG_TRY(timing_event(ln, s, &e1));
     for (int l = 0; l < c.dec_layers; ++l) {     // cross-attention K/V of every decoder layer, once per window (shared by its beams)

@@ -14,7 +14,46 @@ import torch
 
 from . import _lib
 
-DTYPES = {"f32": (0, torch.float32), "bf16": (1, torch.bfloat16), "f16": (2, torch.float16)}
+# name -> (wseg_dtype, torch dtype of parameters and activations).  "bf16x3" / "f16x3" are the split-precision modes
+# (include/wseg.h): fp32 everywhere except that GEMM operands travel as hi + lo 16-bit pairs and are multiplied with three
+# MFMAs per product; their weight MATRICES are attached pre-split (split_operand), everything else is float32.
+DTYPES = {"f32": (0, torch.float32), "bf16": (1, torch.bfloat16), "f16": (2, torch.float16),
+          "bf16x3": (3, torch.float32), "f16x3": (4, torch.float32)}
+SPLIT_BASE = {"bf16x3": torch.bfloat16, "f16x3": torch.float16}
+
+
+def is_gemm_weight(name):
+    """Tensors that are the W operand of a GEMM (the token embedding doubles as the LM head)."""
+    return name.endswith(".w") or name == "dec.tok"
+
+
+def split_operand(w, base):
+    """fp32 [N, K] (K % 32 == 0) -> int16 [N, 2K] operand rows of the split-precision modes: hi = rn(w), lo = rn(w - hi) in
+    the 16-bit type `base`, every 32 logical columns stored as [32 hi | 32 lo] (csrc/wseg_common.h)."""
+    n, k = w.shape
+    if k % 32:
+        raise ValueError("split_operand: K must be a multiple of 32")
+    w = w.float()
+    hi = w.to(base)
+    lo = (w - hi.float()).to(base)
+    out = torch.stack([hi.view(n, k // 32, 32), lo.view(n, k // 32, 32)], dim=2)
+    return out.reshape(n, 2 * k).view(torch.int16).contiguous()
+
+
+def unsplit_operand(t, base):
+    """Inverse of split_operand (hi + lo is exact in fp32): int16 [N, 2K] -> fp32 [N, K]."""
+    n, k2 = t.shape
+    v = t.view(base).view(n, k2 // 64, 2, 32).float()
+    return (v[:, :, 0] + v[:, :, 1]).reshape(n, k2 // 2)
+
+
+def to_engine_layout(weights, dtype):
+    """{name: fp32 tensor in libwseg layout} -> tensors as the engine of mode `dtype` attaches them."""
+    base = SPLIT_BASE.get(dtype)
+    td = DTYPES[dtype][1]
+    if base is None:
+        return {k: v.to(td).contiguous() for k, v in weights.items()}
+    return {k: (split_operand(v, base) if is_gemm_weight(k) else v.float().contiguous()) for k, v in weights.items()}
 
 # generation_config.suppress_tokens of the multilingual Whisper checkpoints WhisperSeg fine-tunes
 # (saved with the trained models: reference docs/WhisperSeg_Training_Pipeline.ipynb, generation params).
@@ -52,8 +91,9 @@ def geometry_from_config(cfg):
                 dec_positions=cfg.get("max_target_positions", 448))
 
 
-def prepare_weights(sd, geo, torch_dtype, device):
+def prepare_weights(sd, geo, torch_dtype, device, split_base=None):
     """HF-named state dict -> {libwseg tensor name: contiguous device tensor} (layouts of include/wseg.h).
+    split_base (torch.bfloat16 / torch.float16): split-precision mode — GEMM weight matrices become operand rows.
 
     qkv.w  [3d, d]   rows = q | k | v projections;   qkv.b has zeros for k (k_proj has no bias)
     ckv.w  [2d, d]   rows = cross-attention k | v
@@ -69,7 +109,10 @@ def prepare_weights(sd, geo, torch_dtype, device):
 
     class _Out(dict):     # every prepared tensor is cast to the model dtype as soon as it exists (no full fp32 copy)
         def __setitem__(self, key, value):
-            dict.__setitem__(self, key, value.to(torch_dtype).contiguous())
+            if split_base is not None and is_gemm_weight(key):
+                dict.__setitem__(self, key, split_operand(value, split_base))
+            else:
+                dict.__setitem__(self, key, value.to(torch_dtype).contiguous())
 
     out = _Out()
     kp1 = _round_up(3 * n_mels, 64)
@@ -125,9 +168,11 @@ def prepare_weights(sd, geo, torch_dtype, device):
     return dict(out)
 
 
-def random_weights(geo, torch_dtype, device, seed=0):
+def random_weights(geo, torch_dtype, device, seed=0, split_base=None):
     """Seeded random weights generated directly on the device in libwseg layout (benchmarks:
-    no checkpoint exists offline).  Same distributions as oracle.whisper_ref.random_state_dict."""
+    no checkpoint exists offline).  Same distributions as oracle.whisper_ref.random_state_dict.
+    split_base: split-precision mode (torch_dtype float32) — the fp32 draws of the GEMM matrices become operand rows, so an
+    "f32" engine with the same seed holds exactly the values these hi + lo pairs approximate."""
     gen = torch.Generator(device=device).manual_seed(seed)
     d, f, nm = geo["d_model"], geo["ffn"], geo["n_mels"]
     vp, kp1 = _round_up(geo["vocab"], 128), _round_up(3 * nm, 64)
@@ -157,6 +202,10 @@ def random_weights(geo, torch_dtype, device, seed=0):
                 lin(p + "cq", d, d); lin(p + "ckv", 2 * d, d); lin(p + "co", d, d); ln(p + "ln3")
                 out[p + "ckv.b"][:d] = 0
             lin(p + "fc1", f, d); lin(p + "fc2", d, f)
+    if split_base is not None:
+        for k in list(out):
+            if is_gemm_weight(k):
+                out[k] = split_operand(out[k], split_base)
     return out
 
 
@@ -174,8 +223,10 @@ class Engine:
         _lib.check(self.lib.wseg_model_create(C.byref(cfg), C.byref(handle)))
         self.handle = handle
         self.weights = weights          # keep the device tensors alive
+        self.split_base = SPLIT_BASE.get(dtype)
         for name, t in weights.items():
-            if t.device != self.device or t.dtype != self.torch_dtype or not t.is_contiguous():
+            want = torch.int16 if (self.split_base is not None and is_gemm_weight(name)) else self.torch_dtype
+            if t.device != self.device or t.dtype != want or not t.is_contiguous():
                 raise ValueError(f"weight {name}: wrong device/dtype/layout")
             _lib.check(self.lib.wseg_model_set_tensor(handle, name.encode(), t.data_ptr(), t.numel() * t.element_size()))
         _lib.check(self.lib.wseg_model_ready(handle))
@@ -185,7 +236,7 @@ class Engine:
     @classmethod
     def from_state_dict(cls, sd, hf_config, device="cuda:0", dtype="bf16"):
         geo = geometry_from_config(hf_config)
-        return cls(geo, prepare_weights(sd, geo, DTYPES[dtype][1], device), device, dtype)
+        return cls(geo, prepare_weights(sd, geo, DTYPES[dtype][1], device, SPLIT_BASE.get(dtype)), device, dtype)
 
     @classmethod
     def from_pretrained(cls, model_dir, device="cuda:0", dtype="bf16"):
@@ -203,7 +254,7 @@ class Engine:
     @classmethod
     def random(cls, hf_config, device="cuda:0", dtype="bf16", seed=0):
         geo = geometry_from_config(hf_config)
-        return cls(geo, random_weights(geo, DTYPES[dtype][1], device, seed), device, dtype)
+        return cls(geo, random_weights(geo, DTYPES[dtype][1], device, seed, SPLIT_BASE.get(dtype)), device, dtype)
 
     def __del__(self):
         try:
@@ -244,7 +295,7 @@ class Engine:
         return s, lanes
 
     def encode(self, feats):
-        """feats float32 device tensor [W, 80, 1000] -> [W, 500, d] in the model dtype."""
+        """feats float32 device tensor [W, 80, 1000] -> [W, 500, d] in the model dtype (float32 in the split-precision modes)."""
         feats = feats.to(device=self.device, dtype=torch.float32).contiguous()
         W = feats.shape[0]
         ws = self._workspace(W, 1, 8)
