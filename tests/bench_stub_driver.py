@@ -29,7 +29,14 @@ class StubEngine:
         toks[:, 3] = (feats[:, 0] * 1000).to(torch.int32) % 1000 + 50364
         toks[:, 4] = 15 + int(self.weights["w"][0].item()) % 10           # 15 + 0 on every rank once the broadcast happened
         toks[:, 5] = toks[:, 3] + 7
-        return toks, torch.full((n,), 6, dtype=torch.int32)
+        lens = torch.full((n,), 6, dtype=torch.int32)
+        if return_first_logits:      # [n * beams, vocab]: the beams of a window agree at the first step
+            logits = (feats[:, :1] % 7.0 + torch.arange(32)[None, :] * 0.25).repeat_interleave(num_beams, dim=0)
+            return toks, lens, logits
+        return toks, lens
+
+    def exact_reference(self):
+        return self
 
     def last_timing(self):
         return (0.0, 0.0, 0.0, 0.0)

@@ -51,3 +51,18 @@ def test_single_process_default_and_mismatch():
     env.update(RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     res = subprocess.run([sys.executable, DRIVER, "--gpus", "1"] + ARGS, env=env, capture_output=True, text=True, timeout=120)
     assert res.returncode == 2 and "WORLD_SIZE" in res.stderr
+
+
+@pytest.mark.timeout(300)
+def test_self_check_runs_on_rank_0_without_a_collective():
+    """the self-check runs on rank 0 only, so it must not enter a collective (its step used to call the
+    token all_gather while the other ranks were already in the final barrier: a mismatched collective that hangs under RCCL).
+    Two gloo ranks with the check enabled must finish and report it."""
+    args = [a for a in ARGS] + ["--check-on-cpu", "--check-windows", "3"]
+    res = subprocess.run([sys.executable, DRIVER, "--gpus", "2"] + args, env=clean_env(), capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = last_json(res.stdout)
+    assert out["world_size"] == 2
+    chk = out["check"]
+    assert chk is not None and chk["ok"] and chk["deterministic"] and chk["subset_windows"] == 3
+    assert chk["beams_equal_at_first_step"] and chk["first_token_equal_to_f32"] == "3/3"

@@ -10,7 +10,7 @@ infrastructure only (imports oracle/); nothing here ships.
 POLICY = comma-separated  class=fmt  pairs, classes:
     gemm   operands of every Linear / conv (activations and weights)          fmt: f32 | f16 | bf16 | bf16x3 | f16x3
     eattn  encoder attention tensors Q, K, V, P (softmax probabilities)        fmt: f32 | f16 | bf16 | bf16x2 | f16x2
-    ckv    cross-attention K / V storage                                       (x2 = hi + lo pair, i.e. ~16 / ~22 mantissa bits)
+    ckv    cross-attention K / V storage (ck / cv: one of them)                (x2 = hi + lo pair, i.e. ~16 / ~22 mantissa bits)
     skv    decoder self-attention K / V cache
     dq     decoder attention queries (self + cross) and attention outputs are GEMM operands -> class gemm; dq = the query
     all    shorthand: every class
@@ -57,10 +57,10 @@ def rnd(x, fmt):
 
 class Policy:
     def __init__(self, text):
-        self.fmt = dict(gemm="f32", eattn="f32", ckv="f32", skv="f32", dq="f32")
+        self.fmt = dict(gemm="f32", eattn="f32", ck="f32", cv="f32", skv="f32", dq="f32")
         for part in filter(None, text.split(",")):
             k, v = part.split("=")
-            for kk in (self.fmt if k == "all" else [k]):
+            for kk in (self.fmt if k == "all" else (["ck", "cv"] if k == "ckv" else [k])):
                 self.fmt[kk] = v if not (kk != "gemm" and v.endswith("x3")) else v[:-1] + "2"
         self.wcache = {}
 
@@ -137,8 +137,8 @@ class Decoder(W.Decoder):
         self.cross = []
         for i in range(cfg.decoder_layers):
             lp = f"{self.p}layers.{i}.encoder_attn."
-            k = rnd(W._heads(P.linear(enc_out, sd, lp + "k_proj", bias=False), cfg.heads), P.fmt["ckv"])
-            v = rnd(W._heads(P.linear(enc_out, sd, lp + "v_proj"), cfg.heads), P.fmt["ckv"])
+            k = rnd(W._heads(P.linear(enc_out, sd, lp + "k_proj", bias=False), cfg.heads), P.fmt["ck"])
+            v = rnd(W._heads(P.linear(enc_out, sd, lp + "v_proj"), cfg.heads), P.fmt["cv"])
             self.cross.append((k, v))
         self.self_kv = [None] * cfg.decoder_layers
         self.pos = 0

@@ -114,8 +114,15 @@ template <> struct El<float> {
 // X3<HT> is the element-type TAG of these modes (never instantiated); IO<T> maps a tag to its plain parameter type.
 // ------------------------------------------------------------------------------------------------------------------
 template <typename HT> struct X3 {};
-template <typename T> struct IO { typedef T P; typedef T H; static constexpr bool split = false; };
-template <typename HT> struct IO<X3<HT>> { typedef float P; typedef HT H; static constexpr bool split = true; };
+struct f16_t;
+// P: plain parameter / cache type; H: 16-bit MFMA operand type; A: storage type of the ENCODER self-attention's Q / K / V^T.
+// Split-precision modes run the encoder attention on the IEEE-half matrix cores (fp32 softmax statistics): rounding Q, K, V and
+// P to half leaves the 200-recording parity sweep untouched (tools/precision_study.py: "gemm=bf16x3,eattn=f16" 200 / 200, the
+// attention output averages hundreds of independently rounded terms) at a tenth of the fp32-MFMA kernel's time, whereas the
+// decoder's cross-attention K / V must keep >= 16 mantissa bits ("ckv=f16": 188 / 200) and stay fp32.  EpiParams::qkv_f32
+// (WSEG_X3_ENC_ATTN=f32) selects the fp32 attention kernel instead.
+template <typename T> struct IO { typedef T P; typedef T H; typedef T A; static constexpr bool split = false; };
+template <typename HT> struct IO<X3<HT>> { typedef float P; typedef HT H; typedef f16_t A; static constexpr bool split = true; };
 
 __host__ __device__ __forceinline__ int x3_col(int c) { return ((c >> 5) << 6) | (c & 31); }
 

@@ -134,9 +134,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // windows; fewer VALU instructions at 2 per CU measured SLOWER: the kernel lives on occupancy).  Under that cap the
 // register-prefetched K chunks were spilled to scratch directly behind their loads (PMC WRITE_SIZE showed 3.9x the
 // algorithmic output bytes); with K prefetched by LDS-DMA instead the kernel has no scratch: 767 -> 571 us per layer.
-template <typename HT>
+// TO: tag of the output, the o-proj GEMM's operand (HT, or X3<..>: hi | lo rows in the split-precision modes)
+template <typename HT, typename TO>
 __global__ __launch_bounds__(256, 4) void enc_attention_h16_kernel(const HT* __restrict__ Q, const HT* __restrict__ K,
-                                                                const HT* __restrict__ Vt, HT* __restrict__ out,
+                                                                const HT* __restrict__ Vt, void* __restrict__ out,
                                                                  int H, int T, int Tp, int d) {
   // [key][64 hd], 16-B slots XOR ((key >> 1) & 7): a 32-row MFMA fragment read (lane = row + 32*half) is serviced in the
   // lane groups {0-3,12-15,20-27}, ... and needs 16 distinct (row & 1, slot) pairs per group — XOR (key & 7), right for
@@ -263,17 +264,14 @@ __global__ __launch_bounds__(256, 4) void enc_attention_h16_kernel(const HT* __r
   const int q = q0 + qi;
   if (q < T) {
     const float inv = 1.0f / l_run;
-    HT* orow = out + ((size_t)b * T + q) * d + h * 64;
 #pragma unroll
     for (int ht = 0; ht < 2; ++ht) {
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int hd = ht * 32 + 8 * rg + 4 * g2;
         const f32x16& o = ht == 0 ? o0 : o1;
-        uint2 pk;
-        pk.x = H16<HT>::pack(o[4 * rg + 0] * inv, o[4 * rg + 1] * inv);
-        pk.y = H16<HT>::pack(o[4 * rg + 2] * inv, o[4 * rg + 3] * inv);
-        *(uint2*)(orow + hd) = pk;
+        const float v4[4] = {o[4 * rg + 0] * inv, o[4 * rg + 1] * inv, o[4 * rg + 2] * inv, o[4 * rg + 3] * inv};
+        op_st4<TO>(out, (size_t)b * T + q, d, h * 64 + hd, v4);
       }
     }
   }
@@ -429,6 +427,11 @@ __global__ __launch_bounds__(256) void enc_attention_f32_mfma_kernel(const float
 // Launchers
 // ------------------------------------------------------------------------------------------------
 static bool is_x3(int dtype) { return dtype == WSEG_BF16X3 || dtype == WSEG_F16X3; }
+// attribution knob (tools/parity_sweep.py, profiles/): fp32-MFMA encoder attention in the split-precision modes
+bool x3_enc_attention_f32() {
+  static const bool v = getenv("WSEG_X3_ENC_ATTN") && !strcmp(getenv("WSEG_X3_ENC_ATTN"), "f32");
+  return v;
+}
 
 // Split-precision operand rows [M][2d words] <-> fp32 [M][d] (the C-ABI hands encoder states over as fp32 in these modes).
 template <typename HT>
@@ -534,11 +537,16 @@ static void launch_enc_attention_f32(const void* q, const void* k, const void* v
 
 int launch_enc_attention(int dtype, const void* q, const void* k, const void* vt, void* out,
                          int B, int H, int T, int Tp, int d, hipStream_t s) {
-  if (dtype == WSEG_BF16 || dtype == WSEG_F16) {
+  const bool x3 = is_x3(dtype);
+  if (dtype == WSEG_BF16 || dtype == WSEG_F16 || (x3 && !x3_enc_attention_f32())) {
     if (Tp % 128) { set_error("enc_attention: Tp %d %% 128", Tp); return WSEG_ERR_INVALID; }
     dim3 grid(cdiv(T, 128), B * H);
-    if (dtype == WSEG_BF16) hipLaunchKernelGGL(enc_attention_h16_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, T, Tp, d);
-    else hipLaunchKernelGGL(enc_attention_h16_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)q, (const f16_t*)k, (const f16_t*)vt, (f16_t*)out, H, T, Tp, d);
+#define WSEG_EA(HT_, TO_) hipLaunchKernelGGL((enc_attention_h16_kernel<HT_, TO_>), grid, dim3(256), 0, s, (const HT_*)q, (const HT_*)k, (const HT_*)vt, out, H, T, Tp, d)
+    if (dtype == WSEG_BF16) WSEG_EA(bf16_t, bf16_t);
+    else if (dtype == WSEG_F16) WSEG_EA(f16_t, f16_t);
+    else if (dtype == WSEG_BF16X3) WSEG_EA(f16_t, X3<bf16_t>);       // IEEE-half Q / K / V^T (IO<X3<..>>::A) in both split modes
+    else WSEG_EA(f16_t, X3<f16_t>);
+#undef WSEG_EA
   } else if (dtype == WSEG_BF16X3) launch_enc_attention_f32<X3<bf16_t>>(q, k, vt, out, B, H, T, Tp, d, s);
   else if (dtype == WSEG_F16X3) launch_enc_attention_f32<X3<f16_t>>(q, k, vt, out, B, H, T, Tp, d, s);
   else launch_enc_attention_f32<float>(q, k, vt, out, B, H, T, Tp, d, s);

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
+#include <type_traits>
 
 #include <vector>
 #include "wseg_kernels.h"
@@ -80,14 +81,19 @@ __device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, fl
     if (sec == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] *= ep.scale;
-      Vec4<PT>::st((PT*)ep.q + (bh * ep.t_pad + t) * 64 + e, v);
-    } else if (sec == 1) {
-      Vec4<PT>::st((PT*)ep.k + (bh * ep.t_pad + t) * 64 + e, v);
-    } else {
-      PT* vt = (PT*)ep.v + (bh * 64 + e) * ep.t_pad + t;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) El<PT>::st(vt + (size_t)i * ep.t_pad, v[i]);
     }
+    auto put = [&](auto* base) {
+      typedef std::remove_pointer_t<decltype(base)> QT;
+      if (sec == 0) Vec4<QT>::st((QT*)ep.q + (bh * ep.t_pad + t) * 64 + e, v);
+      else if (sec == 1) Vec4<QT>::st((QT*)ep.k + (bh * ep.t_pad + t) * 64 + e, v);
+      else {
+        QT* vt = (QT*)ep.v + (bh * 64 + e) * ep.t_pad + t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) El<QT>::st(vt + (size_t)i * ep.t_pad, v[i]);
+      }
+    };
+    if (IO<T>::split && ep.qkv_f32) put((float*)nullptr);
+    else put((typename IO<T>::A*)nullptr);
   } else if constexpr (EPI == EPI_KV_CROSS) {
     const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
     const int b = m / ep.t_len, t = m - b * ep.t_len;
@@ -168,14 +174,19 @@ __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, f
     if (sec == 0) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] *= ep.scale;
-      st8_h<PT>((PT*)ep.q + (bh * ep.t_pad + t) * 64 + e, v);
-    } else if (sec == 1) {
-      st8_h<PT>((PT*)ep.k + (bh * ep.t_pad + t) * 64 + e, v);
-    } else {
-      PT* vt = (PT*)ep.v + (bh * 64 + e) * ep.t_pad + t;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) El<PT>::st(vt + (size_t)i * ep.t_pad, v[i]);
     }
+    auto put = [&](auto* base) {
+      typedef std::remove_pointer_t<decltype(base)> QT;
+      if (sec == 0) st8_h<QT>((QT*)ep.q + (bh * ep.t_pad + t) * 64 + e, v);
+      else if (sec == 1) st8_h<QT>((QT*)ep.k + (bh * ep.t_pad + t) * 64 + e, v);
+      else {
+        QT* vt = (QT*)ep.v + (bh * 64 + e) * ep.t_pad + t;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) El<QT>::st(vt + (size_t)i * ep.t_pad, v[i]);
+      }
+    };
+    if (IO<T>::split && ep.qkv_f32) put((float*)nullptr);
+    else put((typename IO<T>::A*)nullptr);
   } else if constexpr (EPI == EPI_KV_CROSS) {
     const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
     const int b = m / ep.t_len, t = m - b * ep.t_len;

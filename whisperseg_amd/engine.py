@@ -256,6 +256,22 @@ class Engine:
         geo = geometry_from_config(hf_config)
         return cls(geo, random_weights(geo, DTYPES[dtype][1], device, seed, SPLIT_BASE.get(dtype)), device, dtype)
 
+    def weights_f32(self):
+        """{name: fp32 tensor in libwseg layout} holding exactly the values this engine computes with (operand rows of the
+        split-precision modes are read back as hi + lo)."""
+        out = {}
+        for k, v in self.weights.items():
+            out[k] = unsplit_operand(v, self.split_base) if v.dtype == torch.int16 else v.float()
+        return out
+
+    def sibling(self, dtype):
+        """An engine of another mode over the SAME weight values (rounded to that mode's storage type)."""
+        return Engine(self.geo, to_engine_layout(self.weights_f32(), dtype), self.device, dtype)
+
+    def exact_reference(self):
+        """The exact-parity f32 engine over this engine's weight values (bench.py's self-check, tools/logit_error.py)."""
+        return self.sibling("f32")
+
     def __del__(self):
         try:
             if getattr(self, "handle", None):

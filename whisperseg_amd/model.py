@@ -24,10 +24,14 @@ from .utils import RATIO_DECODING_TIME_STEP_TO_SPEC_TIME_STEP
 from .windows import shard_bounds, window_table
 
 PROMPT_TOKENS = ["<|startoftranscript|>", "<|en|>", "<|notimestamps|>"]   # reference model.py:656
-# Engine dtype when neither the constructor nor $WHISPERSEG_AMD_DTYPE names one: IEEE half — the 16-bit mode with the
-# better parity margin against the fp32 reference (profiles/README.md, parity table) and what the reference's own GPU fast
-# path computes in (CTranslate2 float16, reference model.py:691).  "bf16" is 3-5 % faster, "f32" is the exact-parity mode.
-DEFAULT_DTYPE = "f16"
+# Engine mode when neither the constructor nor $WHISPERSEG_AMD_DTYPE names one: "f16x3", the split-precision mode — the
+# reference computes in fp32 (model.py:655-666), and this is the fastest mode that meets the north-star tolerance (clusters
+# exact, boundaries within +-1 mel frame) on every recording of the 200-recording parity sweep (profiles/README.md): GEMM operands
+# as hi + lo IEEE-half pairs multiplied with three MFMAs per product, fp32 everywhere else; first-step logits within 4e-4 of the
+# exact mode at 32 + 32 layers.  "bf16x3" is the same with bfloat16 halves (no fp16 range limit, 16 instead of 22 operand bits);
+# "f16" / "bf16" are the plain 16-bit modes (2.2x faster, 95 % / 86 % of the sweep inside the tolerance); "f32" is the
+# exact-parity mode.
+DEFAULT_DTYPE = "f16x3"
 POOL_WINDOWS = 8192      # windows per engine call / per pooled group of files (2.6 GB of log-mel features)
 
 
