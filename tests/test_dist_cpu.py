@@ -27,19 +27,29 @@ class FakeSegmenter:
     def __init__(self):
         from whisperseg_amd.model import SegmenterBase
         self.base = SegmenterBase()
-        self.base.total_spec_columns = 1000
+        self.base.total_spec_columns = self.total_spec_columns = 1000
         self.base.cluster_codebook = {"a": 0, "b": 1, "c": 2}
-        self.default_segmentation_config = {}
+        self.default_segmentation_config = self.base.default_segmentation_config = {"spec_time_step": 0.01, "min_frequency": 0}
         self.device_list = [torch.device("cpu")]
         self.parse_generation = self.base.parse_generation
+        self.resolve_segmentation_params = self.base.resolve_segmentation_params
+        self.pcm_samples_seen = 0
 
-    def sliced_features_from_device_pcm(self, pcm, sr, min_frequency, spec_time_step, num_trials, rank=0, world=1):
+    def sliced_features_from_device_pcm(self, pcm, sr, min_frequency, spec_time_step, num_trials, rank=0, world=1,
+                                        window_range=None):
         from whisperseg_amd.windows import shard_bounds, window_table
         table = window_table(int(pcm.numel()), sr, spec_time_step, num_trials, 1000)
-        bounds = shard_bounds(len(table), world)
-        lo, hi = bounds[rank] if rank < len(bounds) else (len(table), len(table))
+        if window_range is not None:
+            lo, hi = max(0, window_range[0]), min(len(table), window_range[1])
+            hi = max(lo, hi)
+        else:
+            bounds = shard_bounds(len(table), world)
+            lo, hi = bounds[rank] if rank < len(bounds) else (len(table), len(table))
+        self.pcm_samples_seen += int(pcm.numel())
         clip_len = int(1000 * spec_time_step * sr)
-        shard = [(w.trial_id, w.offset_time, fake_features(pcm, w.start, clip_len), w.clip_seconds) for w in table[lo:hi]]
+        # the stand-in "features" also depend on the front-end parameters, as the real filterbank does
+        shard = [(w.trial_id, w.offset_time, fake_features(pcm, w.start, clip_len) + 0.37 * (min_frequency > 0) + sr * 1e-6,
+                  w.clip_seconds) for w in table[lo:hi]]
         rows = [(w.trial_id, w.offset_time, None, w.clip_seconds) for w in table]
         return {"table": rows, "shard": shard, "n_total": len(table), "lo": lo, "hi": hi}
 
@@ -115,3 +125,108 @@ def test_gather_rows_single_process():
     a, b = wd.gather_rows(t, ln, 3)
     assert torch.equal(a, t) and torch.equal(b, ln)
     assert wd.my_shard(10, 3, 4) == (9, 10) and wd.my_shard(3, 5, 8) == (3, 3)
+
+
+# ---- a clip BATCH partitioned over the ranks (BASELINE configs[4]: mixed 16 / 32 / 48 kHz, per-species parameters) ----------------
+BATCH = [  # sr, seconds, spec_time_step, min_frequency, num_trials, min_segment_length, eps
+    (16000, 23.4, 0.01, 0, 1, None, None),
+    (32000, 7.9, 0.0025, 0, 3, 0.01, 0.02),
+    (48000, 5.2, 0.0025, 1000, 2, 0.0, None),       # an explicit 0 must stay 0 (not "or default")
+    (16000, 0.4, None, None, 1, None, None),        # checkpoint defaults
+]
+
+
+def make_batch():
+    rng = np.random.default_rng(11)
+    return [(0.1 * rng.standard_normal(int(sr * sec))).astype(np.float32) for sr, sec, *_ in BATCH]
+
+
+def batch_kwargs():
+    return dict(min_frequency=[b[3] for b in BATCH], spec_time_step=[b[2] for b in BATCH], num_trials=[b[4] for b in BATCH],
+                min_segment_length=[b[5] for b in BATCH], eps=[b[6] for b in BATCH], batch_size=2, max_length=L)
+
+
+def per_file_reference():
+    """What per-file segment() gives: segment_distributed of each recording alone, single process."""
+    from whisperseg_amd import dist as wd
+    seg = FakeSegmenter()
+    out = []
+    for audio, (sr, _, sts, mf, nt, msl, eps) in zip(make_batch(), BATCH):
+        out.append(wd.segment_distributed(seg, audio, sr, spec_time_step=sts, min_frequency=mf, num_trials=nt, min_segment_length=msl,
+                                          eps=eps, batch_size=2, max_length=L))
+    return out
+
+
+def batch_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from whisperseg_amd import dist as wd
+    wd.init_from_env(backend="gloo")
+    seg = FakeSegmenter()
+    audios = make_batch() if rank == 0 else None
+    srs = [b[0] for b in BATCH] if rank == 0 else None
+    res = wd.segment_batch_distributed(seg, audios, srs, **(batch_kwargs() if rank == 0 else dict(batch_size=2, max_length=L)))
+    q.put((rank, res, seg.pcm_samples_seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_clip_batch_equals_per_file_segment_gloo(world):
+    want = per_file_reference()
+    assert sum(len(p["onset"]) for p in want) > 5 and len(want) == len(BATCH)
+    from whisperseg_amd import dist as wd
+    single = wd.segment_batch_distributed(FakeSegmenter(), make_batch(), [b[0] for b in BATCH], **batch_kwargs())
+    assert single == want
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=batch_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total = sum(len(a) for a in make_batch())
+    for rank, res, seen in results:
+        assert res == want, rank                       # every rank holds every recording's rows == per-file segment()
+        assert seen < total                            # ... having received only the recordings its windows read
+
+
+def test_per_recording_parameters_in_segment_batch_cpu():
+    """SegmenterBase.segment_batch with per-recording lists == segment() per file (device stages stubbed)."""
+    from whisperseg_amd.model import SegmenterBase
+    from whisperseg_amd.windows import window_table
+
+    class Stub(SegmenterBase):
+        def __init__(self):
+            super().__init__()
+            self.total_spec_columns = 1000
+            self.cluster_codebook = {"a": 0, "b": 1, "c": 2}
+            self.default_segmentation_config = {"spec_time_step": 0.01, "min_frequency": 0}
+            self.device_list = ["stub"]
+            self.calls = 0
+
+        def get_sliced_audios_features(self, audio, sr, min_frequency, spec_time_step, num_trials):
+            clip_len = int(1000 * spec_time_step * sr)
+            pcm = torch.from_numpy(np.asarray(audio))
+            return [(w.trial_id, w.offset_time, fake_features(pcm, w.start, clip_len) + 0.37 * (min_frequency > 0) + sr * 1e-6, w.clip_seconds)
+                    for w in window_table(len(audio), sr, spec_time_step, num_trials, 1000)]
+
+        def generate_segment_text(self, sliced, *a, **k):
+            self.calls += 1
+            fs = FakeSegmenter()
+            return fs.tokens_to_texts(*[t.numpy() for t in fs.decode_shard_tokens(sliced)])
+
+    seg = Stub()
+    kw = batch_kwargs()
+    kw.pop("batch_size"); kw.pop("max_length")
+    pooled = seg.segment_batch(make_batch(), [b[0] for b in BATCH], **kw)
+    assert seg.calls == 1                                                # ONE pooled decode for the mixed-parameter batch
+    for pred, audio, (sr, _, sts, mf, nt, msl, eps) in zip(pooled, make_batch(), BATCH):
+        assert pred == seg.segment(audio, sr, min_frequency=mf, spec_time_step=sts, num_trials=nt, min_segment_length=msl, eps=eps)
+    assert pooled == per_file_reference()
+    with pytest.raises(ValueError):
+        seg.segment_batch(make_batch(), [b[0] for b in BATCH], spec_time_step=[0.01, 0.01])      # list shorter than the batch

@@ -51,6 +51,71 @@ def test_mixed_rate_files_pooled_equal_per_file(gpu_lib):
     assert sum(len(p["onset"]) for p in pooled) >= 8
 
 
+def species_batch():
+    """A multi-species batch in the reference's sense (config/segment_config.json:1-49): per-recording sampling rate, spectrogram
+    time step, minimum frequency, trial count and post-filter lengths."""
+    from scipy.signal import resample_poly
+    base = [GI.tiny_recording(100, 3), GI.tiny_recording(103, 2), GI.tiny_recording(105, 2), GI.tiny_recording(107, 1)]
+    audios = [base[0], resample_poly(base[1], 2, 1).astype(np.float32), resample_poly(base[2], 3, 1).astype(np.float32), base[3]]
+    srs = [16000, 32000, 48000, 16000]
+    kw = dict(spec_time_step=[TM.STS, 0.005, 0.0025, None], min_frequency=[0, 0, 2000, None], num_trials=[1, 3, 2, 1],
+              min_segment_length=[None, 0.01, 0.0, None], eps=[None, 0.02, None, None])
+    return audios, srs, kw
+
+
+def per_file(seg, audios, srs, kw):
+    return [seg.segment(a, sr, **{k: v[i] for k, v in kw.items()}) for i, (a, sr) in enumerate(zip(audios, srs))]
+
+
+def test_multi_species_batch_is_one_pooled_decode(gpu_lib):
+    """configs[4] "multi-species batch": recordings with DIFFERENT sr / spec_time_step / min_frequency / num_trials / filter
+    lengths go through one segment_batch call = one pooled decode, each with its own front-end configuration; results equal
+    per-file segment() with the same parameters (exact in f32 mode, and in the default split-precision mode the rows agree
+    too).  Reference: evaluate.py:15-24 passes these per file; config/segment_config.json:1-49 ships them per species."""
+    from whisperseg_amd.model import WhisperSegmenter
+    audios, srs, kw = species_batch()
+    for dtype in ("f32", None):          # None: the default mode
+        seg = WhisperSegmenter(MODEL_DIR, device="cuda", device_ids=[0], dtype=dtype)
+        calls = []
+        inner = seg.generate_segment_text
+        seg.generate_segment_text = lambda sliced, *a, **k: (calls.append(len(sliced)), inner(sliced, *a, **k))[1]
+        pooled = seg.segment_batch(audios, srs, **kw)
+        assert len(calls) == 1 and calls[0] >= 15        # ONE decode over the pooled windows of all four recordings
+        seg.generate_segment_text = inner
+        assert pooled == per_file(seg, audios, srs, kw), dtype
+    assert sum(len(p["onset"]) for p in pooled) >= 8
+
+
+def test_distributed_clip_batch_on_the_gpu(gpu_lib):
+    """dist.segment_batch_distributed with the RCCL collectives live (WSEG_FORCE_DIST=1: a one-rank nccl group in a child
+    process): metadata broadcast, PCM hand-over, token all_gather, per-recording parse == per-file segment()."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, json
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import torch
+from whisperseg_amd import dist as wd
+from whisperseg_amd.model import WhisperSegmenter
+import test_ingest_eval_gpu as T
+rank, world, _ = wd.init_from_env()
+assert torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl"
+seg = WhisperSegmenter(T.MODEL_DIR, device="cuda", device_ids=[0], dtype="f32")
+audios, srs, kw = T.species_batch()
+got = wd.segment_batch_distributed(seg, audios, srs, **kw)
+assert got == T.per_file(seg, audios, srs, kw)
+one = wd.segment_distributed(seg, audios[1], srs[1], **{k: v[1] for k, v in kw.items()})
+assert one == got[1]
+print("DIST-OK", sum(len(p["onset"]) for p in got))
+torch.distributed.destroy_process_group()
+"""
+    from conftest import ROOT
+    env = dict(os.environ, WSEG_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29700 + os.getpid() % 200), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-c", code, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "DIST-OK" in res.stdout, res.stderr[-3000:]
+
+
 def test_resample_then_segment_batch(gpu_lib):
     """"mixed sr 16/32/48 kHz resampled": 32 / 48 kHz sources -> GPU polyphase resampler -> 16 kHz model input (device tensors
     go straight into segment_batch, no host round trip) -> the segments of the original 16 kHz recordings."""

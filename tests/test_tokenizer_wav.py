@@ -41,3 +41,25 @@ def test_wav_formats(golden_dir):
     b24 = bytes([0, 0, 0x40, 0, 0, 0xC0])
     y, _ = load_wav(io.BytesIO(_wav(1, 24, 1, 48000, b24)))
     assert y.tolist() == [0.5, -0.5]
+
+
+def test_tokenizer_equals_huggingface_on_both_layouts(golden_dir):
+    """a-8 pinned on HF: `batch_decode(ids, skip_special_tokens=False)` of transformers' WhisperTokenizer (recorded by
+    tools/make_tok_fixture.py: synthetic byte-level BPE with merged multi-digit tokens, <|0|>..<|1000|> and species tokens added the
+    way reference model.py:111-113 adds them, saved the way model.py:66 saves them) against WhisperSegTokenizer reading the saved
+    directory — the tokenizer.json layout transformers 5.15 writes and the vocab.json + added_tokens.json layout of 4.38.2."""
+    import json
+    root = os.path.join(golden_dir, "tok_fixture")
+    with open(os.path.join(root, "decode_cases.json"), encoding="utf-8") as f:
+        cases = json.load(f)
+    assert len(cases["rows"]) >= 200
+    for layout in ("hf", "slow"):
+        tok = WhisperSegTokenizer.from_pretrained(os.path.join(root, layout), language="english")
+        assert tok.convert_tokens_to_ids(["<|startoftranscript|>", "<|en|>", "<|notimestamps|>"]) == cases["prompt"], layout
+        assert tok.eos_token_id == cases["eos_token_id"] == tok.pad_token_id
+        assert tok.batch_decode(cases["rows"], skip_special_tokens=False) == cases["decoded"], layout
+        assert tok.batch_decode(cases["rows"], skip_special_tokens=True) == cases["decoded_skip_special"], layout
+    # the segment grammar survives: multi-digit cluster tokens sit between two time tokens with nothing inserted
+    from whisperseg_amd import postprocess
+    segs = postprocess.extract_segments(cases["decoded"][0], 0.01, {str(i): i for i in range(100000)})
+    assert len(segs) >= 1 and all(len(r) == 3 for r in segs)

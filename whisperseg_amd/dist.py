@@ -105,40 +105,151 @@ def _all_gather_lists(out, part, world):
     out.copy_(torch.cat(chunks, 0))
 
 
+def _decode_kwargs(kwargs):
+    return dict(batch_size=kwargs.get("batch_size", 4), max_length=kwargs.get("max_length", 448),
+                num_beams=kwargs.get("num_beams", 4), length_penalty=kwargs.get("length_penalty", 1.0),
+                top_k=kwargs.get("top_k", 1), top_p=kwargs.get("top_p", 1.0))
+
+
+def _resolve(segmenter, min_frequency, spec_time_step, min_segment_length, eps, frame):
+    """segment()'s None-defaults (only None is a default: an explicit 0 stays 0)."""
+    if hasattr(segmenter, "resolve_segmentation_params"):
+        return segmenter.resolve_segmentation_params(min_frequency, spec_time_step, min_segment_length, eps, frame)
+    from .utils import RATIO_DECODING_TIME_STEP_TO_SPEC_TIME_STEP as RATIO
+    d = segmenter.default_segmentation_config
+    min_frequency = d.get("min_frequency", 0) if min_frequency is None else min_frequency
+    spec_time_step = d.get("spec_time_step", 0.0025) if spec_time_step is None else spec_time_step
+    min_segment_length = spec_time_step * RATIO if min_segment_length is None else min_segment_length
+    eps = spec_time_step * RATIO * 4 if eps is None else eps
+    frame = spec_time_step if frame is None else frame
+    return min_frequency, spec_time_step, min_segment_length, eps, frame
+
+
 def segment_distributed(segmenter, audio, sr, decode_shard=None, **kwargs):
     """segment() of one recording with its windows sharded over the ranks of the default group.
 
     Every rank must call this; rank 0 supplies `audio` (other ranks may pass None).  Returns the
     prediction dict on every rank.  `decode_shard(sliced_shard, **gen) -> (tokens, lengths)` defaults to
-    the segmenter's engine (tests inject a CPU stand-in to exercise the collectives under gloo)."""
+    the segmenter's engine (tests inject a CPU stand-in to exercise the collectives under gloo).  Keyword arguments are
+    segment()'s (model.py:397-470), with segment()'s None-defaults."""
     from . import postprocess
     from .audio_utils import get_n_fft_given_sr
-    from .utils import RATIO_DECODING_TIME_STEP_TO_SPEC_TIME_STEP as RATIO
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
-    d = segmenter.default_segmentation_config
-    min_frequency = kwargs.get("min_frequency", None)
-    spec_time_step = kwargs.get("spec_time_step", None)
-    if min_frequency is None:
-        min_frequency = d.get("min_frequency", 0)
-    if spec_time_step is None:
-        spec_time_step = d.get("spec_time_step", 0.0025)
+    min_frequency, spec_time_step, min_segment_length, eps, frame = _resolve(
+        segmenter, kwargs.get("min_frequency"), kwargs.get("spec_time_step"), kwargs.get("min_segment_length"), kwargs.get("eps"),
+        kwargs.get("time_per_frame_for_voting"))
     num_trials = kwargs.get("num_trials", 1)
     device = segmenter.device_list[0]
     pcm = broadcast_pcm(audio, device)
     sliced = segmenter.sliced_features_from_device_pcm(pcm, sr, min_frequency, spec_time_step, num_trials, rank, world)
     n_total = sliced["n_total"]
-    gen = dict(batch_size=kwargs.get("batch_size", 4), max_length=kwargs.get("max_length", 448),
-               num_beams=kwargs.get("num_beams", 4), length_penalty=kwargs.get("length_penalty", 1.0))
     fn = decode_shard or segmenter.decode_shard_tokens
-    tokens, lengths = fn(sliced["shard"], **gen)
+    tokens, lengths = fn(sliced["shard"], **_decode_kwargs(kwargs))
     tokens, lengths = gather_rows(tokens, lengths, n_total)
     tokens, lengths = tokens.cpu().numpy(), lengths.cpu().numpy()
     texts = segmenter.tokens_to_texts(tokens, lengths)
-    min_segment_length = kwargs.get("min_segment_length") or spec_time_step * RATIO
-    eps = kwargs.get("eps") or spec_time_step * RATIO * 4
-    frame = kwargs.get("time_per_frame_for_voting") or spec_time_step
     pred = segmenter.parse_generation(texts, sliced["table"], min_segment_length, pcm.numel() / sr, spec_time_step,
                                       num_trials, eps, frame, kwargs.get("consolidation_method", "clustering"))
     pred = postprocess.correct_fft_blur(pred, get_n_fft_given_sr(sr), sr)
     return postprocess.drop_consecutive_duplicates(pred)
+
+
+def _broadcast_object(obj, src=0):
+    if _single():
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src)
+    return box[0]
+
+
+def _scatter_recordings(audios, meta, need, device, rank, world):
+    """Rank 0 holds the recordings; every rank returns {recording index: device PCM} for the recordings in need[rank].
+    One point-to-point message per destination rank (the recordings it needs, concatenated): a rank receives only the PCM
+    its share of the pooled window list reads, not the whole batch."""
+    mine = {}
+    if rank == 0:
+        for dst in range(1, world):
+            if need[dst]:
+                buf = np.concatenate([np.ascontiguousarray(audios[i], dtype=np.float32) for i in need[dst]])
+                if buf.size:
+                    dist.send(torch.from_numpy(buf).to(device), dst)
+        for i in need[0]:
+            mine[i] = torch.as_tensor(np.ascontiguousarray(audios[i], dtype=np.float32)).to(device)
+    elif need[rank]:
+        total = sum(meta[i]["n"] for i in need[rank])
+        buf = torch.empty(total, dtype=torch.float32, device=device)
+        if total:
+            dist.recv(buf, 0)
+        pos = 0
+        for i in need[rank]:
+            mine[i] = buf[pos:pos + meta[i]["n"]]
+            pos += meta[i]["n"]
+    return mine
+
+
+def segment_batch_distributed(segmenter, audios, srs=None, decode_shard=None, **kwargs):
+    """segment_batch() of a list of recordings — a folder, a multi-species batch (BASELINE configs[4]) — with the POOLED
+    window list of all recordings partitioned over the ranks of the default group: the reference's fan-out shards whatever
+    window list it is given into contiguous ceil(N / n_devices) chunks (model.py:169-189); here N is the window count of the
+    whole batch and a chunk belongs to a process (one per GPU).
+
+    Every rank must call this; rank 0 supplies `audios` / `srs` and the per-recording parameters (lists or scalars, exactly
+    as SegmenterBase.segment_batch takes them); other ranks may pass None.  Exchange: (1) the recordings' metadata (lengths,
+    rates, resolved parameters: a small pickled list, broadcast), (2) PCM point-to-point from rank 0 to the ranks whose
+    windows read it, (3) all_gather of token ids + lengths.  Every rank then holds all tokens and parses every recording
+    (host work, milliseconds); returns the list of prediction dicts on every rank, equal to per-file segment()."""
+    from . import postprocess
+    from .audio_utils import get_n_fft_given_sr
+    from .model import _per_item
+    from .windows import window_table
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    device = segmenter.device_list[0]
+    meta = None
+    if rank == 0:
+        audios = list(audios)
+        if srs is None:
+            audios, sr_list = [a for a, _ in audios], [s for _, s in audios]
+        elif isinstance(srs, (int, float)):
+            sr_list = [srs] * len(audios)
+        else:
+            sr_list = list(srs)
+        names = ("min_frequency", "spec_time_step", "min_segment_length", "eps", "time_per_frame_for_voting")
+        per = [_per_item(kwargs.get(k)) for k in names] + [_per_item(kwargs.get("num_trials", 1)),
+                                                            _per_item(kwargs.get("consolidation_method", "clustering"))]
+        meta = []
+        for audio, sr, mf, sts, msl, e, tpf, nt, method in zip(audios, sr_list, *per):
+            mf, sts, msl, e, tpf = _resolve(segmenter, mf, sts, msl, e, tpf)
+            meta.append(dict(n=int(len(audio)), sr=sr, min_frequency=mf, spec_time_step=sts, min_segment_length=msl, eps=e,
+                             frame=tpf, num_trials=int(nt), method=method))
+    meta = _broadcast_object(meta)
+    cols = segmenter.total_spec_columns
+    counts = [len(window_table(m["n"], m["sr"], m["spec_time_step"], m["num_trials"], cols)) for m in meta]
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    n_total = int(offs[-1])
+    bounds = [my_shard(n_total, r, world) for r in range(world)]
+    need = [[i for i in range(len(meta)) if offs[i] < hi and offs[i + 1] > lo] for lo, hi in bounds]
+    pcm = _scatter_recordings(audios, meta, need, device, rank, world) if not _single() else \
+        {i: torch.as_tensor(np.ascontiguousarray(audios[i], dtype=np.float32)).to(device) for i in need[0]}
+    lo, hi = bounds[rank]
+    shard = []
+    for i in need[rank]:
+        m = meta[i]
+        part = segmenter.sliced_features_from_device_pcm(pcm[i], m["sr"], m["min_frequency"], m["spec_time_step"], m["num_trials"],
+                                                         window_range=(lo - int(offs[i]), hi - int(offs[i])))
+        shard += part["shard"]
+    fn = decode_shard or segmenter.decode_shard_tokens
+    tokens, lengths = fn(shard, **_decode_kwargs(kwargs))
+    tokens, lengths = gather_rows(tokens, lengths, n_total)
+    tokens, lengths = tokens.cpu().numpy(), lengths.cpu().numpy()
+    texts = segmenter.tokens_to_texts(tokens, lengths)
+    out = []
+    for i, m in enumerate(meta):
+        rows = [(w.trial_id, w.offset_time, None, w.clip_seconds)
+                for w in window_table(m["n"], m["sr"], m["spec_time_step"], m["num_trials"], cols)]
+        pred = segmenter.parse_generation(texts[int(offs[i]):int(offs[i + 1])], rows, m["min_segment_length"], m["n"] / m["sr"],
+                                          m["spec_time_step"], m["num_trials"], m["eps"], m["frame"], m["method"])
+        pred = postprocess.correct_fft_blur(pred, get_n_fft_given_sr(m["sr"]), m["sr"])
+        out.append(postprocess.drop_consecutive_duplicates(pred))
+    return out

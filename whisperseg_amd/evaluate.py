@@ -56,12 +56,31 @@ def _prf(tp, n_pred, n_label):
 
 
 def evaluate(audio_list, label_list, segmenter, batch_size, max_length, num_trials, num_beams=4, target_cluster=None):
-    """reference evaluate.py:9-51 -> {"segment_wise": [TP, P_pred, P_label, precision, recall, f1], "frame_wise": [...]}"""
+    """reference evaluate.py:9-51 -> {"segment_wise": [TP, P_pred, P_label, precision, recall, f1], "frame_wise": [...]}
+
+    The reference segments file by file with each label's own sr / min_frequency / spec_time_step (evaluate.py:15-24).  Here
+    all recordings go through ONE pooled decode with those per-recording parameters (SegmenterBase.segment_batch) — sharded
+    over the ranks of the default process group when one is active (dist.segment_batch_distributed: every rank must call
+    evaluate(); rank 0's audio_list is used) — which yields the per-file predictions of segment() (pooling only changes the
+    batch a window is decoded in).  A segmenter without segment_batch (any object with the reference's interface) is driven
+    file by file as upstream."""
+    from . import dist as wdist
+    kw = dict(min_frequency=[label.get("min_frequency", None) for label in label_list],
+              spec_time_step=[label.get("spec_time_step", None) for label in label_list],
+              max_length=max_length, batch_size=batch_size, num_trials=num_trials, num_beams=num_beams)
+    srs = [label["sr"] for label in label_list]
+    from .model import SegmenterBase
+    ours = getattr(type(segmenter), "segment", None) is SegmenterBase.segment      # not a subclass with its own segment()
+    if ours and not wdist._single() and hasattr(segmenter, "decode_shard_tokens"):
+        predictions = wdist.segment_batch_distributed(segmenter, audio_list, srs, **kw)
+    elif ours and hasattr(segmenter, "segment_batch"):
+        predictions = segmenter.segment_batch(audio_list, srs, **kw)
+    else:
+        predictions = [segmenter.segment(audio, sr=sr, min_frequency=mf, spec_time_step=sts, max_length=max_length,
+                                         batch_size=batch_size, num_trials=num_trials, num_beams=num_beams)
+                       for audio, sr, mf, sts in zip(audio_list, srs, kw["min_frequency"], kw["spec_time_step"])]
     seg_tot, frame_tot = [0, 0, 0], [0, 0, 0]
-    for audio, label in zip(audio_list, label_list):
-        prediction = segmenter.segment(audio, sr=label["sr"], min_frequency=label.get("min_frequency", None),
-                                       spec_time_step=label.get("spec_time_step", None), max_length=max_length,
-                                       batch_size=batch_size, num_trials=num_trials, num_beams=num_beams)
+    for prediction, label in zip(predictions, label_list):
         for tot, scores in ((seg_tot, segmenter.segment_score(prediction, label, target_cluster=target_cluster)[:3]),
                             (frame_tot, segmenter.frame_score(prediction, label, target_cluster=target_cluster)[:3])):
             for i in range(3):

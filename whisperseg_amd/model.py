@@ -8,6 +8,7 @@ work happens: windows are cut, transformed to log-mel and decoded on the GPU by 
 does bookkeeping.  There is no CPU execution path — constructing a segmenter without a gfx950 device or
 without libwseg.so raises.
 """
+import itertools
 import json
 import os
 import threading
@@ -33,6 +34,17 @@ PROMPT_TOKENS = ["<|startoftranscript|>", "<|en|>", "<|notimestamps|>"]   # refe
 # exact-parity mode.
 DEFAULT_DTYPE = "f16x3"
 POOL_WINDOWS = 8192      # windows per engine call / per pooled group of files (2.6 GB of log-mel features)
+
+
+def _per_item(value):
+    """Iterator over a per-recording parameter: a list / tuple / array has one entry per recording, anything else (incl.
+    None and strings) is the value for every recording."""
+    if isinstance(value, (list, tuple, np.ndarray)):
+        def entries():
+            yield from value
+            raise ValueError("a per-recording parameter list has fewer entries than there are recordings")
+        return entries()
+    return itertools.repeat(value)
 
 
 def _read_json(path, default=None):
@@ -87,16 +99,22 @@ class SegmenterBase:
         out = self.sliced_features_from_device_pcm(pcm, sr, min_frequency, spec_time_step, num_trials)
         return out["shard"]
 
-    def sliced_features_from_device_pcm(self, pcm, sr, min_frequency, spec_time_step, num_trials, rank=0, world=1):
+    def sliced_features_from_device_pcm(self, pcm, sr, min_frequency, spec_time_step, num_trials, rank=0, world=1,
+                                        window_range=None):
         """Window table of a recording already resident in HBM + log-mel features of THIS rank's contiguous
-        shard of it (world == 1: everything).  Returns {"table": all rows without features, "shard": this
+        shard of it (world == 1: everything; window_range = (lo, hi): exactly those rows of the table, for callers that
+        shard a pooled multi-recording window list).  Returns {"table": all rows without features, "shard": this
         rank's rows with device features, "n_total", "lo", "hi"}."""
         cols = self.total_spec_columns
         chunk_length = max(30, int(np.ceil(spec_time_step * cols)))
         extractor = get_feature_extractor(sr, spec_time_step, min_frequency, chunk_length, cols, pcm.device)
         table = window_table(int(pcm.numel()), sr, spec_time_step, num_trials, cols)
-        bounds = shard_bounds(len(table), world)
-        lo, hi = bounds[rank] if rank < len(bounds) else (len(table), len(table))
+        if window_range is not None:
+            lo, hi = max(0, int(window_range[0])), min(len(table), int(window_range[1]))
+            hi = max(lo, hi)
+        else:
+            bounds = shard_bounds(len(table), world)
+            lo, hi = bounds[rank] if rank < len(bounds) else (len(table), len(table))
         clip_len = int(cols * spec_time_step * sr)
         starts = torch.tensor([w.start for w in table[lo:hi]], dtype=torch.int64).to(pcm.device, non_blocking=True)
         feats = extractor.extract_windows(pcm, starts, clip_len)
@@ -186,10 +204,10 @@ class SegmenterBase:
             return self.model_list[0], self.tokenizer_list[0]
         return self.model, self.tokenizer
 
-    def decode_shard_tokens(self, shard, batch_size=4, max_length=448, num_beams=4, length_penalty=1.0):
+    def decode_shard_tokens(self, shard, batch_size=4, max_length=448, num_beams=4, length_penalty=1.0, top_k=1, top_p=1.0):
         engine, tokenizer = self._first_engine()
         L = int(min(max_length, engine.geo["dec_positions"]))
-        parts = self._decode_token_batches(engine, tokenizer, shard, batch_size, max_length, num_beams, 1, 1.0, length_penalty)
+        parts = self._decode_token_batches(engine, tokenizer, shard, batch_size, max_length, num_beams, top_k, top_p, length_penalty)
         if not parts:
             return (torch.zeros((0, L), dtype=torch.int32, device=engine.device),
                     torch.zeros((0,), dtype=torch.int32, device=engine.device))
@@ -219,11 +237,10 @@ class SegmenterBase:
     def consolidate_trials_by_voting(self, trials, time_per_frame_for_voting):
         return postprocess.consolidate_by_voting(trials, time_per_frame_for_voting, self.cluster_codebook)
 
-    # ---- the public entry point (reference model.py:397-470) -------------------------------------
-    @torch.no_grad()
-    def segment(self, audio, sr, min_frequency=None, spec_time_step=None, min_segment_length=None, eps=None,
-                time_per_frame_for_voting=None, consolidation_method="clustering", max_length=448, batch_size=4,
-                num_trials=1, num_beams=4, top_k=1, top_p=1.0, length_penalty=1.0, status_monitor=None):
+    def resolve_segmentation_params(self, min_frequency=None, spec_time_step=None, min_segment_length=None, eps=None,
+                                    time_per_frame_for_voting=None):
+        """The None-defaults of segment() (reference model.py:416-432): checkpoint defaults, then multiples of spec_time_step.
+        Only None is a default: an explicit 0 stays 0."""
         defaults = self.default_segmentation_config
         if min_frequency is None:
             min_frequency = defaults.get("min_frequency", 0)
@@ -235,6 +252,15 @@ class SegmenterBase:
             eps = spec_time_step * RATIO_DECODING_TIME_STEP_TO_SPEC_TIME_STEP * 4
         if time_per_frame_for_voting is None:
             time_per_frame_for_voting = spec_time_step
+        return min_frequency, spec_time_step, min_segment_length, eps, time_per_frame_for_voting
+
+    # ---- the public entry point (reference model.py:397-470) -------------------------------------
+    @torch.no_grad()
+    def segment(self, audio, sr, min_frequency=None, spec_time_step=None, min_segment_length=None, eps=None,
+                time_per_frame_for_voting=None, consolidation_method="clustering", max_length=448, batch_size=4,
+                num_trials=1, num_beams=4, top_k=1, top_p=1.0, length_penalty=1.0, status_monitor=None):
+        min_frequency, spec_time_step, min_segment_length, eps, time_per_frame_for_voting = self.resolve_segmentation_params(
+            min_frequency, spec_time_step, min_segment_length, eps, time_per_frame_for_voting)
         sliced = self.get_sliced_audios_features(audio, sr, min_frequency, spec_time_step, num_trials)
         texts = self.generate_segment_text(sliced, batch_size, max_length, num_beams, top_k, top_p, length_penalty,
                                            status_monitor)
@@ -251,50 +277,50 @@ class SegmenterBase:
         """segment() for a list of recordings with their windows POOLED into shared decode batches.
 
         The reference batches only inside one file (model.py:653) and its folder mode is a serial loop
-        (scripts/segment.py:39-56), so short clips decode with 1-2 windows per launch.  Windows are independent, hence
-        pooling changes nothing but the batch a window is decoded in: the per-recording results equal segment()'s
-        (bit-identical in f32 mode).  `srs` is one int, a list, or None when `audios` yields (audio, sr) pairs — `audios`
-        may be a generator that loads files lazily: recordings are consumed group by group.  Returns a list of
-        prediction dicts."""
+        (scripts/segment.py:39-56, evaluate.py:15-24), so short clips decode with 1-2 windows per launch.  Windows are
+        independent, hence pooling changes nothing but the batch a window is decoded in: the per-recording results equal
+        segment()'s (bit-identical in f32 mode).  `srs` is one int, a list, or None when `audios` yields (audio, sr) pairs —
+        `audios` may be a generator that loads files lazily: recordings are consumed group by group.
+        PER-RECORDING parameters: `min_frequency`, `spec_time_step`, `min_segment_length`, `eps`, `time_per_frame_for_voting`,
+        `num_trials` and `consolidation_method` may each be one value for all recordings or a list with one entry per
+        recording (None entries take segment()'s defaults) — what the reference passes per file (evaluate.py:15-24) or per
+        species (config/segment_config.json:1-49: sr 16 k-300 k, spec_time_step 0.0005-0.01, min_frequency 0 / 35 000,
+        1 or 3 trials).  The front-end runs per recording with its own (sr, spec_time_step, min_frequency) filterbank; the
+        windows of all recordings — every one a [80, 1000] log-mel image whatever its rate — share ONE pooled decode.
+        The decode parameters (max_length, num_beams, top_k, top_p, length_penalty) are per call.
+        Returns a list of prediction dicts."""
         if srs is None:
             pairs = iter(audios)
         elif isinstance(srs, (int, float)):
             pairs = ((a, srs) for a in audios)
         else:
             pairs = zip(audios, srs)
-        defaults = self.default_segmentation_config
-        if min_frequency is None:
-            min_frequency = defaults.get("min_frequency", 0)
-        if spec_time_step is None:
-            spec_time_step = defaults.get("spec_time_step", 0.0025)
-        if min_segment_length is None:
-            min_segment_length = spec_time_step * RATIO_DECODING_TIME_STEP_TO_SPEC_TIME_STEP
-        if eps is None:
-            eps = spec_time_step * RATIO_DECODING_TIME_STEP_TO_SPEC_TIME_STEP * 4
-        if time_per_frame_for_voting is None:
-            time_per_frame_for_voting = spec_time_step
+        per_item = [_per_item(v) for v in (min_frequency, spec_time_step, min_segment_length, eps, time_per_frame_for_voting,
+                                          num_trials, consolidation_method)]
         out, group, pending = [], [], 0
 
         def flush():
             nonlocal group, pending
-            pooled = [w for _, _, windows in group for w in windows]
+            pooled = [w for g in group for w in g["windows"]]
             texts = self.generate_segment_text(pooled, batch_size, max_length, num_beams, top_k, top_p, length_penalty,
                                                status_monitor) if pooled else []
             pos = 0
-            for duration, sr, windows in group:
-                mine = texts[pos:pos + len(windows)]
-                pos += len(windows)
-                pred = self.parse_generation(mine, windows, min_segment_length, duration, spec_time_step, num_trials,
-                                             eps, time_per_frame_for_voting, consolidation_method)
-                pred = postprocess.correct_fft_blur(pred, get_n_fft_given_sr(sr), sr)
+            for g in group:
+                mine = texts[pos:pos + len(g["windows"])]
+                pos += len(g["windows"])
+                pred = self.parse_generation(mine, g["windows"], g["min_segment_length"], g["duration"], g["spec_time_step"],
+                                             g["num_trials"], g["eps"], g["frame"], g["method"])
+                pred = postprocess.correct_fft_blur(pred, get_n_fft_given_sr(g["sr"]), g["sr"])
                 out.append(postprocess.drop_consecutive_duplicates(pred))
             group, pending = [], 0
 
         # recordings are pooled in bounded groups (~POOL_WINDOWS windows): features of a group are freed before the next
         # group is cut, so a large folder needs no more device memory than a small one
-        for audio, sr in pairs:
-            windows = self.get_sliced_audios_features(audio, sr, min_frequency, spec_time_step, num_trials)
-            group.append((len(audio) / sr, sr, windows))
+        for (audio, sr), mf, sts, msl, e, tpf, nt, method in zip(pairs, *per_item):
+            mf, sts, msl, e, tpf = self.resolve_segmentation_params(mf, sts, msl, e, tpf)
+            windows = self.get_sliced_audios_features(audio, sr, mf, sts, nt)
+            group.append(dict(duration=len(audio) / sr, sr=sr, windows=windows, spec_time_step=sts, min_segment_length=msl, eps=e,
+                              frame=tpf, num_trials=nt, method=method))
             pending += len(windows)
             if pending >= POOL_WINDOWS:
                 flush()

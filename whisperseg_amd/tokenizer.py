@@ -85,9 +85,10 @@ class WhisperSegTokenizer:
             if tok is None:
                 continue
             if tok in self.added:
+                if skip_special_tokens:      # HF drops them BEFORE byte decoding: the bytes either side form one UTF-8 run
+                    continue
                 flush()
-                if not skip_special_tokens:
-                    out.append(tok)
+                out.append(tok)
             else:
                 buf.extend(self.byte_decoder.get(ch, ord("?")) for ch in tok)
         flush()
