@@ -562,6 +562,26 @@ def extra_lines(args, eng, step, main_in, make_extractor, device, W, slots):
         if engp is not eng:
             del engp
         torch.cuda.empty_cache()
+    # the other BASELINE.json single-GPU configurations with this binary (engine.generate only, log-mel precomputed):
+    # configs[2] large x 8, configs[3] large x 120 (one 1-hour recording), configs[1] base x 32
+    def config_line(engine, n, label):
+        f = feats[:n] if n <= feats.shape[0] else torch.cat([feats] * ((n + feats.shape[0] - 1) // feats.shape[0]))[:n]
+        dt, _ = timed(lambda: engine.generate(f, PROMPT, EOS, EOS, n_slots=n, **gen_kw), reps=3)
+        enc_ms, ckv_ms, dec_ms, n_steps = engine.last_timing()
+        return {"config": label, "windows": n, "audio_sec_per_s": n * 1000 * args.spec_time_step / dt, "ms_per_call": dt * 1e3,
+                "encoder_ms": enc_ms, "cross_kv_ms": ckv_ms, "decode_ms": dec_ms, "decode_ms_per_step": dec_ms / max(n_steps, 1)}
+    cfgs = [config_line(eng, 8, f"configs[2] whisperseg-large {args.dtype}, 8 windows"),
+            config_line(eng, 120, f"configs[3] whisperseg-large {args.dtype}, 120 windows (1 h recording), one GPU")]
+    try:
+        from whisperseg_amd.engine import Engine
+        base = Engine.random(hf_config("base"), device, args.dtype, seed=0)
+        cfgs.insert(0, config_line(base, 32, f"configs[1] whisperseg-base {args.dtype}, 32 windows"))
+        del base
+        torch.cuda.empty_cache()
+    except Exception as exc:
+        cfgs.append({"config": "configs[1]", "error": f"{type(exc).__name__}: {exc}"[:300]})
+    out["baseline_configs"] = cfgs
+
     def big_queues():
         # in-flight batching: 16 x W windows with per-window length caps drawn from a synthetic distribution
         rng = np.random.default_rng(3)

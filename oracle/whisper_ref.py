@@ -286,6 +286,30 @@ def generate(sd, cfg, feats, gp, return_first_logits=False):
     return (out, first_logits) if return_first_logits else out
 
 
+@torch.no_grad()
+def score_sequence(sd, cfg, feats, gp, tokens):
+    """HF's beam score of ONE given hypothesis for ONE window: sum of log_softmax(logits)[token] over the generated tokens
+    (teacher-forced through the same decoder) / generated_length ** length_penalty — the quantity `_beam_search` ranks finished
+    hypotheses by (HF generation/utils.py:3440-3452: topk_log_probs / (cur_len + 1 - prompt_len) ** length_penalty).
+    feats [1,80,1000]; tokens: ids INCLUDING the prompt, up to and including EOS if there is one (pads stripped).
+    Used by tests to show that a beam result that differs from the oracle's is an equally scored hypothesis (a near-tie
+    resolved differently by another summation order), not an error."""
+    P = len(gp.prompt)
+    toks = [int(t) for t in tokens]
+    assert toks[:P] == list(gp.prompt)
+    gen = toks[P:]
+    if gp.eos_token_id in gen:
+        gen = gen[: gen.index(gp.eos_token_id) + 1]
+    dec = Decoder(sd, cfg, encoder_forward(sd, cfg, feats))
+    total = 0.0
+    inp = torch.tensor([toks[:P]], dtype=torch.int64)
+    for t in gen:
+        lp = F.log_softmax(dec.step(inp), dim=-1)
+        total += float(lp[0, t])
+        inp = torch.tensor([[t]], dtype=torch.int64)
+    return total / (len(gen) ** gp.length_penalty)
+
+
 def canonical(tokens, prompt_len, eos_token_id, prompt=None):
     """Generated ids up to and including the first EOS, prompt stripped (works for both HF
     conventions: 4.38.2 returns the prompt, 5.15 strips it)."""

@@ -52,6 +52,19 @@ def gp(nb, ml):
                        suppress_tokens=SUP, begin_suppress_tokens=BSUP)
 
 
+NEAR_TIE = 5e-5      # |score difference| (HF beam score: mean log-prob) under which two hypotheses count as tied
+
+
+def assert_equally_scored(sd, rc, x_i, params, got_tokens, want_tokens, where):
+    """A beam result that differs from the oracle's must be a hypothesis the ORACLE scores the same (to fp32 summation-order
+    noise) as its own choice: seeded-random weights give nearly flat distributions, so beams that differ in one token can
+    tie to ~1e-6 and either arithmetic may rank them either way.  Anything else is a real disagreement and fails."""
+    s_got = R.score_sequence(sd, rc, x_i, params, got_tokens)
+    s_want = R.score_sequence(sd, rc, x_i, params, [int(t) for t in want_tokens])
+    assert abs(s_got - s_want) <= NEAR_TIE, (where, s_got, s_want, list(got_tokens), [int(t) for t in want_tokens])
+    return abs(s_got - s_want)
+
+
 def test_two_layer_8_windows_vs_oracle(gpu_lib, two_layer):
     cfg, rc, sd, engines = two_layer
     x = feats(8, seed=3)
@@ -68,8 +81,11 @@ def test_two_layer_8_windows_vs_oracle(gpu_lib, two_layer):
         assert all(int(toks[i, 3]) == int(want_tok[i][3]) for i in range(8)), nb
         if nb == 1:            # f32 mode, greedy: token-exact
             assert all(same), same
-        else:                  # beams over seeded-random weights score near-ties (two beams that differ in one token of a
-            assert sum(same) >= 6, same   # nearly flat distribution): a 1-ulp summation-order difference may reorder them
+        else:                  # beams: token-exact, or an equally scored hypothesis (asserted, not excused)
+            for i in range(8):
+                if not same[i]:
+                    assert_equally_scored(sd, rc, x[i:i + 1], gp(nb, 10), toks[i, :lens[i]].tolist(), want_tok[i].tolist(), ("8w", nb, i))
+            assert sum(same) >= 4, same
         for dt, cos_min, rel in (("bf16", 0.999, 0.1), ("f16", 0.99999, 0.015)):
             _, _, got16 = gen(engines[dt], x, nb, 10, return_first_logits=True)
             got16 = got16.cpu()
@@ -99,7 +115,10 @@ def test_two_layer_256_windows_1024_rows_vs_oracle(gpu_lib, two_layer):
     same = [R.canonical(t32n[p, :l32n[p]].tolist(), 3, EOS, PROMPT) == R.canonical(want_tok[k].tolist(), 3, EOS, PROMPT)
             for k, p in enumerate(pick)]
     assert all(int(t32n[p, 3]) == int(want_tok[k][3]) for k, p in enumerate(pick))
-    assert sum(same) >= 4, same          # beam near-ties of random weights, see the 8-window test
+    for k, p in enumerate(pick):         # token-exact, or an equally scored hypothesis (see the 8-window test)
+        if not same[k]:
+            assert_equally_scored(sd, rc, x[p:p + 1], gp(4, 8), t32n[p, :l32n[p]].tolist(), want_tok[k].tolist(), ("256w", p))
+    assert sum(same) >= 3, same
     # greedy is free of beam ties: token-exact vs the oracle at 256 rows
     want_g = R.generate(sd, rc, x[pick], gp(1, 8))
     tg, lg = (v.cpu().numpy() for v in gen(engines["f32"], x, 1, 8))
