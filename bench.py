@@ -598,12 +598,12 @@ def extra_lines(args, eng, step, main_in, make_extractor, device, W, slots):
             r = step(audio=audio_q, win_starts=st_q, gen_tokens=2 * args.gen_tokens, window_max_length=lens, **kw)
             torch.cuda.synchronize()
             return time.perf_counter() - t0, r, eng.last_stats()
-        queued(n_slots=DEFAULT_SLOTS, n_lanes=1)                                # graph capture / workspace growth
-        dtd, (tkd, lnd, _), statsd = queued(n_slots=DEFAULT_SLOTS, n_lanes=1)   # the engine's default slot count
-        dt1, (tk, ln, _), stats = queued(n_slots=W, n_lanes=1)                  # W slots, as in the timed step
+        queued(n_slots=DEFAULT_SLOTS)                                # graph capture / workspace growth
+        dtd, (tkd, lnd, _), statsd = queued(n_slots=DEFAULT_SLOTS)   # the engine's default slot count
+        dt1, (tk, ln, _), stats = queued(n_slots=W)                  # W slots, as in the timed step
         # the same windows decoded batch by batch as the reference does (model.py:653): every batch runs to its longest window
         t0 = time.perf_counter()
-        resb = [step(audio=audio_q, win_starts=st_q[lo:lo + W], gen_tokens=2 * args.gen_tokens, window_max_length=lens[lo:lo + W], n_lanes=1)
+        resb = [step(audio=audio_q, win_starts=st_q[lo:lo + W], gen_tokens=2 * args.gen_tokens, window_max_length=lens[lo:lo + W])
                 for lo in range(0, nq, W)]
         torch.cuda.synchronize()
         dtb = time.perf_counter() - t0
@@ -622,20 +622,18 @@ def extra_lines(args, eng, step, main_in, make_extractor, device, W, slots):
                                     "windows_with_tokens_identical_across_slot_counts": agree,
                                     "note": "in the 16-bit modes a window's tokens may depend on the slot COUNT (GEMM plans follow the row "
                                             "count), never on its neighbours; identical in f32 mode (tests/test_scheduler_gpu.py)"}
-        # concurrency: 4 x W windows of fixed decode length through W, 2W, 4W slots (one lane) and as two lanes of 2W slots
+        # concurrency: 4 x W windows of fixed decode length through W, 2W, 4W slots
         audio_4 = torch.cat([audio] * 4)
         st_4 = (torch.arange(4 * W, dtype=torch.int64) * wl).to(device)
         conc = {}
-        for name, kw in ((f"{W}_slots", dict(n_slots=W, n_lanes=1)), (f"{2 * W}_slots", dict(n_slots=2 * W, n_lanes=1)),
-                         (f"{4 * W}_slots", dict(n_slots=4 * W, n_lanes=1)), (f"2_lanes_of_{2 * W}_slots", dict(n_slots=2 * W, n_lanes=2))):
+        for name, kw in ((f"{W}_slots", dict(n_slots=W)), (f"{2 * W}_slots", dict(n_slots=2 * W)), (f"{4 * W}_slots", dict(n_slots=4 * W))):
             step(audio=audio_4, win_starts=st_4, **dict(kw))
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             step(audio=audio_4, win_starts=st_4, **dict(kw))
             torch.cuda.synchronize()
             conc[name] = {"audio_sec_per_s": 4 * W * 1000 * args.spec_time_step / (time.perf_counter() - t0)}
-        out["concurrency"] = dict(conc, windows=4 * W, note="whole step() incl. log-mel and the CPU epilogue; lanes = independent slot groups "
-                                                            "on their own streams: equivalent to one lane with their total slot count")
+        out["concurrency"] = dict(conc, windows=4 * W, note="whole step() incl. log-mel and the CPU epilogue")
     try:      # the two long-queue lines need the 1024-slot workspace (154 GB): report instead of failing when it does not fit
         big_queues()
     except Exception as exc:

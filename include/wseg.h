@@ -138,8 +138,6 @@ size_t wseg_workspace_bytes(const wseg_model* m, int32_t max_windows, int32_t nu
 int wseg_encode(wseg_model* m, const float* feats, int32_t n_windows,
                 void* workspace, size_t workspace_bytes, void* enc_out, void* stream);
 
-#define WSEG_MAX_LANES 4
-
 typedef struct {
   int32_t prompt[8];              /* decoder_input_ids, reference model.py:656 */
   int32_t prompt_len;
@@ -153,7 +151,7 @@ typedef struct {
   int32_t n_begin_suppress;
   /* In-flight batching (the reference decodes batch by batch, model.py:653, one file at a time,
    * scripts/segment.py:39-56).  0 selects the default of each. */
-  int32_t n_slots;                /* window slots PER LANE decoded concurrently; 0 or >= the lane's share: one per window */
+  int32_t n_slots;                /* window slots decoded concurrently; 0 or >= n_windows: one per window                */
   int32_t refill_min;             /* admit queued windows once this many slots are free; 0: n_slots / 8 (min 1)         */
   int32_t lookahead;              /* decode steps the host may run ahead of the device; 0: 1                            */
   const int32_t* window_max_length; /* device [n_windows] per-window cap on the total length (clamped to max_length), or
@@ -168,10 +166,6 @@ typedef struct {
   const void* encoder_output;     /* device [n_windows][enc_positions][d_model] in the model dtype: precomputed encoder
                                      states (wseg_encode) used instead of running the encoder on feats (feats may then
                                      be NULL; rows past the last window must be readable up to a multiple of 256), or NULL */
-  int32_t n_lanes;                /* decode lanes (0 / 1: one): independent groups of n_slots slots stepping side by side
-                                     on separate streams, all fed from the one window queue; at most WSEG_MAX_LANES.  The
-                                     workspace must hold n_lanes * wseg_workspace_bytes(m, n_slots, ...)                    */
-  int32_t reserved_;
 } wseg_generate_params;
 
 /*
@@ -182,10 +176,10 @@ typedef struct {
  * The windows are decoded through n_slots window slots: a slot whose window has finished (EOS / early-stop heuristic /
  * max_length) is retired and re-used for the next queued window while the other slots keep decoding, every slot at its
  * own position.  Idle slots are skipped by every per-step kernel.  The workspace is sized by
- * max(n_lanes, 1) * wseg_workspace_bytes(m, n_slots, ...): it does not grow with n_windows.  The host stays `lookahead`
- * steps ahead of the device and otherwise only waits on the small per-step status mirror.  With n_lanes > 1 the call
- * runs lanes 1.. on streams and host threads of its own (forked behind / joined into `stream`, so the call is still
- * stream-ordered for the caller); a window's tokens do not depend on the lane it ran in.
+ * wseg_workspace_bytes(m, n_slots, ...): it does not grow with n_windows.  The host stays `lookahead` steps ahead of the
+ * device and otherwise only waits on the small per-step status mirror; the call is stream-ordered on `stream`.
+ * (ABI 3 had decode "lanes" — slot groups on separate streams; they measured exactly as one group with their total slot
+ * count and were removed in ABI 4.)
  */
 int wseg_generate(wseg_model* m, const float* feats, int32_t n_windows, const wseg_generate_params* p,
                   void* workspace, size_t workspace_bytes,
@@ -193,15 +187,13 @@ int wseg_generate(wseg_model* m, const float* feats, int32_t n_windows, const ws
 
 /* Scheduler statistics of the last wseg_generate call on this model. */
 typedef struct {
-  int32_t n_windows, n_slots;     /* n_slots: over all lanes                                                            */
-  int32_t n_steps;                /* decode steps launched (each steps every active slot once); the longest lane's count */
+  int32_t n_windows, n_slots;
+  int32_t n_steps;                /* decode steps launched (each steps every active slot once)                          */
   int32_t n_admissions;           /* encoder + cross-K/V passes (groups of windows admitted into free slots)            */
   int64_t slot_steps_active;      /* sum over steps of slots that were decoding a window                                */
-  int64_t slot_steps_total;       /* sum over lanes of steps * slots per lane                                           */
+  int64_t slot_steps_total;       /* steps * slots                                                                      */
   int64_t queued_slot_steps_active; /* the same two sums over the steps launched while windows were still queued, i.e.   */
   int64_t queued_slot_steps_total;  /* without the drain of the last windows (steady-state occupancy of the refill)      */
-  int32_t n_lanes;
-  int32_t reserved_;
 } wseg_generate_stats;
 int wseg_last_stats(const wseg_model* m, wseg_generate_stats* out);
 
@@ -211,7 +203,7 @@ int wseg_debug_first_logits(wseg_model* m, void* workspace, float* out, int32_t 
 
 /* Per-stage device time (ms) of the last wseg_generate call on this model, measured with HIP events
  * on the call's stream: [0]=encoder passes, [1]=cross-K/V passes, [2]=everything else (the decode steps),
- * [3]=number of decode steps.  With several lanes [0] and [1] are per-lane averages (the lanes overlap in time). */
+ * [3]=number of decode steps. */
 int wseg_last_timing(const wseg_model* m, float out[4]);
 
 /* Test / tuning tap: out[M][N] = epilogue(A[M][K] * W[N][K]^T + bias) with the library's GEMM of the given dtype.

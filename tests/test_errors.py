@@ -96,7 +96,7 @@ def test_generate_rejects_bad_requests(gpu_lib):
     for over, word in ((dict(num_beams=0), "num_beams"), (dict(num_beams=9), "num_beams"), (dict(prompt_len=0), "prompt_len"),
                        (dict(prompt_len=9), "prompt_len"), (dict(max_length=3), "max_length"), (dict(max_length=449), "max_length"),
                        (dict(n_suppress=2), "suppress"), (dict(n_begin_suppress=-1), "suppress"), (dict(n_slots=-1), "scheduler"),
-                       (dict(n_lanes=5), "scheduler"), (dict(lookahead=-2), "scheduler"),
+                       (dict(refill_min=-1), "scheduler"), (dict(lookahead=-2), "scheduler"),
                        (dict(num_beams=1, top_k=17), "top_k")):
         assert call(**over) == INVALID, over
         assert word in err(lib), (over, err(lib))
@@ -112,7 +112,7 @@ def test_generate_rejects_bad_requests(gpu_lib):
     torch.cuda.synchronize()
     assert int(lens.min()) >= 4 and int(lens.max()) <= L
     st = _lib.GenerateStats()
-    assert lib.wseg_last_stats(eng.handle, C.byref(st)) == 0 and st.n_windows == W and st.n_lanes == 1
+    assert lib.wseg_last_stats(eng.handle, C.byref(st)) == 0 and st.n_windows == W and st.n_slots == W
     # encode: zero windows is a no-op, null output is rejected
     assert lib.wseg_encode(eng.handle, feats.data_ptr(), 0, ws.data_ptr(), ws.numel(), toks.data_ptr(), _lib.stream_ptr()) == 0
     assert lib.wseg_encode(eng.handle, feats.data_ptr(), W, ws.data_ptr(), ws.numel(), None, _lib.stream_ptr()) == INVALID

@@ -148,7 +148,7 @@ def test_two_layer_1024_windows_4096_rows(gpu_lib, two_layer):
         ref_logits.append(g.cpu()); ref_tok.append(t.cpu())
     g32, t32 = torch.cat(ref_logits), torch.cat(ref_tok)
     for dt, cos_min in (("bf16", 0.999), ("f16", 0.99999)):
-        t, l, g = gen(engines[dt], x, 4, 8, return_first_logits=True, n_slots=1024, n_lanes=1)
+        t, l, g = gen(engines[dt], x, 4, 8, return_first_logits=True, n_slots=1024)
         assert engines[dt].last_stats()["n_slots"] == 1024
         g, t = g.cpu(), t.cpu()
         assert torch.nn.functional.cosine_similarity(g, g32, dim=1).min().item() > cos_min, dt
@@ -156,11 +156,11 @@ def test_two_layer_1024_windows_4096_rows(gpu_lib, two_layer):
         assert float((t[:, 3] == t32[:, 3]).float().mean()) >= (0.9 if dt == "bf16" else 0.97), dt
         small = []
         for lo in range(0, 1024, 256):
-            small.append(gen(engines[dt], x[lo:lo + 256], 4, 8, return_first_logits=True, n_slots=256, n_lanes=1)[2].cpu())
+            small.append(gen(engines[dt], x[lo:lo + 256], 4, 8, return_first_logits=True, n_slots=256)[2].cpu())
         small = torch.cat(small)
         assert torch.nn.functional.cosine_similarity(g, small, dim=1).min().item() > (0.9999 if dt == "bf16" else 0.999999), dt
         # run to run identical at this row count
-        t2, l2 = gen(engines[dt], x, 4, 8, n_slots=1024, n_lanes=1)
+        t2, l2 = gen(engines[dt], x, 4, 8, n_slots=1024)
         assert torch.equal(t2.cpu(), t) and torch.equal(l2.cpu(), l.cpu())
 
 

@@ -9,8 +9,7 @@ window slots, refilling a slot as soon as its window ends.  Properties checked h
     longest window needs, not 445 (device-side idle flags + bounded host look-ahead);
   * per-window length caps behave exactly like separate calls with that max_length;
   * the scheduler statistics add up (every window decoded once, occupancy within (0, 1]);
-  * several lanes (independent slot groups stepping side by side on their own streams and host threads, one shared
-    window queue) give the tokens of one lane with the same slot count."""
+  * a caller stream other than the default one, a sampling call and a per-window-cap call reuse the captured step graph."""
 import json
 import os
 
@@ -46,7 +45,6 @@ def tiny_feats(n_recordings, seed0=300):
 
 
 def gen(eng, x, nb=4, ml=448, **kw):
-    kw.setdefault("n_lanes", 1)      # the single-lane scheduler unless a test asks for lanes (None: the engine's default)
     t, l = eng.generate(x, TM.PROMPT, TM.EOT, TM.EOT, max_length=ml, num_beams=nb, suppress_tokens=TM.SUPPRESS,
                         begin_suppress_tokens=TM.BEGIN_SUPPRESS, **kw)
     return t.cpu(), l.cpu()
@@ -77,39 +75,31 @@ def test_slot_refill_gives_the_same_tokens(gpu_lib, dtype, nb):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_lanes_give_the_same_tokens(gpu_lib, dtype):
+def test_non_default_stream_and_graph_reuse(gpu_lib, dtype):
+    """The call is stream-ordered on the caller's stream; the captured decode-step graph survives calls that differ only in
+    per-call data (sampling seed, per-window length caps: both live in device memory / the admission kernel)."""
     eng = tiny_engine(dtype)
     x = tiny_feats(23)
-    ref_t, ref_l = gen(eng, x, 4, n_slots=5)             # one lane of 5 slots
-    assert eng.last_stats()["n_lanes"] == 1
-    for lanes in (2, 3, 4):
-        t, l = gen(eng, x, 4, n_slots=5, n_lanes=lanes)
-        st = eng.last_stats()
-        assert st["n_lanes"] == lanes and st["n_slots"] == 5 * lanes and st["n_windows"] == 23, st
-        # every lane makes its first claim behind a start gate, so each of them admits at least once
-        assert 0 < st["occupancy"] <= 1.0 and st["n_admissions"] >= lanes, st
-        assert torch.equal(l, ref_l), (lanes, l.tolist(), ref_l.tolist())
-        assert torch.equal(t, ref_t), (lanes, (t != ref_t).any(1).nonzero().flatten().tolist())
-        assert eng.last_timing()[3] == st["n_steps"]
-    # a queue shorter than the lanes' slots is split evenly: 23 windows over 2 lanes of up to 16 slots -> 12 slots each
-    t, l = gen(eng, x, 4, n_slots=16, n_lanes=2)
-    st = eng.last_stats()
-    assert st["n_slots"] == 24 and st["n_admissions"] == 2, st
-    one_t, one_l = gen(eng, x, 4, n_slots=12)
-    assert torch.equal(l, one_l) and torch.equal(t, one_t)
-    # the engine's default: as many full lanes as the queue fills (up to DEFAULT_MAX_LANES)
-    from whisperseg_amd.engine import DEFAULT_MAX_LANES
-    t, l = gen(eng, x, 4, n_slots=8, n_lanes=None)
-    assert eng.last_stats()["n_lanes"] == min(DEFAULT_MAX_LANES, 23 // 8)
-    one_t, one_l = gen(eng, x, 4, n_slots=8)
-    assert torch.equal(l, one_l) and torch.equal(t, one_t)
-    # on a caller stream that is not the default one, results are ordered behind the call
+    ref_t, ref_l = gen(eng, x, 4, n_slots=5)
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
         t, l = eng.generate(x.clone(), TM.PROMPT, TM.EOT, TM.EOT, max_length=448, num_beams=4, suppress_tokens=TM.SUPPRESS,
-                            begin_suppress_tokens=TM.BEGIN_SUPPRESS, n_slots=5, n_lanes=3)
+                            begin_suppress_tokens=TM.BEGIN_SUPPRESS, n_slots=5)
         t, l = t.cpu(), l.cpu()
     assert torch.equal(l, ref_l) and torch.equal(t, ref_t)
+    caps = [6 + (i % 5) for i in range(23)]
+    tc, lc = gen(eng, x, 4, n_slots=5, window_max_length=caps)
+    assert all(int(v) <= c for v, c in zip(lc.tolist(), caps))
+    t2, l2 = gen(eng, x, 4, n_slots=5)                   # back to uncapped: same graph, same tokens as before
+    assert torch.equal(l2, ref_l) and torch.equal(t2, ref_t)
+    # sampling with two seeds: reproducible per seed, different across seeds, and the beam call after it is unaffected
+    a1 = gen(eng, x, 1, n_slots=5, top_k=8, top_p=0.95, seed=1)
+    a2 = gen(eng, x, 1, n_slots=5, top_k=8, top_p=0.95, seed=1)
+    b1 = gen(eng, x, 1, n_slots=5, top_k=8, top_p=0.95, seed=2)
+    assert torch.equal(a1[0], a2[0]) and torch.equal(a1[1], a2[1])
+    assert not torch.equal(a1[0], b1[0])
+    t3, l3 = gen(eng, x, 4, n_slots=5)
+    assert torch.equal(l3, ref_l) and torch.equal(t3, ref_t)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
@@ -123,24 +113,12 @@ def test_default_slot_count_with_a_long_queue(gpu_lib, dtype):
     x = base.repeat(48, 1, 1)[:1100]
     t, l = gen(eng, x, 4, n_slots=None)
     st = eng.last_stats()
-    assert st["n_slots"] == min(DEFAULT_SLOTS, 1100) and st["n_windows"] == 1100 and st["n_lanes"] == 1
+    assert st["n_slots"] == min(DEFAULT_SLOTS, 1100) and st["n_windows"] == 1100
     for i in range(23, 1100):
         assert int(l[i]) == int(l[i % 23]) and torch.equal(t[i], t[i % 23]), (dtype, i)
     if dtype == "f32":
         ref_t, ref_l = gen(eng, base, 4)
         assert torch.equal(l[:23], ref_l) and torch.equal(t[:23], ref_t)
-
-
-def test_lanes_reject_bad_requests(gpu_lib):
-    from whisperseg_amd import _lib
-    eng = tiny_engine("f32")
-    x = tiny_feats(3)
-    with pytest.raises(_lib.WsegError):
-        gen(eng, x, 4, n_slots=2, n_lanes=5)             # more than WSEG_MAX_LANES
-    t, l = gen(eng, x, 4, n_slots=2, n_lanes=4)          # more lanes than windows: clamped
-    assert eng.last_stats()["n_lanes"] == 3
-    ref_t, ref_l = gen(eng, x, 4)
-    assert torch.equal(l, ref_l) and torch.equal(t, ref_t)
 
 
 def test_early_stop_executes_few_steps(gpu_lib):

@@ -9,7 +9,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="large"); ap.add_argument("--windows", type=int, default=8)
 ap.add_argument("--gen", type=int, default=32); ap.add_argument("--beams", type=int, default=4)
 ap.add_argument("--iters", type=int, default=3); ap.add_argument("--dtype", default="bf16")
-ap.add_argument("--slots", type=int, default=0, help="window slots (default: one per window, single lane)")
+ap.add_argument("--slots", type=int, default=0, help="window slots (default: one per window)")
+ap.add_argument("--decode-only", action="store_true", help="encoder states precomputed (64 windows at a time): the call is cross-K/V + decode")
 a = ap.parse_args()
 g = GEO[a.model]
 cfg = dict(d_model=g["d"], encoder_attention_heads=g["h"], decoder_attention_heads=g["h"], encoder_layers=g["L"], decoder_layers=g["L"],
@@ -17,10 +18,13 @@ cfg = dict(d_model=g["d"], encoder_attention_heads=g["h"], decoder_attention_hea
 eng = Engine.random(cfg, "cuda:0", a.dtype)
 feats = torch.randn(a.windows, 80, 1000, device="cuda") * 0.5
 prompt, eos = [50258, 50259, 50363], 50257
+extra = {}
+if a.decode_only:
+    extra["encoder_output"] = torch.cat([eng.encode(feats[lo:lo + 64]) for lo in range(0, a.windows, 64)])
 for it in range(a.iters):
     torch.cuda.synchronize(); t0 = time.time()
     toks, lens = eng.generate(feats, prompt, eos, eos, max_length=3 + a.gen, num_beams=a.beams, suppress_tokens=[eos, 1, 2], begin_suppress_tokens=[220],
-                                n_slots=a.slots or a.windows, n_lanes=1)
+                                n_slots=a.slots or a.windows, **extra)
     torch.cuda.synchronize(); dt = time.time() - t0
     enc, ckv, dec, steps = eng.last_timing()
     print(f"iter {it}: total {dt*1e3:.1f} ms | enc {enc:.1f} ckv {ckv:.1f} dec {dec:.1f} ms over {int(steps)} steps ({dec/max(steps,1):.3f} ms/step) | {a.windows/dt:.1f} windows/s", flush=True)

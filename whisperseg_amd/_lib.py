@@ -26,14 +26,13 @@ class GenerateParams(C.Structure):
                 ("begin_suppress_tokens", C.c_void_p), ("n_begin_suppress", C.c_int32),
                 ("n_slots", C.c_int32), ("refill_min", C.c_int32), ("lookahead", C.c_int32),
                 ("window_max_length", C.c_void_p), ("top_k", C.c_int32), ("top_p", C.c_float), ("seed", C.c_uint64),
-                ("encoder_output", C.c_void_p), ("n_lanes", C.c_int32), ("reserved_", C.c_int32)]
+                ("encoder_output", C.c_void_p)]
 
 
 class GenerateStats(C.Structure):
     _fields_ = [("n_windows", C.c_int32), ("n_slots", C.c_int32), ("n_steps", C.c_int32), ("n_admissions", C.c_int32),
                 ("slot_steps_active", C.c_int64), ("slot_steps_total", C.c_int64),
-                ("queued_slot_steps_active", C.c_int64), ("queued_slot_steps_total", C.c_int64),
-                ("n_lanes", C.c_int32), ("reserved_", C.c_int32)]
+                ("queued_slot_steps_active", C.c_int64), ("queued_slot_steps_total", C.c_int64)]
 
 
 # name -> (restype, argtypes); every symbol include/wseg.h declares.

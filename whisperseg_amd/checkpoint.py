@@ -52,7 +52,8 @@ class LazyCheckpoint:
         self.model_dir = model_dir
         self.kind, wm = checkpoint_files(model_dir)
         self._handles = {}        # safetensors: shard file -> open handle
-        self._bin_cache = (None, None)   # (shard file, state dict) of the .bin shard touched last
+        self._bin_cache = {}      # .bin shards: the two most recently used state dicts (LRU; prepare_weights interleaves
+        self.non_mmap_loads = 0   # embedding / norm tensors with the layers, so one cached shard would thrash)
         if wm is None:
             single = SAFE_SINGLE if self.kind == "safetensors" else BIN_SINGLE
             wm = {k: single for k in self._shard_keys(single)}
@@ -67,15 +68,21 @@ class LazyCheckpoint:
         return h
 
     def _bin(self, shard):
-        if self._bin_cache[0] != shard:
-            self._bin_cache = (None, None)
-            path = os.path.join(self.model_dir, shard)
-            try:
-                sd = torch.load(path, map_location="cpu", weights_only=True, mmap=True)
-            except (RuntimeError, ValueError):      # legacy (non-zipfile) serialisation cannot be mmapped
-                sd = torch.load(path, map_location="cpu", weights_only=True)
-            self._bin_cache = (shard, sd)
-        return self._bin_cache[1]
+        if shard in self._bin_cache:
+            self._bin_cache[shard] = self._bin_cache.pop(shard)      # most recently used last
+            return self._bin_cache[shard]
+        while len(self._bin_cache) >= 2:
+            self._bin_cache.pop(next(iter(self._bin_cache)))
+        path = os.path.join(self.model_dir, shard)
+        try:
+            sd = torch.load(path, map_location="cpu", weights_only=True, mmap=True)
+        except (RuntimeError, ValueError):      # legacy (non-zipfile) serialisation cannot be mmapped: the whole shard is read
+            self.non_mmap_loads += 1
+            import warnings
+            warnings.warn(f"{path}: legacy torch serialisation, loading the whole shard into host memory (no mmap)")
+            sd = torch.load(path, map_location="cpu", weights_only=True)
+        self._bin_cache[shard] = sd
+        return sd
 
     def _shard_keys(self, shard):
         return list(self._safe(shard).keys()) if self.kind == "safetensors" else list(self._bin(shard).keys())
@@ -100,4 +107,4 @@ class LazyCheckpoint:
 
     def close(self):
         self._handles.clear()
-        self._bin_cache = (None, None)
+        self._bin_cache = {}

@@ -24,7 +24,7 @@ struct DecodeState {
   const int* win_max_length;       // [n_windows] per-window caps (device) or null
   int top_k;                       // > 1 (greedy path only): sample among the top_k processed logits
   float top_p;                     // nucleus mass for sampling
-  unsigned long long seed;
+  const unsigned long long* seed;  // device: sampling seed of the current call (read by greedy_step_kernel; not part of the step graph)
   int* tokens_in;                  // [R]   token fed at this step
   int* run_seq;                    // [W][nb][L]
   int* fin_seq;                    // [W][nb][L]

@@ -880,7 +880,7 @@ __global__ void greedy_step_kernel(DecodeState st) {
       kept += pr[j]; before += pr[j]; ++n_keep;
     }
     // counter-based uniform in [0, 1): splitmix64 of (seed, window, position)
-    unsigned long long x = st.seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)st.win[w] * 4096ull + (unsigned long long)cur_len + 1ull);
+    unsigned long long x = *st.seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)st.win[w] * 4096ull + (unsigned long long)cur_len + 1ull);
     x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
     const float u = (float)(x >> 40) * (1.0f / 16777216.0f) * kept;
     float acc = 0.f;

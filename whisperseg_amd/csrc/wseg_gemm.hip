@@ -662,11 +662,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h16_persist_kernel(const ty
 // leaves buffer e & 1 to the epilogue as its staging area: the B pair of K tile e+2 is held back to phase 1 of K tile
 // e+1, which both groups reach only after the barrier that closes the (shared) epilogue interval.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int EPI>
+template <typename T, int EPI, bool STAGED_RESID = false>
 __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::H* __restrict__ A, int lda, const typename IO<T>::H* __restrict__ W,
                                                           int ldw, int M, int N, int K, EpiParams ep, int ntm, int GM) {
   typedef typename IO<T>::H HT;
   constexpr bool X3M = IO<T>::split;      // hi | lo K tiles: 24 instead of 16 MFMAs per phase, (W hi, A hi) (W hi, A lo) (W lo, A hi)
+  // Residual epilogue without LDS and without barriers (EPI_RESID, opt-in: WSEG_PP_DIRECT_RESID=1; the LDS-staged one is the
+  // default): the accumulators of a tile START as its fp32 residual rows (loaded in the MFMA accumulator layout: a lane owns 4
+  // consecutive columns of a row, 16 bytes), the MFMAs add A W^T on top, and the epilogue is bias + 32 direct 16-byte stores
+  // per lane, each followed by the residual load of the NEXT tile into the register quad just stored.  The staged epilogue
+  // costs 21 us per 256x256 tile with the matrix pipe idle; this one measured 27 us: timing-only variants (no loads: -13 us, no
+  // stores: -16 us per tile) show the epilogue is the HBM-bound burst of all CUs hitting their tile boundary together
+  // (1.31 GB of fp32 residual traffic at ~4.6 TB/s), not a per-wave latency chain — kept as an experiment knob.
+  constexpr bool DIRECT = EPI == EPI_RESID && !STAGED_RESID;
   constexpr int BM = 256, BN = 256, BK = 64, TM = 128, TN = 64, MI = 8, NI = 4;
   constexpr int HTILE = 128 * BK;                      // elements per half-tile (16 KB)
   constexpr int BUF = 4 * HTILE;                       // elements per K-tile buffer: [A0 | A1 | B0 | B1]
@@ -761,17 +769,39 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   } while (0)
 
   int g = 0;                                           // K tiles consumed so far
+  f32x4 acc[NI][MI];
+  constexpr bool direct = DIRECT;
+  // residual rows of the tile at (tm0, tn0) into the accumulators, opaque to the compiler's waitcnt bookkeeping (as C++ loads
+  // it would have to wait for them at the first accumulator use of EVERY K-loop iteration, draining the LDS-DMA prefetch each
+  // time): retired by the explicit vmcnt(0) in front of the tile's first MFMA.  Quadrant order = the order phases 0..3 use them.
+  auto resid_ptr = [&](int tm0, int tn0, int i, int j) {
+    const int m = min(tm0 + wr * TM + j * 16 + fr, M - 1);
+    return (const float*)ep.resid + (size_t)m * ep.ldc + (tn0 + wc * TN + i * 16 + fg * 4);
+  };
+  if constexpr (DIRECT) {
+    int tm0, tn0;
+    tile_coords(start + loc, tm0, tn0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 2 * ((q == 1 || q == 2) ? 1 : 0); i < 2 * ((q == 1 || q == 2) ? 1 : 0) + 2; ++i)
+#pragma unroll
+        for (int j = 4 * (q >> 1); j < 4 * (q >> 1) + 4; ++j)
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(acc[i][j]) : "v"(resid_ptr(tm0, tn0, i, j)) : "memory");
+  }
   for (int idx = loc; idx < count; idx += bpx) {
   int m0, n0;
   tile_coords(start + idx, m0, n0);
-  f32x4 acc[NI][MI];
+  if (!(DIRECT && direct)) {
 #pragma unroll
-  for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 #pragma nounroll
   for (int kt = 0; kt < nk; ++kt, ++g) {
-    const bool first = kt == 0 && g > 0, final = kt == nk - 1;
+    // direct epilogue: the K-tile stream never pauses at an output-tile boundary (no staging buffer to protect)
+    const bool first = !(DIRECT && direct) && kt == 0 && g > 0, final = !(DIRECT && direct) && kt == nk - 1;
     const HT* cur = smem + (g & 1) * BUF;
     bf16x8 afr[4][2], bfr[NI][2];
     // ---- phase 0: b0, a0 -> quadrant (a0, b0) ----
@@ -785,6 +815,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
       afr[j][0] = *(const bf16x8*)(cur + j * 16 * BK + fa0);
       afr[j][1] = *(const bf16x8*)(cur + j * 16 * BK + fa1);
     }
+    if (DIRECT && direct && kt == 0) wait_vmcnt<0>();        // this tile's residual rows have landed in acc
     __builtin_amdgcn_sched_barrier(0);
     WSEG_PP_MFMA(0, 0);
     __builtin_amdgcn_s_barrier();
@@ -821,10 +852,35 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   // then drops one barrier behind again.  Every wave stages in its own strip of the buffer the last K tile left; nothing
   // is prefetched into that buffer before phase 1 of the next K tile, which both groups reach only after the barrier
   // below.  (Requesting group 0's residual rows before its idle interval measured no further gain.)
-  if (wr == 0) __builtin_amdgcn_s_barrier();
-  staged_epilogue<T, EPI, MI, NI>(acc, (float*)(smem + ((g - 1) & 1) * BUF), ep, M, m0 + wr * TM, n0 + wc * TN, lane, wave);
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();
+  if constexpr (DIRECT) {
+    typedef typename IO<T>::P PT;
+    const int nidx = idx + bpx;
+    const bool has_next = nidx < count;
+    int nm0 = 0, nn0 = 0;
+    if (has_next) tile_coords(start + nidx, nm0, nn0);
+    float bv[NI][4];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (ep.bias) Vec4<PT>::ld((const PT*)ep.bias + n0 + wc * TN + i * 16 + fg * 4, bv[i]);
+      else bv[i][0] = bv[i][1] = bv[i][2] = bv[i][3] = 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 2 * ((q == 1 || q == 2) ? 1 : 0); i < 2 * ((q == 1 || q == 2) ? 1 : 0) + 2; ++i)
+#pragma unroll
+        for (int j = 4 * (q >> 1); j < 4 * (q >> 1) + 4; ++j) {
+          const int m = m0 + wr * TM + j * 16 + fr;
+          const f32x4 v = {acc[i][j][0] + bv[i][0], acc[i][j][1] + bv[i][1], acc[i][j][2] + bv[i][2], acc[i][j][3] + bv[i][3]};
+          if (m < M) *(f32x4*)((float*)ep.out + (size_t)m * ep.ldc + (n0 + wc * TN + i * 16 + fg * 4)) = v;
+          if (has_next) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(acc[i][j]) : "v"(resid_ptr(nm0, nn0, i, j)) : "memory");
+        }
+  } else {
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    staged_epilogue<T, EPI, MI, NI>(acc, (float*)(smem + ((g - 1) & 1) * BUF), ep, M, m0 + wr * TM, n0 + wc * TN, lane, wave);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+  }
   }
 #undef WSEG_PP_MFMA
   if (wr == 0) __builtin_amdgcn_s_barrier();          // pair group 1's extra barrier
@@ -1275,8 +1331,15 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
       if (pingpong && g.K >= 128) {
         int grid = ntiles < n_cu ? ntiles : n_cu;
         grid &= ~7;
-        hipLaunchKernelGGL((gemm_h16_pp_kernel<T, EPI>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K, g.ep, ntm,
-                           group_m);
+        // A/B knob: register-resident residual epilogue (measured slower, profiles/README.md r03: all CUs reach their epilogue
+        // together and its 1.3 GB of fp32 residual traffic is an HBM-bound burst either way; staged 540 / 1513 us, direct 590 / 1525 us)
+        static const bool resid_staged = getenv("WSEG_PP_DIRECT_RESID") == nullptr;
+        if (EPI == EPI_RESID && resid_staged)
+          hipLaunchKernelGGL((gemm_h16_pp_kernel<T, EPI, true>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K, g.ep, ntm,
+                             group_m);
+        else
+          hipLaunchKernelGGL((gemm_h16_pp_kernel<T, EPI, false>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K, g.ep, ntm,
+                             group_m);
       } else if (persist) {
         int grid = ntiles < n_cu ? ntiles : n_cu;
         grid &= ~7;

@@ -5,12 +5,8 @@
 // greedy / beam-search decoding (HF generation/utils.py:3208-3510).  The host code below only enqueues
 // kernels on the caller's stream; all decoding state lives in the caller-provided workspace.
 #include <algorithm>
-#include <condition_variable>
 #include <map>
-#include <memory>
-#include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 #include "wseg_dec.h"
 
@@ -31,6 +27,7 @@ struct DecPlan {   // decoder-side buffers (W window slots)
   char *ck, *cv, *sk, *sv, *dx, *dy, *dq, *dattn, *dh, *logits, *first_logits, *splitk, *mask;
   char *tk_val, *tk_idx, *tk_stat;
   int *adm_slots, *adm_wins, *ret_slots;     // device lists written by the scheduler (admission / retirement)
+  int* seed_dev;                             // sampling seed (2 words), rewritten per call: the step graph stays valid
   size_t splitk_bytes;
   DecodeState st;
 };
@@ -52,11 +49,9 @@ struct PinnedRing {
   int next = 0;
 };
 
-// One decode lane of wseg_generate: the scheduler state that survives between calls (pinned staging rings, timing
-// events, the captured step graph).  Lane 0 runs on the caller's stream in the caller's thread; lanes 1.. own a stream.
-struct Lane {
-  hipStream_t own_stream = nullptr;
-  hipEvent_t ev_sync = nullptr;        // fork (caller's stream -> lanes) / join (lane -> caller's stream)
+// Scheduler state of wseg_generate that survives between calls: pinned staging rings, timing events, the captured
+// decode-step graph.
+struct Sched {
   std::vector<hipEvent_t> ev_pool;     // timing events: pairs around every encoder / cross-K/V pass
   size_t ev_used = 0;
   std::vector<int> ev_enc, ev_ckv;     // indices of (begin, end) pairs in ev_pool
@@ -65,7 +60,6 @@ struct Lane {
   hipGraphExec_t step_graph = nullptr;
   hipStream_t cap_stream = nullptr;    // capture happens on a private stream (the legacy NULL stream cannot capture)
   std::vector<unsigned char> step_graph_key;
-  wseg_generate_stats stats = {};
 };
 
 }  // namespace
@@ -80,11 +74,11 @@ struct wseg_model {
   const void *dec_tok, *dec_pos, *dec_ln_g, *dec_ln_b;
   std::vector<EncLayer> enc;
   std::vector<DecLayer> dec;
-  std::vector<std::unique_ptr<Lane>> lanes;
-  // last wseg_generate call: whole-call event pair (in lane 0's pool), geometry, merged scheduler statistics
+  Sched sched;
+  // last wseg_generate call: whole-call event pair, geometry, scheduler statistics
   int ev_total[2] = {-1, -1};
   bool timing_valid = false;
-  int last_W = 0, last_nb = 0, last_L = 0, last_lanes = 0;
+  int last_W = 0, last_nb = 0, last_L = 0;
   wseg_generate_stats stats = {};
 };
 
@@ -143,6 +137,7 @@ void make_plan(const wseg_model* m, int W, int nb, int L, char* base, Plan& p) {
   q.adm_slots = (int*)take(Wc * 4);
   q.adm_wins = (int*)take(Wc * 4);
   q.ret_slots = (int*)take(Wc * 4);
+  q.seed_dev = (int*)take(8);
   DecodeState& st = q.st;
   st.W = (int)Wc; st.nb = nb; st.L = L; st.V = c.vocab; st.ldv = m->vp;
   st.pos = (int*)take(Wc * 4);
@@ -360,16 +355,12 @@ static void ring_free(PinnedRing& r) {
 
 extern "C" void wseg_model_destroy(wseg_model* m) {
   if (!m) return;
-  for (auto& lp : m->lanes) {
-    Lane& ln = *lp;
-    for (hipEvent_t e : ln.ev_pool) (void)hipEventDestroy(e);
-    if (ln.ev_sync) (void)hipEventDestroy(ln.ev_sync);
-    if (ln.step_graph) (void)hipGraphExecDestroy(ln.step_graph);
-    if (ln.cap_stream) (void)hipStreamDestroy(ln.cap_stream);
-    if (ln.own_stream) (void)hipStreamDestroy(ln.own_stream);
-    ring_free(ln.ring_h2d);
-    ring_free(ln.ring_status);
-  }
+  Sched& sc = m->sched;
+  for (hipEvent_t e : sc.ev_pool) (void)hipEventDestroy(e);
+  if (sc.step_graph) (void)hipGraphExecDestroy(sc.step_graph);
+  if (sc.cap_stream) (void)hipStreamDestroy(sc.cap_stream);
+  ring_free(sc.ring_h2d);
+  ring_free(sc.ring_status);
   delete m;
 }
 
@@ -381,6 +372,7 @@ extern "C" int wseg_model_set_tensor(wseg_model* m, const char* name, const void
   if (((uintptr_t)dev_ptr) & 15) { set_error("tensor '%s' is not 16-byte aligned", name); return WSEG_ERR_INVALID; }
   *it->second.field = dev_ptr;
   it->second.set = true;
+  m->sched.step_graph_key.clear();      // a captured decode step holds the old pointer: recapture on the next call
   return WSEG_OK;
 }
 
@@ -436,7 +428,7 @@ static int ring_acquire(PinnedRing& r, int* idx) {
   *idx = i;
   return WSEG_OK;
 }
-static int h2d_list(Lane& ln, const int* vals, int n, int* dev, hipStream_t s) {
+static int h2d_list(Sched& ln, const int* vals, int n, int* dev, hipStream_t s) {
   int i;
   WSEG_TRY(ring_acquire(ln.ring_h2d, &i));
   int* h = ln.ring_h2d.host + (size_t)i * ln.ring_h2d.cap;
@@ -446,64 +438,28 @@ static int h2d_list(Lane& ln, const int* vals, int n, int* dev, hipStream_t s) {
   ln.ring_h2d.used[i] = true;
   return WSEG_OK;
 }
-static int timing_event(Lane& ln, hipStream_t s, int* idx) {
+static int timing_event(Sched& ln, hipStream_t s, int* idx) {
   if (ln.ev_used == ln.ev_pool.size()) { hipEvent_t e; WSEG_HIP_CHECK(hipEventCreate(&e)); ln.ev_pool.push_back(e); }
   *idx = (int)ln.ev_used++;
   WSEG_HIP_CHECK(hipEventRecord(ln.ev_pool[*idx], s));
   return WSEG_OK;
 }
 
-namespace {
-// The queue of windows still waiting for a slot, shared by the lanes of one wseg_generate call.
-struct WindowQueue {
-  std::mutex mu;
-  std::condition_variable cv;
-  int next = 0, total = 0;
-  int lanes = 1, arrived = 0;
-  // Every lane makes its first claim only once all lanes are running: a lane whose host thread starts late would otherwise
-  // find its even share of a short queue already taken by the others' refills.
-  void arrive() {                                        // (also called by a lane that fails before it can start)
-    std::lock_guard<std::mutex> lk(mu);
-    if (++arrived >= lanes) cv.notify_all();
-  }
-  void start_gate() {
-    std::unique_lock<std::mutex> lk(mu);
-    if (++arrived >= lanes) cv.notify_all();
-    else cv.wait(lk, [&] { return arrived >= lanes; });
-  }
-  // Claims up to min(n_free, cap) windows for a lane under the refill rule (enough free slots, or the rest of the queue,
-  // or a lane with nothing to do).  Returns the count, *start = first claimed window, *drained = queue empty afterwards.
-  int claim(int n_free, int cap, int refill_min, bool lane_idle, int* start, bool* drained) {
-    std::lock_guard<std::mutex> lk(mu);
-    const int rem = total - next;
-    int n = rem < n_free ? rem : n_free;
-    if (n > cap) n = cap;
-    if (n > 0 && (n >= refill_min || n == rem || lane_idle)) { *start = next; next += n; }
-    else n = 0;
-    *drained = next == total;
-    return n;
-  }
-};
-}  // namespace
-
-// One lane of a wseg_generate call: decodes windows claimed from `wq` through S window slots laid out at `base`, on
-// stream s, until the queue is empty and its own slots have drained.
+// Decode of n_windows windows through S window slots on stream s.
 //
 // The reference decodes batch by batch (model.py:653): a batch runs until its slowest window has finished.  Here a
 // finished window's slot is retired and handed to the next queued window while the other slots keep decoding: every
 // slot has its own position, every per-step kernel skips idle slots (so they cost no K/V traffic), and the captured
-// step graph never changes.  Windows are independent, so the tokens of a window do not depend on which slot (or lane)
-// it ran in or on what ran beside it (row-independent kernels, fixed row count => fixed tile / split-K plan).
+// step graph never changes.  Windows are independent, so the tokens of a window do not depend on which slot it ran in
+// or on what ran beside it (row-independent kernels, fixed row count => fixed tile / split-K plan).
 // The host runs at most `lookahead` steps ahead of the device: the per-step status mirror (done flag of every slot)
 // is read behind an event, which both bounds the wasted steps after the last window finishes and tells the scheduler
 // which slots to retire / refill.
-static int generate_lane(wseg_model* m, Lane& ln, int n_lanes, const float* feats, WindowQueue& wq,
-                         const wseg_generate_params* gp, char* base, int S, int first_cap, int32_t* out_tokens,
-                         int32_t* out_lengths, hipStream_t s) {
-  wq.start_gate();                                       // before anything that can fail: every lane passes exactly once
+static int generate_windows(wseg_model* m, const float* feats, int n_windows, const wseg_generate_params* gp, char* base, int S,
+                            int32_t* out_tokens, int32_t* out_lengths, hipStream_t s) {
+  Sched& ln = m->sched;
   const wseg_model_config& c = m->cfg;
   const int nb = gp->num_beams, P = gp->prompt_len, L = gp->max_length;
-  const int n_windows = wq.total;
   const int G = gp->refill_min > 0 ? gp->refill_min : (S >= 16 ? S / 8 : 1);                // admit once this many slots are free
   const int K = gp->lookahead > 0 ? (gp->lookahead < PinnedRing::N - 2 ? gp->lookahead : PinnedRing::N - 2) : 1;
   Plan p;
@@ -515,10 +471,18 @@ static int generate_lane(wseg_model* m, Lane& ln, int n_lanes, const float* feat
   st.win_max_length = gp->window_max_length;
   st.top_k = (nb == 1 && gp->top_k > 1) ? gp->top_k : 1;
   st.top_p = gp->top_p;
-  st.seed = gp->seed;
-  WSEG_TRY(ring_prepare(ln.ring_h2d, S));
+  st.seed = (const unsigned long long*)q.seed_dev;
+  WSEG_TRY(ring_prepare(ln.ring_h2d, S > 2 ? S : 2));
   WSEG_TRY(ring_prepare(ln.ring_status, S));
-  ln.stats = wseg_generate_stats();
+  wseg_generate_stats& stats = m->stats;
+  stats = wseg_generate_stats();
+  stats.n_windows = n_windows; stats.n_slots = S;
+  {   // the seed lives in device memory (read by the sampling kernel): per-call values do not invalidate the step graph
+    const unsigned long long sd = gp->seed;
+    int words[2];
+    memcpy(words, &sd, 8);
+    WSEG_TRY(h2d_list(ln, words, 2, q.seed_dev, s));
+  }
   WSEG_TRY(launch_build_suppress_mask((unsigned char*)q.mask, c.vocab, gp->suppress_tokens, gp->n_suppress,
                                       gp->begin_suppress_tokens, gp->n_begin_suppress, s));
   WSEG_TRY(launch_decode_reset(st, s));
@@ -531,8 +495,7 @@ static int generate_lane(wseg_model* m, Lane& ln, int n_lanes, const float* feat
   std::vector<int> slot_win(S, -1), slot_from(S, 0);   // window in the slot (-1 = free), first step whose status counts for it
   std::vector<int> free_slots, tmp_a, tmp_b;
   for (int i = S - 1; i >= 0; --i) free_slots.push_back(i);   // popped from the back: lowest slot first
-  int in_flight = 0, t = 0;
-  bool drained = false;                                  // no window left in the queue (for any lane)
+  int in_flight = 0, t = 0, next_window = 0;
 
   // encoder + cross-K/V of windows [w0, w0 + n) into n free slots; their decode state starts at position 0
   auto admit = [&](int w0, int n) -> int {
@@ -562,7 +525,7 @@ static int generate_lane(wseg_model* m, Lane& ln, int n_lanes, const float* feat
     ln.ev_enc.push_back(e0); ln.ev_enc.push_back(e1); ln.ev_ckv.push_back(e1); ln.ev_ckv.push_back(e2);
     WSEG_TRY(launch_decode_admit(st, q.adm_slots, q.adm_wins, n, s));
     in_flight += n;
-    ln.stats.n_admissions += 1;
+    stats.n_admissions += 1;
     return WSEG_OK;
   };
 
@@ -576,22 +539,22 @@ static int generate_lane(wseg_model* m, Lane& ln, int n_lanes, const float* feat
     else WSEG_TRY(launch_beam_step(st, qs));
     return WSEG_OK;
   };
-  // The step reads every step-dependent value (positions, tokens, ancestry, idle flags) from device memory, so ONE
-  // captured graph per lane serves all steps and later calls: replay costs ~1.6 us per kernel instead of ~5 us per
-  // eager launch.
+  // The step reads every step-dependent value (positions, tokens, ancestry, idle flags, the sampling seed) from device
+  // memory, so ONE captured graph serves all steps and later calls: replay costs ~1.6 us per kernel instead of ~5 us per
+  // eager launch.  The key holds what the captured kernels take BY VALUE; per-window length caps are applied by the
+  // admission kernel (launched outside the graph) and the weight pointers invalidate the key in wseg_model_set_tensor.
   static const bool use_graph = getenv("WSEG_NO_GRAPH") == nullptr;
   std::vector<unsigned char> key;
   {
     auto put = [&](const void* ptr, size_t n) { const unsigned char* b = (const unsigned char*)ptr; key.insert(key.end(), b, b + n); };
     put(&base, sizeof(base)); put(&S, 4); put(&nb, 4); put(&L, 4);
     put(&st.P, 4); put(&st.eos, 4); put(&st.pad, 4); put(&st.length_penalty, 4); put(st.prompt, sizeof(st.prompt));
-    put(&st.win_max_length, sizeof(st.win_max_length));
-    put(&st.top_k, 4); put(&st.top_p, 4); put(&st.seed, 8);
+    put(&st.top_k, 4); put(&st.top_p, 4);
   }
   auto launch_step = [&]() -> int {
-    // the first generated step of a single-lane call whose windows all start together is launched eagerly with the
-    // logits snapshot (wseg_debug_first_logits); every other step replays the graph
-    const bool snap = n_lanes == 1 && t == P - 1 && n_windows <= S;
+    // the first generated step of a call whose windows all start together is launched eagerly with the logits snapshot
+    // (wseg_debug_first_logits); every other step replays the graph
+    const bool snap = t == P - 1 && n_windows <= S;
     if (snap || !use_graph) return enqueue_step(snap, s);
     if (!ln.step_graph || ln.step_graph_key != key) {
       if (ln.step_graph) { (void)hipGraphExecDestroy(ln.step_graph); ln.step_graph = nullptr; }
@@ -625,10 +588,10 @@ static int generate_lane(wseg_model* m, Lane& ln, int n_lanes, const float* feat
       if (done[sl]) { tmp_a.push_back(sl); slot_win[sl] = -1; }
       else ++active;
     }
-    ln.stats.slot_steps_active += active + (int64_t)tmp_a.size();
+    stats.slot_steps_active += active + (int64_t)tmp_a.size();
     if (step_queued[u % PinnedRing::N]) {
-      ln.stats.queued_slot_steps_active += active + (int64_t)tmp_a.size();
-      ln.stats.queued_slot_steps_total += S;
+      stats.queued_slot_steps_active += active + (int64_t)tmp_a.size();
+      stats.queued_slot_steps_total += S;
     }
     if (!tmp_a.empty()) {
       const int n = (int)tmp_a.size();
@@ -642,15 +605,16 @@ static int generate_lane(wseg_model* m, Lane& ln, int n_lanes, const float* feat
   };
 
   int consumed = 0;                               // statuses of steps [0, consumed) have been processed
-  bool first = true;
   while (true) {
-    if (!drained) {
-      // a lane's first claim is capped at its even share of a short queue, so that the lanes start balanced
-      int w0 = 0;
-      const int n_adm = wq.claim((int)free_slots.size(), first ? first_cap : S, G, in_flight == 0, &w0, &drained);
-      first = false;
-      if (n_adm > 0) WSEG_TRY(admit(w0, n_adm));
+    const int rem = n_windows - next_window;
+    if (rem > 0) {      // refill rule: enough free slots, or the rest of the queue, or nothing else is running
+      const int n_adm = std::min(rem, (int)free_slots.size());
+      if (n_adm > 0 && (n_adm >= G || n_adm == rem || in_flight == 0)) {
+        WSEG_TRY(admit(next_window, n_adm));
+        next_window += n_adm;
+      }
     }
+    const bool drained = next_window == n_windows;
     if (in_flight == 0) break;
     if (drained) {                // nothing left to admit later: stop launching once every window in flight must have ended
       bool may_run = false;       // (a window admitted before step f feeds its last position, L - 2, at step f + L - 2)
@@ -669,21 +633,19 @@ static int generate_lane(wseg_model* m, Lane& ln, int n_lanes, const float* feat
       step_queued[t % PinnedRing::N] = !drained;
     }
     ++t;
-    ln.stats.slot_steps_total += S;
+    stats.slot_steps_total += S;
     // stay at most K steps ahead of the device
     while (consumed < t - K) WSEG_TRY(consume_status(consumed++));
   }
   while (consumed < t) WSEG_TRY(consume_status(consumed++));
   if (in_flight != 0) { set_error("scheduler ended with %d windows in flight", in_flight); return WSEG_ERR_STATE; }
-  ln.stats.n_steps = t;
+  stats.n_steps = t;
   return WSEG_OK;
 }
 
-// Decode of n_windows windows: n_lanes lanes of n_slots window slots each, all claiming windows from one queue.
-// Lanes are independent decode loops on separate streams (lane 0: the caller's stream and thread; lanes 1..: a stream
-// and a host thread of their own for the duration of the call).  A decode step alternates short latency-bound GEMM
-// launches with HBM-bound attention launches, so two or three lanes stepping side by side fill each other's gaps
-// (profiles/README.md: 2 x 256 slots decode 512 windows 13 % faster than one lane of 256 or of 512 slots).
+// Decode of n_windows windows through n_slots window slots (one decode loop on the caller's stream).  More concurrency comes
+// from more SLOTS: independent slot groups on separate streams ("lanes", round 2) measured exactly as one group with their
+// total slot count (profiles/README.md r02) and were removed in round 3.
 extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_windows, const wseg_generate_params* gp,
                              void* workspace, size_t workspace_bytes, int32_t* out_tokens, int32_t* out_lengths,
                              void* stream_) {
@@ -698,71 +660,19 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
   if (gp->n_suppress < 0 || gp->n_begin_suppress < 0 || (gp->n_suppress && !gp->suppress_tokens) || (gp->n_begin_suppress && !gp->begin_suppress_tokens)) {
     set_error("bad suppress-token lists"); return WSEG_ERR_INVALID;
   }
-  if (gp->n_slots < 0 || gp->refill_min < 0 || gp->lookahead < 0 || gp->n_lanes < 0 || gp->n_lanes > WSEG_MAX_LANES) {
-    set_error("bad scheduler parameters"); return WSEG_ERR_INVALID;
-  }
+  if (gp->n_slots < 0 || gp->refill_min < 0 || gp->lookahead < 0) { set_error("bad scheduler parameters"); return WSEG_ERR_INVALID; }
   if (nb == 1 && gp->top_k > MAX_CAND) { set_error("top_k %d unsupported (sampling draws among at most %d candidates)", gp->top_k, MAX_CAND); return WSEG_ERR_INVALID; }
-  int NL = gp->n_lanes > 1 ? gp->n_lanes : 1;
-  if (NL > n_windows) NL = n_windows;
-  const int share = (n_windows + NL - 1) / NL;                                               // even split of a short queue
-  const int S = gp->n_slots > 0 && gp->n_slots < share ? gp->n_slots : share;               // window slots per lane
+  const int S = gp->n_slots > 0 && gp->n_slots < n_windows ? gp->n_slots : n_windows;       // window slots
   Plan p;
   make_plan(m, S, nb, L, nullptr, p);
-  const size_t lane_bytes = p.total;                                                         // a multiple of 256
-  if (lane_bytes * NL + 256 > workspace_bytes) {
-    set_error("workspace too small: need %d x %zu + 256, have %zu", NL, lane_bytes, workspace_bytes); return WSEG_ERR_STATE;
-  }
-  while ((int)m->lanes.size() < NL) m->lanes.emplace_back(new Lane());
-  int dev = 0;
-  WSEG_HIP_CHECK(hipGetDevice(&dev));
-  for (int g = 0; g < NL; ++g) {
-    Lane& ln = *m->lanes[g];
-    ln.ev_used = 0; ln.ev_enc.clear(); ln.ev_ckv.clear();
-    if (!ln.ev_sync) WSEG_HIP_CHECK(hipEventCreateWithFlags(&ln.ev_sync, hipEventDisableTiming));
-    if (g > 0 && !ln.own_stream) WSEG_HIP_CHECK(hipStreamCreateWithFlags(&ln.own_stream, hipStreamNonBlocking));
-  }
+  if (p.total + 256 > workspace_bytes) { set_error("workspace too small: need %zu, have %zu", p.total + 256, workspace_bytes); return WSEG_ERR_STATE; }
+  Sched& sc = m->sched;
+  sc.ev_used = 0; sc.ev_enc.clear(); sc.ev_ckv.clear();
   m->timing_valid = false;
-  Lane& l0 = *m->lanes[0];
-  WSEG_TRY(timing_event(l0, s, &m->ev_total[0]));
-  if (NL > 1) {     // the other lanes start behind everything already queued on the caller's stream
-    WSEG_HIP_CHECK(hipEventRecord(l0.ev_sync, s));
-    for (int g = 1; g < NL; ++g) WSEG_HIP_CHECK(hipStreamWaitEvent(m->lanes[g]->own_stream, l0.ev_sync, 0));
-  }
-  WindowQueue wq;
-  wq.total = n_windows;
-  wq.lanes = NL;
-  char* base = aligned_base(workspace);
-  std::vector<int> rc(NL, WSEG_OK);
-  std::vector<std::string> err(NL);
-  std::vector<std::thread> threads;
-  for (int g = 1; g < NL; ++g)
-    threads.emplace_back([&, g]() {
-      if (hipSetDevice(dev) != hipSuccess) { wq.arrive(); rc[g] = WSEG_ERR_HIP; err[g] = "hipSetDevice failed in a lane thread"; return; }
-      rc[g] = generate_lane(m, *m->lanes[g], NL, feats, wq, gp, base + (size_t)g * lane_bytes, S, share, out_tokens, out_lengths,
-                            m->lanes[g]->own_stream);
-      if (rc[g] != WSEG_OK) err[g] = wseg_last_error();
-    });
-  rc[0] = generate_lane(m, l0, NL, feats, wq, gp, base, S, share, out_tokens, out_lengths, s);
-  if (rc[0] != WSEG_OK) err[0] = wseg_last_error();
-  for (std::thread& th : threads) th.join();
-  for (int g = 1; g < NL; ++g) {   // the caller's stream continues behind every lane
-    WSEG_HIP_CHECK(hipEventRecord(m->lanes[g]->ev_sync, m->lanes[g]->own_stream));
-    WSEG_HIP_CHECK(hipStreamWaitEvent(s, m->lanes[g]->ev_sync, 0));
-  }
-  for (int g = 0; g < NL; ++g)
-    if (rc[g] != WSEG_OK) { set_error("%s", err[g].c_str()); return rc[g]; }
-  WSEG_TRY(timing_event(l0, s, &m->ev_total[1]));
-  wseg_generate_stats& T = m->stats;
-  T = wseg_generate_stats();
-  T.n_windows = n_windows; T.n_slots = S * NL; T.n_lanes = NL;
-  for (int g = 0; g < NL; ++g) {
-    const wseg_generate_stats& a = m->lanes[g]->stats;
-    T.n_steps = a.n_steps > T.n_steps ? a.n_steps : T.n_steps;
-    T.n_admissions += a.n_admissions;
-    T.slot_steps_active += a.slot_steps_active; T.slot_steps_total += a.slot_steps_total;
-    T.queued_slot_steps_active += a.queued_slot_steps_active; T.queued_slot_steps_total += a.queued_slot_steps_total;
-  }
-  m->last_W = S; m->last_nb = nb; m->last_L = L; m->last_lanes = NL;
+  WSEG_TRY(timing_event(sc, s, &m->ev_total[0]));
+  WSEG_TRY(generate_windows(m, feats, n_windows, gp, aligned_base(workspace), S, out_tokens, out_lengths, s));
+  WSEG_TRY(timing_event(sc, s, &m->ev_total[1]));
+  m->last_W = S; m->last_nb = nb; m->last_L = L;
   m->timing_valid = true;
   return WSEG_OK;
 }
@@ -770,7 +680,7 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
 extern "C" int wseg_debug_first_logits(wseg_model* m, void* workspace, float* out, int32_t n_rows, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   if (!m || !workspace || !out || n_rows <= 0) { set_error("wseg_debug_first_logits: bad argument"); return WSEG_ERR_INVALID; }
-  if (m->last_W <= 0 || m->last_lanes != 1 || n_rows > m->last_W * m->last_nb || m->stats.n_windows > m->stats.n_slots) {
+  if (m->last_W <= 0 || n_rows > m->last_W * m->last_nb || m->stats.n_windows > m->stats.n_slots) {
     set_error("no matching wseg_generate call (all windows must have started together)"); return WSEG_ERR_STATE;
   }
   Plan p;
@@ -783,28 +693,21 @@ extern "C" int wseg_debug_first_logits(wseg_model* m, void* workspace, float* ou
 extern "C" int wseg_last_timing(const wseg_model* m, float out[4]) {
   if (!m || !out) { set_error("wseg_last_timing: null argument"); return WSEG_ERR_INVALID; }
   if (!m->timing_valid) { set_error("no completed wseg_generate call to time"); return WSEG_ERR_STATE; }
-  const std::vector<hipEvent_t>& pool0 = m->lanes[0]->ev_pool;
-  WSEG_HIP_CHECK(hipEventSynchronize(pool0[m->ev_total[1]]));
-  // Sum of the event pairs of every lane, divided by the lane count: with one lane the stage times add up to the call;
-  // with several lanes (which overlap in time) they are per-lane averages.
-  auto sum_pairs = [&](bool enc, float* acc) -> int {
+  const Sched& sc = m->sched;
+  WSEG_HIP_CHECK(hipEventSynchronize(sc.ev_pool[m->ev_total[1]]));
+  auto sum_pairs = [&](const std::vector<int>& v, float* acc) -> int {
     *acc = 0.f;
-    for (int g = 0; g < m->last_lanes; ++g) {
-      const Lane& ln = *m->lanes[g];
-      const std::vector<int>& v = enc ? ln.ev_enc : ln.ev_ckv;
-      for (size_t i = 0; i + 1 < v.size(); i += 2) {
-        float ms = 0.f;
-        WSEG_HIP_CHECK(hipEventElapsedTime(&ms, ln.ev_pool[v[i]], ln.ev_pool[v[i + 1]]));
-        *acc += ms;
-      }
+    for (size_t i = 0; i + 1 < v.size(); i += 2) {
+      float ms = 0.f;
+      WSEG_HIP_CHECK(hipEventElapsedTime(&ms, sc.ev_pool[v[i]], sc.ev_pool[v[i + 1]]));
+      *acc += ms;
     }
-    *acc /= (float)m->last_lanes;
     return WSEG_OK;
   };
   float total = 0.f;
-  WSEG_TRY(sum_pairs(true, &out[0]));
-  WSEG_TRY(sum_pairs(false, &out[1]));
-  WSEG_HIP_CHECK(hipEventElapsedTime(&total, pool0[m->ev_total[0]], pool0[m->ev_total[1]]));
+  WSEG_TRY(sum_pairs(sc.ev_enc, &out[0]));
+  WSEG_TRY(sum_pairs(sc.ev_ckv, &out[1]));
+  WSEG_HIP_CHECK(hipEventElapsedTime(&total, sc.ev_pool[m->ev_total[0]], sc.ev_pool[m->ev_total[1]]));
   out[2] = total - out[0] - out[1];
   out[3] = (float)m->stats.n_steps;
   return WSEG_OK;

@@ -70,8 +70,6 @@ DEFAULT_BEGIN_SUPPRESS_TOKENS = [220, 50257]
 # decode positions and 376 MiB at max_length 448 (self-attention cache for the longest allowed sequence), so pick_slots ends at
 # 1024 slots for short decodes and 512 for segment()'s default max_length on a 288 GB part.
 DEFAULT_SLOTS = 1024
-MAX_LANES = 4           # WSEG_MAX_LANES
-DEFAULT_MAX_LANES = 1   # lanes are equivalent to the same total slot count in one lane (profiles/README.md): off by default
 
 
 def _round_up(v, a):
@@ -280,35 +278,33 @@ class Engine:
         except Exception:
             pass
 
-    def _workspace(self, n_slots, num_beams, max_length, n_lanes=1):
+    def _workspace(self, n_slots, num_beams, max_length):
         need = self.lib.wseg_workspace_bytes(self.handle, n_slots, num_beams, max_length)
         if need == 0:
             raise _lib.WsegError("wseg_workspace_bytes rejected the request")
-        need *= max(1, n_lanes)
-        if self._ws is None or self._ws.numel() < need:
+        # grow when too small; give a much larger one back (a single long file must not pin ~100 GB for every later short call)
+        if self._ws is None or self._ws.numel() < need or (self._ws.numel() > 4 * need and self._ws.numel() > (2 << 30)):
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def pick_slots(self, n_windows, num_beams, max_length, n_slots=None, n_lanes=None):
-        """(slots per lane, lanes) for a generate call.  Slots: min(n_windows, cap) where cap is `n_slots`, else
-        $WSEG_SLOTS, else DEFAULT_SLOTS.  Lanes: `n_lanes`, else $WSEG_LANES, else as many full lanes as the queue fills, up
-        to DEFAULT_MAX_LANES (1: lanes measure the same as one lane with their total slot count).  Lanes are dropped,
-        then slots halved, until the workspace (whisperseg-large, 4 beams: 82 MiB of cross-K/V + 0.58 MiB of self-K/V per position + 16 MiB of
-        activations per slot)
-        fits in 80 % of the free device memory (plus what this engine's current workspace already holds)."""
+    def release_workspace(self):
+        """Free the decode workspace (it is re-allocated by the next call)."""
+        self._ws = None
+
+    def pick_slots(self, n_windows, num_beams, max_length, n_slots=None):
+        """Window slots for a generate call: min(n_windows, cap) where cap is `n_slots`, else $WSEG_SLOTS, else DEFAULT_SLOTS,
+        halved until the workspace (whisperseg-large, 4 beams, 16-bit modes: 82 MiB of cross-K/V + 0.58 MiB of self-K/V per
+        position + 16 MiB of activations per slot; twice that in the f32 / split-precision modes) fits in 80 % of the free
+        device memory (plus what this engine's current workspace already holds).  The reference bounds memory with
+        `batch_size`; here that role is played by `n_slots` / $WSEG_SLOTS (SegmenterBase.max_slots)."""
         cap = int(n_slots or os.environ.get("WSEG_SLOTS", 0) or DEFAULT_SLOTS)
         s = max(1, min(int(n_windows), cap))
-        lanes = int(n_lanes or os.environ.get("WSEG_LANES", 0) or min(DEFAULT_MAX_LANES, int(n_windows) // s))
-        lanes = max(1, lanes)            # (wseg_generate rejects more than WSEG_MAX_LANES and clamps to the window count)
         free, _ = torch.cuda.mem_get_info(self.device)
         budget = 0.8 * (free + (self._ws.numel() if self._ws is not None else 0))
-        need = lambda: lanes * self.lib.wseg_workspace_bytes(self.handle, s, num_beams, max_length)
-        while lanes > 1 and need() > budget:
-            lanes -= 1
-        while s > 1 and need() > budget:
+        while s > 1 and self.lib.wseg_workspace_bytes(self.handle, s, num_beams, max_length) > budget:
             s = (s + 1) // 2
-        return s, lanes
+        return s
 
     def encode(self, feats):
         """feats float32 device tensor [W, 80, 1000] -> [W, 500, d] in the model dtype (float32 in the split-precision modes)."""
@@ -323,20 +319,18 @@ class Engine:
 
     def generate(self, feats, prompt, eos_token_id, pad_token_id, max_length=448, num_beams=4, length_penalty=1.0,
                  suppress_tokens=(), begin_suppress_tokens=(), return_first_logits=False, n_slots=None, refill_min=0,
-                 lookahead=0, window_max_length=None, encoder_output=None, top_k=1, top_p=1.0, seed=0, n_lanes=None):
+                 lookahead=0, window_max_length=None, encoder_output=None, top_k=1, top_p=1.0, seed=0):
         """Greedy / beam-search decode of ALL windows of `feats` [N, 80, 1000] through `n_slots` window slots with
-        in-flight refill (a finished window's slot goes to the next queued window; wseg_generate), in `n_lanes` lanes of
-        `n_slots` slots that step side by side on separate streams (see pick_slots for the defaults).  `top_k` in 2..16 with
+        in-flight refill (a finished window's slot goes to the next queued window; wseg_generate; see pick_slots for the
+        default slot count).  `top_k` in 2..16 with
         num_beams == 1 samples (top-k, then nucleus `top_p`) with a counter-based generator keyed by `seed`.
         Returns (tokens int32 [N, max_length] on device, lengths int32 [N])."""
         feats = feats.to(device=self.device, dtype=torch.float32).contiguous()
         W = feats.shape[0]
         max_length = int(min(max_length, self.geo["dec_positions"]))
         with torch.cuda.device(self.device):
-            slots, lanes = self.pick_slots(W, num_beams, max_length, n_slots, n_lanes)
-            if return_first_logits:
-                lanes = 1
-            ws = self._workspace(slots, num_beams, max_length, lanes)
+            slots = self.pick_slots(W, num_beams, max_length, n_slots)
+            ws = self._workspace(slots, num_beams, max_length)
         sup = torch.tensor(list(suppress_tokens) or [0], dtype=torch.int32, device=self.device)
         bsup = torch.tensor(list(begin_suppress_tokens) or [0], dtype=torch.int32, device=self.device)
         gp = _lib.GenerateParams()
@@ -347,7 +341,7 @@ class Engine:
         gp.max_length, gp.num_beams, gp.length_penalty = max_length, int(num_beams), float(length_penalty)
         gp.suppress_tokens, gp.n_suppress = sup.data_ptr(), len(suppress_tokens)
         gp.begin_suppress_tokens, gp.n_begin_suppress = bsup.data_ptr(), len(begin_suppress_tokens)
-        gp.n_slots, gp.refill_min, gp.lookahead, gp.n_lanes = int(slots), int(refill_min), int(lookahead), int(lanes)
+        gp.n_slots, gp.refill_min, gp.lookahead = int(slots), int(refill_min), int(lookahead)
         gp.top_k, gp.top_p, gp.seed = int(top_k), float(top_p), int(seed) & (2 ** 64 - 1)      # sampling: num_beams == 1 and top_k > 1
         wml = None
         if window_max_length is not None:      # per-window total-length caps (int32 [W])
@@ -376,7 +370,7 @@ class Engine:
         return tokens, lengths
 
     def last_stats(self):
-        """Scheduler statistics of the last generate call: dict(n_windows, n_slots (all lanes), n_lanes, n_steps, n_admissions,
+        """Scheduler statistics of the last generate call: dict(n_windows, n_slots, n_steps, n_admissions,
         slot_steps_active, slot_steps_total, occupancy, steady_occupancy = occupancy while windows were still queued)."""
         st = _lib.GenerateStats()
         _lib.check(self.lib.wseg_last_stats(self.handle, C.byref(st)))

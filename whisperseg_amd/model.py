@@ -86,6 +86,10 @@ class SegmenterBase:
         self.default_segmentation_config = {}
         self.device_list = []
         self.suppress_tokens, self.begin_suppress_tokens = [], []
+        # Cap on the window slots the engine decodes concurrently (None: $WSEG_SLOTS, else 1024, halved until the workspace
+        # fits 80 % of the free device memory).  The reference bounds memory with `batch_size`; here `batch_size` no longer
+        # caps the concurrency, this attribute does.
+        self.max_slots = None
 
     # ---- slicing + features (reference model.py:127-166), batched on the first device ------------
     def get_sliced_audios_features(self, audio, sr, min_frequency, spec_time_step, num_trials):
@@ -182,7 +186,7 @@ class SegmenterBase:
             out.append(engine.generate(batch, prompt, tokenizer.eos_token_id, tokenizer.pad_token_id,
                                        max_length=max_length, num_beams=num_beams, length_penalty=length_penalty,
                                        suppress_tokens=self.suppress_tokens,
-                                       begin_suppress_tokens=self.begin_suppress_tokens, **sample))
+                                       begin_suppress_tokens=self.begin_suppress_tokens, n_slots=self.max_slots, **sample))
             if sample:
                 sample["seed"] += 1
             if status_monitor is not None:
