@@ -6,10 +6,16 @@
 // the min-fill follow reference model.py:138-161.
 //
 // Bound: HBM (algorithmic bytes per window = 4*win_len in + 4*n_mels*n_cols out); the FFT itself is
-// ~0.05 GFLOP/window.  Layout: one workgroup = FPB consecutive frames of one window; samples are read
-// coalesced (consecutive lanes -> consecutive samples), the packed real FFT (n_fft/2 complex points,
-// radix-2 in place) runs in LDS with the twiddle table staged in LDS once per workgroup, and the mel
-// projection walks each filter's contiguous non-zero bin range (sparse triangles, <= 2 filters per bin).
+// ~0.05 GFLOP/window.  Two STFT kernels write log10-mel values straight into the output image (no raw scratch) and the
+// window maximum / minimum into two ordered-uint words; a second pass clamps and normalises in place.
+//   logmel_fft256_kernel (n_fft = 512: every 16 / 32 kHz configuration of the reference): one WAVE per frame, the 256-point
+//     packed complex FFT as four radix-4 DIF stages on 4 points per lane — butterflies and twiddles in registers (packed
+//     fp32 math), three transposes through a 2-KB wave-private LDS buffer whose XOR swizzle makes every one of them
+//     bank-conflict free, no workgroup barrier until the 32 frames of a workgroup are written out as 128-byte rows.
+//   logmel_stft_kernel (any n_fft up to 8192): one workgroup = FPB consecutive frames, radix-2 in LDS with the twiddle table
+//     staged in LDS and a __syncthreads per stage (barrier-bound: 8 % of the HBM roof; kept for the rare wide FFTs).
+// Both project onto the mel filters through their contiguous non-zero bin ranges (sparse triangles, <= 2 filters per bin).
+#include <stdlib.h>
 #include "wseg_common.h"
 
 namespace wseg {
@@ -22,6 +28,18 @@ __device__ __forceinline__ float ord2f(uint32_t u) {
   return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
+constexpr int LM_FB = 32;          // frames per workgroup of the fast path (one 128-byte output row segment per filter)
+constexpr int LM_CH = 8;           // bins per mel work item
+constexpr int LM_MAX_ITEMS = 192;  // mel work items (filters cut into <= LM_CH-bin chunks; 80 slaney filters over 257 bins: ~110)
+// Mel work items of one filterbank: filter m = items cb[m] .. cb[m+1]-1, item n = bins k0[n] .. k0[n]+7 with zero-padded weights.
+// Built once per call by logmel_items_kernel (a few microseconds), copied into LDS by every workgroup of the fast path.
+struct LmTables {
+  int n_items;
+  int cb[97];
+  int k0[LM_MAX_ITEMS];
+  float w[LM_MAX_ITEMS][LM_CH];
+};
+
 struct LogmelArgs {
   wseg_logmel_desc d;
   const float* audio;
@@ -31,7 +49,8 @@ struct LogmelArgs {
   int32_t n_frames;   // floor(win_len / hop): frames kept after HF drops the last one
   int32_t fpb;        // frames per workgroup
   int32_t lg_nc;      // log2(n_fft / 2)
-  float* raw;         // [W][n_mels][n_frames] log10 mel
+  const struct LmTables* tables;   // mel work items of this filterbank (logmel_items_kernel), fast path only
+  float* out;         // [W][n_mels][n_cols]: log10 mel of the first n_cols frames (normalised in place by the finish kernel)
   uint32_t* stats;    // [W][2] ordered-uint (max over all frames, min over the first n_cols frames)
 };
 
@@ -123,9 +142,11 @@ __global__ __launch_bounds__(256) void logmel_stft_kernel(LogmelArgs a) {
     for (int k = 0; k < cnt; ++k) acc = fmaf(wt[k], p[k], acc);
     // mel floor: max(1e-10, x) then log10; log10(1e-10) is exactly -10 in the reference (float64 -> float32)
     const float v = acc > 1e-10f ? log10f(acc) : -10.0f;
-    a.raw[((size_t)w * n_mels + m) * a.n_frames + f] = v;
     lmax = fmaxf(lmax, v);
-    if (f < a.d.n_cols) lmin = fminf(lmin, v);
+    if (f < a.d.n_cols) {
+      a.out[((size_t)w * n_mels + m) * a.d.n_cols + f] = v;
+      lmin = fminf(lmin, v);
+    }
   }
   lmax = wave_max(lmax);
   lmin = -wave_max(-lmin);
@@ -135,21 +156,229 @@ __global__ __launch_bounds__(256) void logmel_stft_kernel(LogmelArgs a) {
   }
 }
 
-// out[w][m][c] = (max(raw, wmax - 8) + 4) / 4 ; columns >= n_frames take the window minimum
+// ------------------------------------------------------------------------------------------------------------------
+// n_fft = 512: wave-per-frame radix-4 FFT
+// ------------------------------------------------------------------------------------------------------------------
+typedef float cf2 __attribute__((ext_vector_type(2)));       // complex (re, im): adds / scalings compile to v_pk_*_f32
+__device__ __forceinline__ cf2 cmul(cf2 a, cf2 w) { return (cf2){a.x, a.x} * w + (cf2){-a.y, a.y} * (cf2){w.y, w.x}; }
+__device__ __forceinline__ cf2 mul_mi(cf2 a) { return (cf2){a.y, -a.x}; }      // a * (-i)
+// radix-4 DIF butterfly with W4 = -i:  y_j = sum_i a_i W4^(i j)
+__device__ __forceinline__ void bfly4(cf2 a[4]) {
+  const cf2 s02 = a[0] + a[2], d02 = a[0] - a[2], s13 = a[1] + a[3], d13 = mul_mi(a[1] - a[3]);
+  a[0] = s02 + s13; a[2] = s02 - s13; a[1] = d02 + d13; a[3] = d02 - d13;
+}
+// Swizzle of the 256-entry wave buffer (8-byte entries): every transpose below reads and writes 32 distinct bank pairs per
+// half wave (searched exhaustively over XOR swizzles of the base-4 digits; only the mirrored read of the unpack is 2-way).
+__device__ __forceinline__ int fsw(int a) { return a ^ ((((a >> 4) & 3) * 2) & 31) ^ ((((a >> 6) & 3) * 9) & 31) ^ ((((a >> 2) & 3) * 8) & 31); }
+__device__ __forceinline__ void wave_lds_sync() {      // this wave's LDS writes before its own later reads (other lanes' data)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(256) void logmel_items_kernel(wseg_logmel_desc d, LmTables* t) {
+  __shared__ int cb[97];
+  const int n_mels = d.n_mels;
+  if (threadIdx.x == 0) {
+    int n = 0;
+    for (int m = 0; m < n_mels; ++m) { cb[m] = n; n += (d.mel_count[m] + LM_CH - 1) / LM_CH; }
+    cb[n_mels] = n;
+    t->n_items = n;
+  }
+  __syncthreads();
+  for (int m = threadIdx.x; m <= n_mels; m += 256) t->cb[m] = cb[m];
+  for (int m = threadIdx.x; m < n_mels; m += 256) {
+    const int k0 = d.mel_start[m], cnt = d.mel_count[m], off = d.mel_offset[m];
+    for (int c = 0; c < cnt; c += LM_CH) {
+      const int n = cb[m] + c / LM_CH;
+      if (n >= LM_MAX_ITEMS) break;
+      t->k0[n] = k0 + c;
+      for (int u = 0; u < LM_CH; ++u) t->w[n][u] = c + u < cnt ? d.mel_weight[off + c + u] : 0.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void logmel_fft256_kernel(LogmelArgs a) {
+  constexpr int NC = 256;
+  __shared__ __attribute__((aligned(16))) cf2 s_z[4][NC];          // wave-private FFT buffers
+  __shared__ float s_pw[4][NC + 4 + LM_CH];                        // wave-private power spectra (257 bins + zero pad for whole items)
+  __shared__ float s_part[4][LM_MAX_ITEMS];                        // wave-private partial mel sums
+  __shared__ float s_tile[96][LM_FB + 1];                          // [filter][frame of the workgroup]
+  __shared__ __attribute__((aligned(16))) float s_w[LM_MAX_ITEMS][LM_CH];     // mel weights per item, zero padded
+  __shared__ int s_ik0[LM_MAX_ITEMS], s_cb[97];
+  __shared__ int s_nitems;
+  __shared__ cf2 s_tw[NC];                                         // e^{-2 pi i k / 512}: unpack twiddles
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int w = blockIdx.y, f0 = blockIdx.x * LM_FB;
+  const int n_mels = a.d.n_mels, hop = a.d.hop;
+  const int64_t wstart = a.win_start[w], L = a.win_len;
+
+  // ---- per-workgroup copy of the mel work-item tables ----
+  if (tid == 0) s_nitems = a.tables->n_items;
+  for (int i = tid; i <= n_mels; i += 256) s_cb[i] = a.tables->cb[i];
+  for (int i = tid; i < LM_MAX_ITEMS; i += 256) s_ik0[i] = a.tables->k0[i];
+  for (int i = tid; i < LM_MAX_ITEMS * LM_CH / 4; i += 256) ((float4*)&s_w[0][0])[i] = ((const float4*)&a.tables->w[0][0])[i];
+  __syncthreads();
+  const int n_items = s_nitems;
+  s_tw[tid] = ((const cf2*)a.d.twiddle)[tid];
+  for (int i = tid; i < 4 * (4 + LM_CH); i += 256) s_pw[i / (4 + LM_CH)][NC + i % (4 + LM_CH)] = 0.f;      // pad stays zero
+  // ---- per-lane constants: window, twiddles ----
+  const cf2* twt = (const cf2*)a.d.twiddle;                    // e^{-2 pi i k / 512}, k < 256
+  auto tw512 = [&](int k) -> cf2 { const cf2 t = twt[k & 255]; return (k & 256) ? -t : t; };
+  cf2 win[4], w1[3], w2[3], w3[3];
+  const int r16 = lane & 15, r4 = lane & 3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = lane + 64 * i;
+    win[i] = (cf2){a.d.window[2 * n], a.d.window[2 * n + 1]};
+  }
+#pragma unroll
+  for (int j = 1; j < 4; ++j) { w1[j - 1] = tw512(2 * j * lane); w2[j - 1] = tw512(8 * j * r16); w3[j - 1] = tw512(32 * j * r4); }
+  __syncthreads();
+
+  cf2* zb = s_z[wave];
+  float* pw = s_pw[wave];
+  float lmax = -3.0e38f, lmin = 3.0e38f;
+  for (int fi = 0; fi < LM_FB / 4; ++fi) {
+    const int fr = wave * (LM_FB / 4) + fi, f = f0 + fr;       // wave-uniform
+    if (f >= a.n_frames) break;
+    // ---- A. load + window: z[n] = x[2n] + i x[2n+1], n = lane + 64 i ----
+    cf2 v[4];
+    const int64_t base = (int64_t)f * hop - NC;                // window-local index of sample 0 of the frame
+    const int64_t abase = wstart + base;
+    if (base >= 0 && base + 2 * NC <= L && abase >= 0 && abase + 2 * NC <= a.n_audio) {      // wave-uniform: the frame is interior
+      typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+      const float* src = a.audio + abase + 2 * lane;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const f2u t = *(const f2u*)(src + 128 * i); v[i] = (cf2){t.x, t.y} * win[i]; }
+    } else
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float xs[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        int64_t jl = base + 2 * (lane + 64 * i) + q;
+        if (jl < 0) jl = -jl;                                  // reflect (np.pad mode="reflect")
+        if (jl >= L) jl = 2 * (L - 1) - jl;
+        const int64_t ai = wstart + jl;
+        xs[q] = (ai >= 0 && ai < a.n_audio) ? a.audio[ai] : 0.f;
+      }
+      v[i] = (cf2){xs[0], xs[1]} * win[i];
+    }
+    // ---- B. 256-point FFT: stage 1 (stride 64, in registers) ----
+    bfly4(v);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) v[j] = cmul(v[j], w1[j - 1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) zb[fsw(j * 64 + lane)] = v[j];
+    wave_lds_sync();
+    // stage 2 (stride 16): lane = (j' = lane >> 4, r = lane & 15)
+    const int g1 = (lane >> 4) * 64;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = zb[fsw(g1 + r16 + 16 * q)];
+    bfly4(v);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) v[j] = cmul(v[j], w2[j - 1]);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) zb[fsw(g1 + j * 16 + r16)] = v[j];
+    wave_lds_sync();
+    // stage 3 (stride 4): lane = (j', j2 = (lane >> 2) & 3, r3 = lane & 3)
+    const int g2 = g1 + ((lane >> 2) & 3) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = zb[fsw(g2 + r4 + 4 * q)];
+    bfly4(v);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) v[j] = cmul(v[j], w3[j - 1]);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) zb[fsw(g2 + j * 4 + r4)] = v[j];
+    wave_lds_sync();
+    // stage 4: lane = (j', j2, j3' = lane & 3) holds the four points of one 4-point FFT
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = zb[fsw(g2 + r4 * 4 + q)];
+    bfly4(v);
+    wave_lds_sync();
+    // natural order: k = j' + 4 j2 + 16 j3' + 64 j4
+    const int k0 = (lane >> 4) + 4 * ((lane >> 2) & 3) + 16 * r4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) zb[fsw(k0 + 64 * j)] = v[j];
+    wave_lds_sync();
+    // ---- C. unpack the real FFT, |X[k]|^2 for k = lane + 64 i (and k = 256 in lane 0) ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = lane + 64 * i;
+      const cf2 zk = zb[fsw(k)], zm = zb[fsw((NC - k) & (NC - 1))];
+      const cf2 e = (cf2){0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y)};        // E = (Z[k] + conj Z[nc-k]) / 2
+      const cf2 o = (cf2){0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x)};       // O = (Z[k] - conj Z[nc-k]) / (2i)
+      const cf2 x = e + cmul(o, s_tw[k]);
+      pw[k] = x.x * x.x + x.y * x.y;
+      if (k == 0) { const cf2 z0 = zk; const float xn = z0.x - z0.y; pw[NC] = xn * xn; }   // X[256] = Re Z[0] - Im Z[0]
+    }
+    wave_lds_sync();
+    // ---- D. mel projection: items of <= LM_CH bins, then each filter sums its items in order ----
+    for (int it = lane; it < n_items; it += 64) {
+      const int kk = s_ik0[it];
+      const float4 wa = *(const float4*)&s_w[it][0], wb = *(const float4*)&s_w[it][4];
+      const float* pp = pw + kk;
+      float acc = wa.x * pp[0];
+      acc = fmaf(wa.y, pp[1], acc); acc = fmaf(wa.z, pp[2], acc); acc = fmaf(wa.w, pp[3], acc);
+      acc = fmaf(wb.x, pp[4], acc); acc = fmaf(wb.y, pp[5], acc); acc = fmaf(wb.z, pp[6], acc); acc = fmaf(wb.w, pp[7], acc);
+      s_part[wave][it] = acc;
+    }
+    wave_lds_sync();
+    for (int m = lane; m < n_mels; m += 64) {
+      float acc = 0.f;
+      for (int c = s_cb[m]; c < s_cb[m + 1]; ++c) acc += s_part[wave][c];
+      // mel floor: max(1e-10, x) then log10; log10(1e-10) is exactly -10 in the reference (float64 -> float32)
+      const float val = acc > 1e-10f ? __log2f(acc) * 0.30102999566398120f : -10.0f;      // v_log_f32: ~1 ulp of log2
+      s_tile[m][fr] = val;
+      lmax = fmaxf(lmax, val);
+      if (f < a.d.n_cols) lmin = fminf(lmin, val);
+    }
+    wave_lds_sync();
+  }
+  lmax = wave_max(lmax);
+  lmin = -wave_max(-lmin);
+  if (lane == 0) {
+    if (lmax > -1.0e38f) atomicMax(&a.stats[2 * w + 0], f2ord(lmax));
+    if (lmin < 1.0e38f) atomicMin(&a.stats[2 * w + 1], f2ord(lmin));
+  }
+  __syncthreads();
+  // ---- E. 32 consecutive frames of every filter = one 128-byte row segment of the output image ----
+  const int n_valid = min(min(a.n_frames, a.d.n_cols) - f0, LM_FB);
+  for (int idx = tid; idx < n_mels * LM_FB; idx += 256) {
+    const int m = idx / LM_FB, fr = idx - m * LM_FB;
+    if (fr < n_valid) a.out[((size_t)w * n_mels + m) * a.d.n_cols + f0 + fr] = s_tile[m][fr];
+  }
+}
+
+// out[w][m][c] = (max(out, wmax - 8) + 4) / 4 in place; columns >= n_frames take the window minimum
 // (reference model.py:155-161).
-__global__ __launch_bounds__(256) void logmel_finish_kernel(const float* __restrict__ raw, const uint32_t* __restrict__ stats,
-                                                            float* __restrict__ out, int n_mels, int n_frames, int n_cols) {
+__global__ __launch_bounds__(256) void logmel_finish_kernel(const uint32_t* __restrict__ stats, float* __restrict__ out, int n_mels,
+                                                            int n_frames, int n_cols) {
   const int w = blockIdx.y;
   const float wmax = ord2f(stats[2 * w + 0]);
   const uint32_t mn = stats[2 * w + 1];
   const float floorv = wmax - 8.0f;
   const float fill = (n_frames > 0 && mn != 0xffffffffu) ? (fmaxf(ord2f(mn), floorv) + 4.0f) / 4.0f : 0.f;
   const int total = n_mels * n_cols;
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
-    const int m = idx / n_cols, c = idx - m * n_cols;
-    float v = fill;
-    if (c < n_frames) v = (fmaxf(raw[((size_t)w * n_mels + m) * n_frames + c], floorv) + 4.0f) / 4.0f;
-    out[(size_t)w * total + idx] = v;
+  float* o = out + (size_t)w * total;
+  if ((n_cols & 3) == 0) {                      // 16-byte accesses: a 4-column group never straddles a row
+    for (int idx = (blockIdx.x * 256 + threadIdx.x) * 4; idx < total; idx += gridDim.x * 1024) {
+      const int c = idx % n_cols;
+      float4 v = *(const float4*)(o + idx);
+      v.x = c + 0 < n_frames ? (fmaxf(v.x, floorv) + 4.0f) / 4.0f : fill;
+      v.y = c + 1 < n_frames ? (fmaxf(v.y, floorv) + 4.0f) / 4.0f : fill;
+      v.z = c + 2 < n_frames ? (fmaxf(v.z, floorv) + 4.0f) / 4.0f : fill;
+      v.w = c + 3 < n_frames ? (fmaxf(v.w, floorv) + 4.0f) / 4.0f : fill;
+      *(float4*)(o + idx) = v;
+    }
+  } else {
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+      const int c = idx % n_cols;
+      o[idx] = c < n_frames ? (fmaxf(o[idx], floorv) + 4.0f) / 4.0f : fill;
+    }
   }
 }
 
@@ -164,8 +393,9 @@ using namespace wseg;
 
 extern "C" size_t wseg_logmel_scratch_bytes(const wseg_logmel_desc* d, int32_t n_windows, int64_t win_len) {
   if (!d || d->hop <= 0 || n_windows <= 0) return 0;
-  const int64_t nf = win_len / d->hop;
-  return align_up((size_t)n_windows * d->n_mels * (size_t)nf * sizeof(float), 256) + align_up((size_t)n_windows * 8, 256);
+  (void)win_len;
+  // two ordered-uint words per window (max / min) + the mel work-item tables of the fast path; no raw spectrum any more
+  return align_up((size_t)n_windows * 8, 256) + align_up(sizeof(LmTables), 256);
 }
 
 extern "C" int wseg_logmel_f32(const wseg_logmel_desc* d, const float* audio, int64_t n_audio,
@@ -190,8 +420,9 @@ extern "C" int wseg_logmel_f32(const wseg_logmel_desc* d, const float* audio, in
   a.n_frames = (int32_t)nf64;
   a.fpb = frames_per_block(d->n_fft);
   a.lg_nc = lg - 1;
-  a.raw = (float*)scratch;
-  a.stats = (uint32_t*)((char*)scratch + align_up((size_t)n_windows * d->n_mels * (size_t)nf64 * sizeof(float), 256));
+  a.out = out;
+  a.stats = (uint32_t*)scratch;
+  a.tables = (const LmTables*)((char*)scratch + align_up((size_t)n_windows * 8, 256));
   // stats: max = lowest ordered value (0), min = highest (0xffffffff)
   WSEG_HIP_CHECK(hipMemsetAsync(a.stats, 0, (size_t)n_windows * 8, stream));
   {
@@ -200,7 +431,14 @@ extern "C" int wseg_logmel_f32(const wseg_logmel_desc* d, const float* audio, in
   }
   const int nc = d->n_fft / 2;
   const size_t smem = (size_t)nc * 8 + (size_t)a.fpb * nc * 8 + (size_t)a.fpb * (nc + 1) * 4;
-  if (a.n_frames > 0) {
+  static const bool generic_only = getenv("WSEG_LOGMEL_GENERIC") != nullptr;       // A/B + test knob
+  bool fast_ok = d->n_fft == 512 && d->n_mels <= 96 && !generic_only;
+  if (a.n_frames > 0 && fast_ok) {
+    dim3 grid(cdiv(a.n_frames, LM_FB), n_windows);
+    hipLaunchKernelGGL(logmel_items_kernel, dim3(1), dim3(256), 0, stream, *d, (LmTables*)a.tables);
+    hipLaunchKernelGGL(logmel_fft256_kernel, grid, dim3(256), 0, stream, a);
+    WSEG_LAUNCH_CHECK();
+  } else if (a.n_frames > 0) {
     dim3 grid(cdiv(a.n_frames, a.fpb), n_windows);
     // the function attribute is per device (thread-per-device mode, reference model.py:173-184): set once for each
     static bool attr_set[64] = {};
@@ -216,7 +454,7 @@ extern "C" int wseg_logmel_f32(const wseg_logmel_desc* d, const float* audio, in
   {
     const int total = d->n_mels * d->n_cols;
     dim3 grid(cdiv(total, 256 * 4), n_windows);
-    hipLaunchKernelGGL(logmel_finish_kernel, grid, dim3(256), 0, stream, a.raw, a.stats, out, d->n_mels, a.n_frames, d->n_cols);
+    hipLaunchKernelGGL(logmel_finish_kernel, grid, dim3(256), 0, stream, a.stats, out, d->n_mels, a.n_frames, d->n_cols);
     WSEG_LAUNCH_CHECK();
   }
   return WSEG_OK;
