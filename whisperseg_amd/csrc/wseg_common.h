@@ -116,11 +116,12 @@ template <> struct El<float> {
 template <typename HT> struct X3 {};
 struct f16_t;
 // P: plain parameter / cache type; H: 16-bit MFMA operand type; A: storage type of the ENCODER self-attention's Q / K / V^T.
-// Split-precision modes run the encoder attention on the IEEE-half matrix cores (fp32 softmax statistics): rounding Q, K, V and
-// P to half leaves the 200-recording parity sweep untouched (tools/precision_study.py: "gemm=bf16x3,eattn=f16" 200 / 200, the
-// attention output averages hundreds of independently rounded terms) at a tenth of the fp32-MFMA kernel's time, whereas the
-// decoder's cross-attention K / V must keep >= 16 mantissa bits ("ckv=f16": 188 / 200) and stay fp32.  EpiParams::qkv_f32
-// (WSEG_X3_ENC_ATTN=f32) selects the fp32 attention kernel instead.
+// Split-precision modes run the encoder attention on the IEEE-half matrix cores with fp32 softmax statistics — by default with
+// Q, K, V^T and P as half hi + lo pairs and three MFMAs per product like the GEMMs (first-step logits within 5e-5 of the exact
+// mode at 32 layers; plain half operands: 4e-4, which is what leaves the parity sweep untouched too — tools/precision_study.py
+// "gemm=bf16x3,eattn=f16" 200 / 200 — but would make the attention the mode's largest error by 10x), whereas the decoder's
+// cross-attention K / V must keep >= 16 mantissa bits ("ckv=f16": 188 / 200) and stay fp32.  WSEG_X3_ENC_ATTN=f16 | f32
+// selects plain half / the fp32-MFMA kernel (EpiParams::qkv_mode).
 template <typename T> struct IO { typedef T P; typedef T H; typedef T A; static constexpr bool split = false; };
 template <typename HT> struct IO<X3<HT>> { typedef float P; typedef HT H; typedef f16_t A; static constexpr bool split = true; };
 

@@ -135,15 +135,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // register-prefetched K chunks were spilled to scratch directly behind their loads (PMC WRITE_SIZE showed 3.9x the
 // algorithmic output bytes); with K prefetched by LDS-DMA instead the kernel has no scratch: 767 -> 571 us per layer.
 // TO: tag of the output, the o-proj GEMM's operand (HT, or X3<..>: hi | lo rows in the split-precision modes)
-template <typename HT, typename TO>
-__global__ __launch_bounds__(256, 4) void enc_attention_h16_kernel(const HT* __restrict__ Q, const HT* __restrict__ K,
+// SPLIT (split-precision modes): Q, K and V^T arrive as hi + lo planes (`plane` elements apart), the probabilities are split in
+// registers, and both products take three MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulation): S^T = K Q^T and O^T = V^T P^T
+// to ~22 operand bits instead of 11.  Twice the LDS tiles and ~40 more registers: 3 workgroups per CU instead of 4.
+template <typename HT, typename TO, bool SPLIT = false>
+__global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(const HT* __restrict__ Q, const HT* __restrict__ K,
                                                                 const HT* __restrict__ Vt, void* __restrict__ out,
-                                                                 int H, int T, int Tp, int d) {
+                                                                 int H, int T, int Tp, int d, size_t plane) {
   // [key][64 hd], 16-B slots XOR ((key >> 1) & 7): a 32-row MFMA fragment read (lane = row + 32*half) is serviced in the
   // lane groups {0-3,12-15,20-27}, ... and needs 16 distinct (row & 1, slot) pairs per group — XOR (key & 7), right for
   // 16-row fragments, was 2-way conflicted here (SQ_LDS_BANK_CONFLICT 44 % of LDS cycles)
   __shared__ __attribute__((aligned(16))) HT sK[2][64 * 64];   // double-buffered: filled by LDS-DMA, no registers in between
   __shared__ __attribute__((aligned(16))) HT sV[64 * 64];   // [hd][64 keys], 8-B granules XOR ((hd >> 1) & 15)
+  __shared__ __attribute__((aligned(16))) HT sKl[SPLIT ? 2 : 1][SPLIT ? 64 * 64 : 8];      // lo planes (SPLIT)
+  __shared__ __attribute__((aligned(16))) HT sVl[SPLIT ? 64 * 64 : 8];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
@@ -153,9 +158,13 @@ __global__ __launch_bounds__(256, 4) void enc_attention_h16_kernel(const HT* __r
   const HT* Kb = K + (size_t)bh * Tp * 64;
   const HT* Vb = Vt + (size_t)bh * 64 * Tp;
 
-  bf16x8 qf[4];
+  bf16x8 qf[4], qfl[SPLIT ? 4 : 1];
 #pragma unroll
   for (int hs = 0; hs < 4; ++hs) qf[hs] = *(const bf16x8*)(Qb + (size_t)(q0 + qi) * 64 + hs * 16 + g2 * 8);
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int hs = 0; hs < 4; ++hs) qfl[hs] = *(const bf16x8*)(Qb + plane + (size_t)(q0 + qi) * 64 + hs * 16 + g2 * 8);
+  }
 
   f32x16 o0, o1;
 #pragma unroll
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(256, 4) void enc_attention_h16_kernel(const HT* __r
   // swizzle is applied on the source side: LDS slot c holds global slot (c & 7) ^ ((row >> 1) & 7) of its row), V^T into 8
   // registers (its 8-byte-granule swizzle is finer than a DMA element).  Keeping the K chunks in registers as well made the
   // compiler spill them right behind their loads (a scratch store that waits for the load: the prefetch was serialised).
-  uint4 v0, v1;
+  uint4 v0, v1, v0l, v1l;
   // V^T row of this thread's two chunks: rows 4j + {0, 2, 1, 3} for consecutive 8-lane groups, so that the two rows sharing a
   // 16-lane ds_write_b64 group have swizzles of different parity (rows 2k and 2k + 1 share theirs and collided 2-way)
   const int vrow = ((tid >> 3) & ~3) | (((tid >> 3) & 1) << 1) | (((tid >> 3) >> 1) & 1);
@@ -180,11 +189,18 @@ __global__ __launch_bounds__(256, 4) void enc_attention_h16_kernel(const HT* __r
       const int c = tid + i * 256, row = c >> 3, sl = (c & 7) ^ ((row >> 1) & 7);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + row * 64 + sl * 8),
                                        (__attribute__((address_space(3))) void*)(kdst + (i * 256 + wave * 64) * 8), 16, 0, 0);
+      if constexpr (SPLIT)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + plane + row * 64 + sl * 8),
+                                         (__attribute__((address_space(3))) void*)(sKl[kt & 1] + (i * 256 + wave * 64) * 8), 16, 0, 0);
     }
     {
       const int r0 = vrow, sl = tid & 7;
       v0 = *(const uint4*)(Vb + (size_t)r0 * Tp + kt * 64 + sl * 8);
       v1 = *(const uint4*)(Vb + (size_t)(r0 + 32) * Tp + kt * 64 + sl * 8);
+      if constexpr (SPLIT) {
+        v0l = *(const uint4*)(Vb + plane + (size_t)r0 * Tp + kt * 64 + sl * 8);
+        v1l = *(const uint4*)(Vb + plane + (size_t)(r0 + 32) * Tp + kt * 64 + sl * 8);
+      }
     }
   };
   fetch(0);
@@ -200,6 +216,11 @@ __global__ __launch_bounds__(256, 4) void enc_attention_h16_kernel(const HT* __r
         const uint4 vv = i == 0 ? v0 : v1;
         *(uint2*)(sV + row * 64 + (((2 * sl) ^ sw) << 2)) = make_uint2(vv.x, vv.y);
         *(uint2*)(sV + row * 64 + (((2 * sl + 1) ^ sw) << 2)) = make_uint2(vv.z, vv.w);
+        if constexpr (SPLIT) {
+          const uint4 vl = i == 0 ? v0l : v1l;
+          *(uint2*)(sVl + row * 64 + (((2 * sl) ^ sw) << 2)) = make_uint2(vl.x, vl.y);
+          *(uint2*)(sVl + row * 64 + (((2 * sl + 1) ^ sw) << 2)) = make_uint2(vl.z, vl.w);
+        }
       }
     }
     __syncthreads();
@@ -217,6 +238,11 @@ __global__ __launch_bounds__(256, 4) void enc_attention_h16_kernel(const HT* __r
       for (int hs = 0; hs < 4; ++hs) {
         const bf16x8 kf = *(const bf16x8*)(cK + krow * 64 + (((hs * 2 + g2) ^ ((krow >> 1) & 7)) << 3));
         s = H16<HT>::mfma32(kf, qf[hs], s);
+        if constexpr (SPLIT) {
+          const bf16x8 kfl = *(const bf16x8*)(sKl[kt & 1] + krow * 64 + (((hs * 2 + g2) ^ ((krow >> 1) & 7)) << 3));
+          s = H16<HT>::mfma32(kf, qfl[hs], s);
+          s = H16<HT>::mfma32(kfl, qf[hs], s);
+        }
       }
       if (key_base + 32 > T) {
 #pragma unroll
@@ -245,18 +271,29 @@ __global__ __launch_bounds__(256, 4) void enc_attention_h16_kernel(const HT* __r
       // keys 16*mm + 4*g2 + {0,1,2,3, 8,9,10,11}  == registers 8*mm .. 8*mm+7 of s.
 #pragma unroll
       for (int mm = 0; mm < 2; ++mm) {
-        union { bf16x8 v; uint32_t u[4]; } pf;
+        union { bf16x8 v; uint32_t u[4]; } pf, pfl;
 #pragma unroll
         for (int j = 0; j < 4; ++j) pf.u[j] = H16<HT>::pack(s[8 * mm + 2 * j], s[8 * mm + 2 * j + 1]);
+        if constexpr (SPLIT) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            pfl.u[j] = H16<HT>::pack(s[8 * mm + 2 * j] - H16<HT>::lo(pf.u[j]), s[8 * mm + 2 * j + 1] - H16<HT>::hi(pf.u[j]));
+        }
         const int gran = sub * 8 + 4 * mm + g2;
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht) {
           const int hd = ht * 32 + qi, sw = (hd >> 1) & 15;
-          union { bf16x8 v; uint2 u[2]; } vf;
+          union { bf16x8 v; uint2 u[2]; } vf, vfl;
           vf.u[0] = *(const uint2*)(sV + hd * 64 + ((gran ^ sw) << 2));
           vf.u[1] = *(const uint2*)(sV + hd * 64 + (((gran + 2) ^ sw) << 2));
           if (ht == 0) o0 = H16<HT>::mfma32(vf.v, pf.v, o0);
           else o1 = H16<HT>::mfma32(vf.v, pf.v, o1);
+          if constexpr (SPLIT) {
+            vfl.u[0] = *(const uint2*)(sVl + hd * 64 + ((gran ^ sw) << 2));
+            vfl.u[1] = *(const uint2*)(sVl + hd * 64 + (((gran + 2) ^ sw) << 2));
+            if (ht == 0) { o0 = H16<HT>::mfma32(vf.v, pfl.v, o0); o0 = H16<HT>::mfma32(vfl.v, pf.v, o0); }
+            else { o1 = H16<HT>::mfma32(vf.v, pfl.v, o1); o1 = H16<HT>::mfma32(vfl.v, pf.v, o1); }
+          }
         }
       }
     }
@@ -428,8 +465,9 @@ __global__ __launch_bounds__(256) void enc_attention_f32_mfma_kernel(const float
 // ------------------------------------------------------------------------------------------------
 static bool is_x3(int dtype) { return dtype == WSEG_BF16X3 || dtype == WSEG_F16X3; }
 // attribution knob (tools/parity_sweep.py, profiles/): fp32-MFMA encoder attention in the split-precision modes
-bool x3_enc_attention_f32() {
-  static const bool v = getenv("WSEG_X3_ENC_ATTN") && !strcmp(getenv("WSEG_X3_ENC_ATTN"), "f32");
+int x3_enc_attention_mode() {
+  static const char* e = getenv("WSEG_X3_ENC_ATTN");
+  static const int v = !e ? 2 : (!strcmp(e, "f32") ? 1 : (!strcmp(e, "f16") ? 0 : 2));
   return v;
 }
 
@@ -538,14 +576,16 @@ static void launch_enc_attention_f32(const void* q, const void* k, const void* v
 int launch_enc_attention(int dtype, const void* q, const void* k, const void* vt, void* out,
                          int B, int H, int T, int Tp, int d, hipStream_t s) {
   const bool x3 = is_x3(dtype);
-  if (dtype == WSEG_BF16 || dtype == WSEG_F16 || (x3 && !x3_enc_attention_f32())) {
+  const int mode = x3 ? x3_enc_attention_mode() : 0;
+  if (dtype == WSEG_BF16 || dtype == WSEG_F16 || (x3 && mode != 1)) {
     if (Tp % 128) { set_error("enc_attention: Tp %d %% 128", Tp); return WSEG_ERR_INVALID; }
     dim3 grid(cdiv(T, 128), B * H);
-#define WSEG_EA(HT_, TO_) hipLaunchKernelGGL((enc_attention_h16_kernel<HT_, TO_>), grid, dim3(256), 0, s, (const HT_*)q, (const HT_*)k, (const HT_*)vt, out, H, T, Tp, d)
-    if (dtype == WSEG_BF16) WSEG_EA(bf16_t, bf16_t);
-    else if (dtype == WSEG_F16) WSEG_EA(f16_t, f16_t);
-    else if (dtype == WSEG_BF16X3) WSEG_EA(f16_t, X3<bf16_t>);       // IEEE-half Q / K / V^T (IO<X3<..>>::A) in both split modes
-    else WSEG_EA(f16_t, X3<f16_t>);
+    const size_t plane = (size_t)B * H * Tp * 64;
+#define WSEG_EA(HT_, TO_, SP_) hipLaunchKernelGGL((enc_attention_h16_kernel<HT_, TO_, SP_>), grid, dim3(256), 0, s, (const HT_*)q, (const HT_*)k, (const HT_*)vt, out, H, T, Tp, d, plane)
+    if (dtype == WSEG_BF16) WSEG_EA(bf16_t, bf16_t, false);
+    else if (dtype == WSEG_F16) WSEG_EA(f16_t, f16_t, false);
+    else if (dtype == WSEG_BF16X3) { if (mode == 2) WSEG_EA(f16_t, X3<bf16_t>, true); else WSEG_EA(f16_t, X3<bf16_t>, false); }   // IEEE-half
+    else { if (mode == 2) WSEG_EA(f16_t, X3<f16_t>, true); else WSEG_EA(f16_t, X3<f16_t>, false); }    // Q / K / V^T in both split modes
 #undef WSEG_EA
   } else if (dtype == WSEG_BF16X3) launch_enc_attention_f32<X3<bf16_t>>(q, k, vt, out, B, H, T, Tp, d, s);
   else if (dtype == WSEG_F16X3) launch_enc_attention_f32<X3<f16_t>>(q, k, vt, out, B, H, T, Tp, d, s);

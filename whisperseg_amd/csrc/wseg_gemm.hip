@@ -82,18 +82,27 @@ __device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, fl
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] *= ep.scale;
     }
-    auto put = [&](auto* base) {
+    auto put = [&](auto* base, size_t plane, const float* x) {
       typedef std::remove_pointer_t<decltype(base)> QT;
-      if (sec == 0) Vec4<QT>::st((QT*)ep.q + (bh * ep.t_pad + t) * 64 + e, v);
-      else if (sec == 1) Vec4<QT>::st((QT*)ep.k + (bh * ep.t_pad + t) * 64 + e, v);
+      if (sec == 0) Vec4<QT>::st((QT*)ep.q + plane + (bh * ep.t_pad + t) * 64 + e, x);
+      else if (sec == 1) Vec4<QT>::st((QT*)ep.k + plane + (bh * ep.t_pad + t) * 64 + e, x);
       else {
-        QT* vt = (QT*)ep.v + (bh * 64 + e) * ep.t_pad + t;
+        QT* vt = (QT*)ep.v + plane + (bh * 64 + e) * ep.t_pad + t;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) El<QT>::st(vt + (size_t)i * ep.t_pad, v[i]);
+        for (int i = 0; i < 4; ++i) El<QT>::st(vt + (size_t)i * ep.t_pad, x[i]);
       }
     };
-    if (IO<T>::split && ep.qkv_f32) put((float*)nullptr);
-    else put((typename IO<T>::A*)nullptr);
+    typedef typename IO<T>::A AT;
+    if (IO<T>::split && ep.qkv_mode == 1) put((float*)nullptr, 0, v);
+    else {
+      put((AT*)nullptr, 0, v);
+      if (IO<T>::split && ep.qkv_mode == 2) {      // lo plane: x - rn(x)
+        float lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lo[i] = v[i] - El<AT>::rnd(v[i]);
+        put((AT*)nullptr, ep.qkv_plane, lo);
+      }
+    }
   } else if constexpr (EPI == EPI_KV_CROSS) {
     const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
     const int b = m / ep.t_len, t = m - b * ep.t_len;
@@ -175,18 +184,27 @@ __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, f
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] *= ep.scale;
     }
-    auto put = [&](auto* base) {
+    auto put = [&](auto* base, size_t plane, const float* x) {
       typedef std::remove_pointer_t<decltype(base)> QT;
-      if (sec == 0) st8_h<QT>((QT*)ep.q + (bh * ep.t_pad + t) * 64 + e, v);
-      else if (sec == 1) st8_h<QT>((QT*)ep.k + (bh * ep.t_pad + t) * 64 + e, v);
+      if (sec == 0) st8_h<QT>((QT*)ep.q + plane + (bh * ep.t_pad + t) * 64 + e, x);
+      else if (sec == 1) st8_h<QT>((QT*)ep.k + plane + (bh * ep.t_pad + t) * 64 + e, x);
       else {
-        QT* vt = (QT*)ep.v + (bh * 64 + e) * ep.t_pad + t;
+        QT* vt = (QT*)ep.v + plane + (bh * 64 + e) * ep.t_pad + t;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) El<QT>::st(vt + (size_t)i * ep.t_pad, v[i]);
+        for (int i = 0; i < 8; ++i) El<QT>::st(vt + (size_t)i * ep.t_pad, x[i]);
       }
     };
-    if (IO<T>::split && ep.qkv_f32) put((float*)nullptr);
-    else put((typename IO<T>::A*)nullptr);
+    typedef typename IO<T>::A AT;
+    if (IO<T>::split && ep.qkv_mode == 1) put((float*)nullptr, 0, v);
+    else {
+      put((AT*)nullptr, 0, v);
+      if (IO<T>::split && ep.qkv_mode == 2) {      // lo plane: x - rn(x)
+        float lo[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lo[i] = v[i] - El<AT>::rnd(v[i]);
+        put((AT*)nullptr, ep.qkv_plane, lo);
+      }
+    }
   } else if constexpr (EPI == EPI_KV_CROSS) {
     const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
     const int b = m / ep.t_len, t = m - b * ep.t_len;

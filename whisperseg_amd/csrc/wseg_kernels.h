@@ -40,7 +40,9 @@ struct EpiParams {
   int pos_div = 1;               // rows (beams) per slot
   const int* slot_map = nullptr; // device [M / t_len]: destination window slot of each window of the batch (EPI_KV_CROSS); null = identity
   float* out_f32 = nullptr;
-  int qkv_f32 = 0;               // split-precision modes, EPI_QKV_ENC: 1 = Q / K / V^T stored fp32 (fp32 attention kernel), 0 = IEEE half
+  int qkv_mode = 0;              // split-precision modes, EPI_QKV_ENC storage of Q / K / V^T (x3_enc_attention_mode): 0 = IEEE half,
+                                 // 1 = fp32 (fp32 attention kernel), 2 = half hi + lo planes, the lo plane qkv_plane elements behind
+  size_t qkv_plane = 0;
 };
 
 struct GemmArgs {
@@ -78,8 +80,9 @@ int launch_layernorm(int dtype, const float* x, const void* g, const void* b, vo
 int launch_enc_attention(int dtype, const void* q, const void* k, const void* vt, void* out,
                          int B, int H, int T, int Tp, int d, hipStream_t s);
 
-// split-precision modes: is the encoder attention forced to the fp32 kernel (WSEG_X3_ENC_ATTN=f32)?  -> EpiParams::qkv_f32
-bool x3_enc_attention_f32();
+// split-precision modes: arithmetic of the encoder self-attention -> EpiParams::qkv_mode.  2 (default): split precision (half
+// hi + lo operands, three MFMAs per product); 0: plain IEEE half (WSEG_X3_ENC_ATTN=f16); 1: fp32 matrix cores (=f32).
+int x3_enc_attention_mode();
 // Split-precision modes only: operand rows (hi | lo pairs, wseg_common.h) [M][2d words] <-> fp32 [M][d], d % 32 == 0.
 int launch_operand_to_f32(int dtype, const void* op, float* out, size_t M, int d, hipStream_t s);
 int launch_f32_to_operand(int dtype, const float* in, void* op, size_t M, int d, hipStream_t s);

@@ -203,7 +203,7 @@ int run_encoder(wseg_model* m, const float* feats, int W, Plan& p, void* enc_out
     WSEG_TRY(launch_layernorm(dt, (const float*)p.x, L.ln1_g, L.ln1_b, p.y, M, d, s));
     e = EpiParams();
     e.bias = L.qkv_b; e.q = p.q; e.k = p.k; e.v = p.vt; e.d_model = d; e.t_len = T; e.t_pad = Tp; e.n_heads = H; e.scale = 0.125f;
-    e.qkv_f32 = m->x3 && x3_enc_attention_f32();
+    if (m->x3) { e.qkv_mode = x3_enc_attention_mode(); e.qkv_plane = (size_t)W * H * Tp * 64; }
     WSEG_TRY(gemm(m, EPI_QKV_ENC, p.y, d, L.qkv_w, d, M, 3 * d, d, e, nullptr, s));
     WSEG_TRY(launch_enc_attention(dt, p.q, p.k, p.vt, p.y, W, H, T, Tp, d, s));
     e = EpiParams();
