@@ -223,7 +223,7 @@ def main(argv=None, backend=make_backend):
                     help="engine mode; bf16 is what BASELINE.json names, f16x3 / bf16x3 are the split-precision parity modes")
     ap.add_argument("--parity-mode", default="f16x3", choices=["bf16x3", "f16x3"],
                     help="split-precision mode reported in extra.split_precision_mode (the segmenter's default mode)")
-    ap.add_argument("--cpu-windows", type=int, default=2)
+    ap.add_argument("--cpu-windows", type=int, default=4, help="windows of the CPU baseline sample (4 x 30 s: ~25 s of CPU work for the HF model and the port together)")
     ap.add_argument("--check-windows", type=int, default=4, help="windows re-decoded in f32 mode for the self-check")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hf-baseline", action="store_true")
