@@ -5,6 +5,8 @@
 // Beam semantics follow HF generation/utils.py:3208-3510 (_beam_search) and helpers :3008-3206 literally,
 // including the float32 "+ -1e9" masking arithmetic; see oracle/whisper_ref.py for the CPU restatement.
 // These kernels are HBM/latency-bound integer + VALU work (no MFMA): reads are 128-byte rows.
+#include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 #include "wseg_dec.h"
 
@@ -561,6 +563,162 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-precision modes: cross-attention over 24-bit K / V (EpiParams::kv24: per (slot, head) a [Tk][64] plane of the fp32
+// words' top halves, then a [Tk][64] plane of their third bytes; 192 instead of 256 bytes per row pair of an HBM-bound stream).
+// fp32 query and arithmetic; same structure as the packed 16-bit kernel above: 8 lanes per row, 8 raw rows per lane in flight
+// (16 + 8 bytes each), one v_perm_b32 per element to rebuild the fp32 word, two beams per v_pk_fma_f32, DPP row sums.
+// ------------------------------------------------------------------------------------------------
+template <typename TO, int NB>
+__global__ __launch_bounds__(256, 3) void dec_cross_attn_k24_kernel(DecodeState st, const float* __restrict__ q,
+                                                                    const unsigned char* __restrict__ ck, const unsigned char* __restrict__ cv,
+                                                                    void* __restrict__ out, int H, int Tk, int d, PartialInfo pi,
+                                                                    const float* __restrict__ q_bias, float scale) {
+  typedef unsigned int raw16 __attribute__((ext_vector_type(4)));
+  typedef unsigned int raw8 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  constexpr int U = 8;
+  __shared__ float sc[NB][512];
+  __shared__ float red[4][NB][64];
+  __shared__ float sinv[NB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int w = blockIdx.x / H, h = blockIdx.x - w * H;
+  if (st.done[w]) return;                              // idle slot: its 96 KiB of K/V are not streamed
+  const int nb = st.nb;
+  const int sub = lane & 7, rowl = lane >> 3;
+  const unsigned char* Kb = ck + ((size_t)w * H + h) * Tk * 192;
+  const unsigned char* Vb = cv + ((size_t)w * H + h) * Tk * 192;
+  const unsigned char* Kl = Kb + (size_t)Tk * 128;
+  const unsigned char* Vl = Vb + (size_t)Tk * 128;
+  constexpr int NP = (NB + 1) / 2;
+  f2 qq[8][NP];
+  {
+    float qv[8];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if (pi.part != nullptr) {
+        reduce8<float>(pi, w * nb + min(j, nb - 1), h * 64 + sub * 8, q_bias, qv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] *= scale;
+      } else {
+        load8<float>(q + (size_t)(w * nb + min(j, nb - 1)) * d + h * 64 + sub * 8, qv);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qq[e][j >> 1][j & 1] = qv[e];
+    }
+    if constexpr (NB == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qq[e][0][1] = 0.f;
+    }
+  }
+  // element e of a row slice: fp32 word = [top half e][third byte e][0]
+  auto unpack = [](const raw16& hi, const raw8& lo, float v[8]) {
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      const unsigned hw = hi[e2], lw = lo[e2 >> 1];
+      const unsigned s0 = (e2 & 1) ? 0x0504020cu : 0x0504000cu, s1 = (e2 & 1) ? 0x0706030cu : 0x0706010cu;
+      v[2 * e2] = __uint_as_float(__builtin_amdgcn_perm(hw, lw, s0));
+      v[2 * e2 + 1] = __uint_as_float(__builtin_amdgcn_perm(hw, lw, s1));
+    }
+  };
+  for (int t0 = 0; t0 < Tk; t0 += 32 * U) {
+    raw16 kh[U];
+    raw8 kl[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = min(t0 + u * 32 + wave * 8 + rowl, Tk - 1);      // clamped: out-of-range rows are discarded below
+      kh[u] = __builtin_nontemporal_load((const raw16*)(Kb + (size_t)t * 128 + sub * 16));
+      kl[u] = __builtin_nontemporal_load((const raw8*)(Kl + (size_t)t * 64 + sub * 8));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + u * 32 + wave * 8 + rowl;
+      float kv[8];
+      unpack(kh[u], kl[u], kv);
+      f2 a2[NP];
+#pragma unroll
+      for (int j2 = 0; j2 < NP; ++j2) a2[j2] = (f2){0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const f2 kk = {kv[e], kv[e]};
+#pragma unroll
+        for (int j2 = 0; j2 < NP; ++j2) a2[j2] = __builtin_elementwise_fma(qq[e][j2], kk, a2[j2]);
+      }
+      float a[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) a[j] = a2[j >> 1][j & 1];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) a[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[j]), 0xB1, 0xF, 0xF, true));
+#pragma unroll
+      for (int j = 0; j < NB; ++j) a[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[j]), 0x4E, 0xF, 0xF, true));
+#pragma unroll
+      for (int j = 0; j < NB; ++j) a[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[j]), 0x141, 0xF, 0xF, true));
+      float mine = a[0];
+#pragma unroll
+      for (int j = 1; j < NB; ++j) mine = sub == j ? a[j] : mine;
+      if (sub < nb && t < Tk) sc[sub][t] = mine;
+    }
+  }
+  __syncthreads();
+  for (int j = wave; j < nb; j += 4) {
+    float mx = -3.0e38f;
+    for (int t = lane; t < Tk; t += 64) mx = fmaxf(mx, sc[j][t]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int t = lane; t < Tk; t += 64) { const float p = expf(sc[j][t] - mx); sc[j][t] = p; sum += p; }
+    sum = wave_sum(sum);
+    if (lane == 0) sinv[j] = 1.0f / sum;
+  }
+  __syncthreads();
+  static_assert(NB == 1 || NB == 2 || NB == 4, "beam tiles");
+  f2 acc[NB][4];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[j][e] = (f2){0.f, 0.f};
+  for (int t0 = 0; t0 < Tk; t0 += 32 * U) {
+    raw16 vh[U];
+    raw8 vl[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = min(t0 + u * 32 + wave * 8 + rowl, Tk - 1);
+      vh[u] = __builtin_nontemporal_load((const raw16*)(Vb + (size_t)t * 128 + sub * 16));
+      vl[u] = __builtin_nontemporal_load((const raw8*)(Vl + (size_t)t * 64 + sub * 8));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + u * 32 + wave * 8 + rowl;
+      const bool ok = t < Tk;
+      const int tc = ok ? t : Tk - 1;
+      float vf[8];
+      unpack(vh[u], vl[u], vf);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const float p = (ok && j < nb) ? sc[j][tc] : 0.f;
+        const f2 pp = {p, p};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][e] = __builtin_elementwise_fma(pp, (f2){vf[2 * e], vf[2 * e + 1]}, acc[j][e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = acc[j][e >> 1][e & 1];
+      a += __shfl_xor(a, 8, 64);
+      a += __shfl_xor(a, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      if (rowl == 0) red[wave][j][sub * 8 + e] = a;
+    }
+  __syncthreads();
+  for (int i = tid; i < nb * 64; i += 256) {
+    const int j = i >> 6, e = i & 63;
+    const float o = ((red[0][j][e] + red[1][j][e]) + red[2][j][e]) + red[3][j][e];
+    Op<TO>::st1(out, (size_t)(w * nb + j), d, h * 64 + e, o * sinv[j]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Per-row candidates: log_softmax (fp32) -> suppress -> + running beam score -> top-Kc.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool better(float av, int ai, float bv, int bi) { return av > bv || (av == bv && ai < bi); }
@@ -966,11 +1124,25 @@ static void launch_cross_t(const DecodeState& st, const void* q, const void* ck,
   else WSEG_CA(8);
 #undef WSEG_CA
 }
+bool x3_cross_kv24() {
+  static const bool v = !(getenv("WSEG_X3_CKV") && !strcmp(getenv("WSEG_X3_CKV"), "f32"));
+  return v;
+}
+
 int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const void* ck, const void* cv, void* out, int H, int Tk, int d,
                           const PartialInfo* q_part, const void* q_bias, float scale, hipStream_t s) {
   if (Tk > 512) { set_error("cross-attention: %d encoder positions > 512", Tk); return WSEG_ERR_INVALID; }
   PartialInfo pi;
   if (q_part) pi = *q_part;
+  if ((dtype == WSEG_BF16X3 || dtype == WSEG_F16X3) && x3_cross_kv24() && st.nb <= 4) {
+    dim3 grid(st.W * H), block(256);
+#define WSEG_K24(TO_, NB_) hipLaunchKernelGGL((dec_cross_attn_k24_kernel<TO_, NB_>), grid, block, 0, s, st, (const float*)q, (const unsigned char*)ck, (const unsigned char*)cv, out, H, Tk, d, pi, (const float*)q_bias, scale)
+    if (dtype == WSEG_BF16X3) { if (st.nb <= 1) WSEG_K24(X3<bf16_t>, 1); else if (st.nb <= 2) WSEG_K24(X3<bf16_t>, 2); else WSEG_K24(X3<bf16_t>, 4); }
+    else { if (st.nb <= 1) WSEG_K24(X3<f16_t>, 1); else if (st.nb <= 2) WSEG_K24(X3<f16_t>, 2); else WSEG_K24(X3<f16_t>, 4); }
+#undef WSEG_K24
+    WSEG_LAUNCH_CHECK();
+    return WSEG_OK;
+  }
   static const bool deep = getenv("WSEG_CROSS_NO_PK") == nullptr;         // tuning knob: fp32-FMA kernel
   if ((dtype == WSEG_BF16 || dtype == WSEG_F16) && deep && Tk <= 512 && st.nb <= 4) {
     dim3 grid(st.W * H), block(256);

@@ -107,8 +107,18 @@ __device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, fl
     const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
     const int b = m / ep.t_len, t = m - b * ep.t_len;
     const int bs = ep.slot_map ? ep.slot_map[b] : b;
-    PT* dst = (PT*)(sec == 0 ? ep.k : ep.v) + (((size_t)bs * ep.n_heads + h) * ep.t_len + t) * 64 + e;
-    Vec4<PT>::st(dst, v);
+    if (IO<T>::split && ep.kv24) {
+      unsigned char* blk = (unsigned char*)(sec == 0 ? ep.k : ep.v) + ((size_t)bs * ep.n_heads + h) * ep.t_len * 192;
+      unsigned w[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[i] = __float_as_uint(v[i]) + 0x80u;        // round to 24 bits (half up in magnitude)
+      *(uint2*)(blk + (size_t)t * 128 + e * 2) = make_uint2((w[0] >> 16) | (w[1] & 0xffff0000u), (w[2] >> 16) | (w[3] & 0xffff0000u));
+      *(unsigned*)(blk + (size_t)ep.t_len * 128 + (size_t)t * 64 + e) =
+          ((w[0] >> 8) & 0xffu) | (w[1] & 0xff00u) | ((w[2] << 8) & 0xff0000u) | ((w[3] << 16) & 0xff000000u);
+    } else {
+      PT* dst = (PT*)(sec == 0 ? ep.k : ep.v) + (((size_t)bs * ep.n_heads + h) * ep.t_len + t) * 64 + e;
+      Vec4<PT>::st(dst, v);
+    }
   } else if constexpr (EPI == EPI_F32) {
     *(float4*)(ep.out_f32 + (size_t)m * ep.ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
   } else if constexpr (EPI == EPI_QKV_DEC) {
@@ -209,8 +219,15 @@ __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, f
     const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
     const int b = m / ep.t_len, t = m - b * ep.t_len;
     const int bs = ep.slot_map ? ep.slot_map[b] : b;
-    PT* dst = (PT*)(sec == 0 ? ep.k : ep.v) + (((size_t)bs * ep.n_heads + h) * ep.t_len + t) * 64 + e;
-    st8_h<PT>(dst, v);
+    if (IO<T>::split && ep.kv24) {
+      EpiParams e2 = ep;                        // the bias has been added above
+      e2.bias = nullptr;
+      epi_apply<EPI, T>(e2, m, n0, v);
+      epi_apply<EPI, T>(e2, m, n0 + 4, v + 4);
+    } else {
+      PT* dst = (PT*)(sec == 0 ? ep.k : ep.v) + (((size_t)bs * ep.n_heads + h) * ep.t_len + t) * 64 + e;
+      st8_h<PT>(dst, v);
+    }
   } else if constexpr (EPI == EPI_F32) {
     float* o = ep.out_f32 + (size_t)m * ep.ldc + n0;
     *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);

@@ -43,6 +43,8 @@ struct EpiParams {
   int qkv_mode = 0;              // split-precision modes, EPI_QKV_ENC storage of Q / K / V^T (x3_enc_attention_mode): 0 = IEEE half,
                                  // 1 = fp32 (fp32 attention kernel), 2 = half hi + lo planes, the lo plane qkv_plane elements behind
   size_t qkv_plane = 0;
+  int kv24 = 0;                  // split-precision modes, EPI_KV_CROSS: 1 = cross K / V as 24-bit values in two planes per (slot, head)
+                                 // — [t_len][64] top halves (16 bits) then [t_len][64] third bytes — instead of fp32 (x3_cross_kv24)
 };
 
 struct GemmArgs {
@@ -83,6 +85,10 @@ int launch_enc_attention(int dtype, const void* q, const void* k, const void* vt
 // split-precision modes: arithmetic of the encoder self-attention -> EpiParams::qkv_mode.  2 (default): split precision (half
 // hi + lo operands, three MFMAs per product); 0: plain IEEE half (WSEG_X3_ENC_ATTN=f16); 1: fp32 matrix cores (=f32).
 int x3_enc_attention_mode();
+// split-precision modes: cross-attention K / V stored as fp32 words rounded to their top 24 bits (sign, exponent, 15 + 1 mantissa
+// bits — the ">= 16 bits" the precision study asks of the cross K; 3 instead of 4 bytes per element of an HBM-bound stream).
+// Default on; WSEG_X3_CKV=f32 keeps fp32.
+bool x3_cross_kv24();
 // Split-precision modes only: operand rows (hi | lo pairs, wseg_common.h) [M][2d words] <-> fp32 [M][d], d % 32 == 0.
 int launch_operand_to_f32(int dtype, const void* op, float* out, size_t M, int d, hipStream_t s);
 int launch_f32_to_operand(int dtype, const float* in, void* op, size_t M, int d, hipStream_t s);

@@ -68,6 +68,7 @@ struct wseg_model {
   wseg_model_config cfg;
   size_t es;                 // element size of the model dtype
   bool x3 = false;           // split-precision mode (GEMM operands are hi | lo rows, everything else fp32)
+  size_t ckv_es = 0;         // bytes per cross-attention K / V element: es, or 3 (24-bit planes) in the split modes with <= 4 beams
   int kp1, vp, tp;           // conv1 K padded, vocab padded, encoder positions padded
   std::map<std::string, Slot> slots;
   const void *conv1_w, *conv1_b, *conv2_w, *conv2_b, *enc_pos, *enc_ln_g, *enc_ln_b;
@@ -117,8 +118,9 @@ void make_plan(const wseg_model* m, int W, int nb, int L, char* base, Plan& p) {
   DecPlan& q = p.dec;
   q.W = W;
   const size_t Wc = W, R = Wc * nb, Rp = align_up(R, 256);
-  q.ck = take(Ld * Wc * H * Tk * 64 * es);
-  q.cv = take(Ld * Wc * H * Tk * 64 * es);
+  const size_t ces = (m->x3 && x3_cross_kv24() && nb <= 4) ? 3 : es;      // 24-bit cross K / V (wseg_dec.hip)
+  q.ck = take(Ld * Wc * H * Tk * 64 * ces);
+  q.cv = take(Ld * Wc * H * Tk * 64 * ces);
   q.sk = take(Ld * R * H * (size_t)L * 64 * es);
   q.sv = take(Ld * R * H * (size_t)L * 64 * es);
   q.dx = take(Rp * d * 4);                         // decoder residual stream, fp32
@@ -229,7 +231,7 @@ int run_decoder_step(wseg_model* m, DecPlan& p, bool want_logits, hipStream_t s)
   const int R = st.W * st.nb;
   const size_t es = m->es;
   const size_t self_stride = (size_t)R * H * st.L * 64 * es;
-  const size_t cross_stride = (size_t)st.W * H * Tk * 64 * es;
+  const size_t cross_stride = (size_t)st.W * H * Tk * 64 * ((m->x3 && x3_cross_kv24() && st.nb <= 4) ? 3 : es);
   WSEG_TRY(launch_embed(dt, st, m->dec_tok, m->dec_pos, p.dx, d, s));
   EpiParams e;
   auto gemm_resid_ln = [&](const void* A, int K, const void* Wt, const void* bias, const void* g_, const void* b_) -> int {
@@ -302,6 +304,7 @@ extern "C" int wseg_model_create(const wseg_model_config* cfg, wseg_model** out)
   // modes, whose tensors are either fp32 or hi | lo pairs of 16-bit words
   m->es = (cfg->dtype == WSEG_BF16 || cfg->dtype == WSEG_F16) ? 2 : 4;
   m->x3 = cfg->dtype == WSEG_BF16X3 || cfg->dtype == WSEG_F16X3;
+  m->ckv_es = m->es;
   m->kp1 = (int)align_up((size_t)3 * cfg->n_mels, 64);
   m->vp = (int)align_up((size_t)cfg->vocab, 128);
   m->tp = (int)align_up((size_t)cfg->enc_positions, 128);
@@ -488,7 +491,8 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
   WSEG_TRY(launch_decode_reset(st, s));
 
   const int d = c.d_model, H = c.n_heads, Tk = c.enc_positions;
-  const size_t cross_stride = (size_t)S * H * Tk * 64 * m->es;
+  const bool kv24 = m->x3 && x3_cross_kv24() && nb <= 4;
+  const size_t cross_stride = (size_t)S * H * Tk * 64 * (kv24 ? 3 : m->es);
   const size_t feat_stride = (size_t)c.n_mels * c.spec_cols;
 
   // host view of the slots
@@ -518,7 +522,7 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
     for (int l = 0; l < c.dec_layers; ++l) {     // cross-attention K/V of every decoder layer, once per window (shared by its beams)
       EpiParams e;
       e.bias = m->dec[l].ckv_b; e.k = q.ck + l * cross_stride; e.v = q.cv + l * cross_stride;
-      e.d_model = d; e.t_len = Tk; e.n_heads = H; e.slot_map = q.adm_slots;
+      e.d_model = d; e.t_len = Tk; e.n_heads = H; e.slot_map = q.adm_slots; e.kv24 = kv24;
       WSEG_TRY(gemm(m, EPI_KV_CROSS, enc_rows, d, m->dec[l].ckv_w, d, n * Tk, 2 * d, d, e, nullptr, s));
     }
     WSEG_TRY(timing_event(ln, s, &e2));
