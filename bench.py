@@ -10,9 +10,10 @@ One "step" = one pass of the whole hot path over one batch of synthetic windows 
 resident in HBM -> log-mel kernels -> Whisper encoder -> cross-K/V -> beam-search decode (libwseg) ->
 token ids to the host -> detokenise + regex parse (the CPU epilogue).  Workload (BASELINE.json metric):
 whisperseg-large geometry (1550 M), bf16, 30 s windows (spec_time_step 0.03 @ 16 kHz, 480 000 samples,
-SURVEY §8d), by default 256 concurrent windows (2 h 8 min of audio) per GPU per step — the concurrency of
-BASELINE.json configs[4], sharded weakly: every GPU gets its own 256 windows; `--windows 120` is the one-hour
-recording of configs[3] — seeded random weights (no checkpoint exists offline), synthetic 16 kHz sine+noise,
+SURVEY §8d), by default 1024 concurrent windows (8 h 32 min of audio) per GPU per step — the engine's default slot count,
+i.e. how a long queue of clips is actually decoded; sharded weakly: every GPU gets its own 1024 windows; `--windows 256`
+is the r01 / r02 headline workload (kept as `extra.step_256_windows`), `--windows 120` the one-hour recording of
+configs[3] — seeded random weights (no checkpoint exists offline), synthetic 16 kHz sine+noise,
 beams 4, decode length pinned to --gen-tokens with EOS suppressed (random weights never emit a meaningful EOS).
 Windows are independent, so ranks shard them with no data-path collective ("weak" scaling: fixed
 windows per GPU); the only exchange is the all_gather of token ids to every rank.
@@ -211,10 +212,11 @@ def main(argv=None, backend=make_backend):
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="large", choices=sorted(GEOMETRY))
-    ap.add_argument("--windows", type=int, default=256,
-                    help="30 s windows per GPU per step (default 256 concurrent windows, BASELINE configs[4]; 120 = one 1-hour "
-                         "recording, configs[3])")
-    ap.add_argument("--slots", type=int, default=0, help="window slots of the engine (0 = one per window of the step)")
+    ap.add_argument("--windows", type=int, default=1024,
+                    help="30 s windows per GPU per step (default 1024 = the engine's default slot count: every window of the step is "
+                         "decoded concurrently; 256 = the r01/r02 headline, reported in extra.step_256_windows; 120 = one 1-hour "
+                         "recording, BASELINE configs[3])")
+    ap.add_argument("--slots", type=int, default=0, help="window slots of the engine (0 = min(windows, the engine default 1024))")
     ap.add_argument("--gen-tokens", type=int, default=32)
     ap.add_argument("--beams", type=int, default=4)
     ap.add_argument("--sr", type=int, default=16000)
@@ -257,7 +259,7 @@ def main(argv=None, backend=make_backend):
     sr, sts = args.sr, args.spec_time_step
     win_len = int(1000 * sts * sr)
     W = args.windows
-    slots = args.slots or W
+    slots = args.slots or min(W, 1024)
     if distributed:   # one copy of the weights is authoritative: broadcast rank 0's over RCCL/xGMI
         wdist.broadcast_weights(eng.weights, src=0)
     extractor = make_extractor(sr, sts)
@@ -460,6 +462,11 @@ def extra_lines(args, eng, step, main_in, make_extractor, device, W, slots):
     """The other lines SURVEY §8(d) asks for, one untimed-warm + one timed pass each (bounded: a few seconds)."""
     from whisperseg_amd.model import WhisperSegmenterForEval
     out = {}
+    # every supplementary line works on (at most) the first 256 windows of the step — the r01 / r02 headline workload — so
+    # that the lines stay comparable across rounds and the f32 / split-precision engines' workspaces stay small
+    W_step, W = W, min(W, 256)
+    slots = min(slots, W)
+    sub = dict(win_starts=main_in["win_starts"][:W], n_slots=W)
 
     def timed(fn, reps=1):
         fn()
@@ -471,7 +478,11 @@ def extra_lines(args, eng, step, main_in, make_extractor, device, W, slots):
         return (time.perf_counter() - t0) / reps, r
 
     # 128 generated tokens (the long end of real WhisperSeg outputs)
-    dt, _ = timed(lambda: step(gen_tokens=128))
+    if W_step != W:
+        dt, _ = timed(lambda: step(**sub), reps=3)
+        out[f"step_{W}_windows"] = {"audio_sec_per_s": W * 1000 * args.spec_time_step / dt, "windows_per_s": W / dt, "ms_per_step": dt * 1e3,
+                                    "note": f"the timed step() restricted to {W} windows through {W} slots (the r01 / r02 headline workload)"}
+    dt, _ = timed(lambda: step(gen_tokens=128, **sub))
     out["gen_tokens_128"] = {"audio_sec_per_s": W * 1000 * args.spec_time_step / dt, "windows_per_s": W / dt, "ms_per_step": dt * 1e3}
     # the reference's realistic window lengths: 10 s (human, sts 0.01 @ 16 kHz) and 2.5 s (animal default, sts 0.0025 @ 32 kHz)
     for name, sr, sts in (("windows_10s_sts0.01_16k", 16000, 0.01), ("windows_2.5s_sts0.0025_32k", 32000, 0.0025)):
@@ -479,10 +490,11 @@ def extra_lines(args, eng, step, main_in, make_extractor, device, W, slots):
         ext = make_extractor(sr, sts)
         audio = torch.from_numpy(synth_pcm(W, wl, sr, seed=5)).to(device)
         st = (torch.arange(W, dtype=torch.int64) * wl).to(device)
-        dt, _ = timed(lambda: step(ext=ext, audio=audio, win_starts=st, wl=wl, step_sts=sts))
+        dt, _ = timed(lambda: step(ext=ext, audio=audio, win_starts=st, wl=wl, step_sts=sts, n_slots=W))
         out[name] = {"audio_sec_per_s": W * 1000 * sts / dt, "windows_per_s": W / dt, "ms_per_step": dt * 1e3}
     # the front-end alone against the HBM roof: 4*L bytes in + 320 KB out per window
-    ext, audio, st, wl = main_in["ext"], main_in["audio"], main_in["win_starts"], main_in["wl"]
+    ext, audio, st, wl = main_in["ext"], main_in["audio"], main_in["win_starts"][:W], main_in["wl"]
+    audio = audio[:W * wl]
     ext.extract_windows(audio, st, wl)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -603,7 +615,7 @@ def extra_lines(args, eng, step, main_in, make_extractor, device, W, slots):
         dt1, (tk, ln, _), stats = queued(n_slots=W)                  # W slots, as in the timed step
         # the same windows decoded batch by batch as the reference does (model.py:653): every batch runs to its longest window
         t0 = time.perf_counter()
-        resb = [step(audio=audio_q, win_starts=st_q[lo:lo + W], gen_tokens=2 * args.gen_tokens, window_max_length=lens[lo:lo + W])
+        resb = [step(audio=audio_q, win_starts=st_q[lo:lo + W], gen_tokens=2 * args.gen_tokens, window_max_length=lens[lo:lo + W], n_slots=W)
                 for lo in range(0, nq, W)]
         torch.cuda.synchronize()
         dtb = time.perf_counter() - t0
