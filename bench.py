@@ -570,6 +570,14 @@ def extra_lines(args, eng, step, main_in, make_extractor, device, W, slots):
         line["mode"] = pm
         line["speedup_over_f32_mode"] = {f"f32_at_{n32}_windows": line["audio_sec_per_s"] / out["f32_mode"]["audio_sec_per_s"],
                                          f"f32_at_{W}_windows": line["audio_sec_per_s"] / out["f32_mode"][f"at_{W}_windows"]["audio_sec_per_s"]}
+        # the public API in its default mode: a one-hour recording through WhisperSegmenterForEval.segment() on the split engine
+        engp.hf_config = dict(hf_config(args.model), cluster_codebook={str(i): i for i in range(10)})
+        segp = WhisperSegmenterForEval(model=engp, tokenizer=fake_tokenizer())
+        segp.suppress_tokens, segp.begin_suppress_tokens = SUPPRESS, BEGIN_SUPPRESS
+        dt, predp = timed(lambda: segp.segment(hour, 16000, spec_time_step=0.03, max_length=3 + args.gen_tokens, num_beams=args.beams))
+        line["segment_api_1h_recording"] = {"audio_sec_per_s": 3600.0 / dt, "seconds": dt, "windows": 120,
+                                            "note": "host numpy PCM -> segment() in the default (split-precision) mode"}
+        del segp
         out["split_precision_mode"] = line
         if engp is not eng:
             del engp

@@ -235,3 +235,32 @@ torch.save(T.gen(eng, x, 4, n_slots=4), sys.argv[1])
         subprocess.check_call([sys.executable, "-c", code, path, ROOT], env={**os.environ, "WSEG_NO_GRAPH": "1"})
         t, l = torch.load(path)
     assert torch.equal(t, ref_t) and torch.equal(l, ref_l)
+
+
+def test_slot_cap_and_workspace_lifecycle(gpu_lib):
+    """`batch_size` no longer bounds the decode memory: `segmenter.max_slots` / n_slots does, and the engine gives a
+    much larger workspace back when a later call needs less than a quarter of it."""
+    import os
+    from conftest import GOLDEN
+    from whisperseg_amd.model import WhisperSegmenter
+    eng = tiny_engine("f32")
+    x = tiny_feats(23)
+    ref_t, ref_l = gen(eng, x, 4)
+    big = eng._ws.numel()
+    assert eng.last_stats()["n_slots"] == 23
+    t, l = gen(eng, x, 4, n_slots=2)                      # 2 slots need less than a quarter of 23 slots' workspace ...
+    assert eng.last_stats()["n_slots"] == 2
+    assert torch.equal(l, ref_l) and torch.equal(t, ref_t)
+    if big > (2 << 30):                                   # ... but only workspaces above 2 GiB are worth re-allocating
+        assert eng._ws.numel() < big
+    eng.release_workspace()
+    assert eng._ws is None
+    t, l = gen(eng, x, 4, n_slots=5)
+    assert torch.equal(l, ref_l) and torch.equal(t, ref_t)
+    seg = WhisperSegmenter(os.path.join(GOLDEN, "tiny_model"), device="cuda", device_ids=[0], dtype="f32")
+    clip = TM.synth_clip(np.random.default_rng(4))[0]
+    audio = np.concatenate([clip] * 4)
+    want = seg.segment(audio, TM.SR)
+    seg.max_slots = 1
+    assert seg.segment(audio, TM.SR, batch_size=64) == want
+    assert seg.model_list[0].last_stats()["n_slots"] == 1

@@ -8,7 +8,7 @@
 // Bound: HBM (algorithmic bytes per window = 4*win_len in + 4*n_mels*n_cols out); the FFT itself is
 // ~0.05 GFLOP/window.  Two STFT kernels write log10-mel values straight into the output image (no raw scratch) and the
 // window maximum / minimum into two ordered-uint words; a second pass clamps and normalises in place.
-//   logmel_fft256_kernel (n_fft = 512: every 16 / 32 kHz configuration of the reference): one WAVE per frame, the 256-point
+//   logmel_fft_kernel<256 | 512> (n_fft = 512 / 1024: every 16 / 32 / 48 kHz configuration of the reference): one WAVE per frame, the 256-point
 //     packed complex FFT as four radix-4 DIF stages on 4 points per lane — butterflies and twiddles in registers (packed
 //     fp32 math), three transposes through a 2-KB wave-private LDS buffer whose XOR swizzle makes every one of them
 //     bank-conflict free, no workgroup barrier until the 32 frames of a workgroup are written out as 128-byte rows.
@@ -30,7 +30,7 @@ __device__ __forceinline__ float ord2f(uint32_t u) {
 
 constexpr int LM_FB = 32;          // frames per workgroup of the fast path (one 128-byte output row segment per filter)
 constexpr int LM_CH = 8;           // bins per mel work item
-constexpr int LM_MAX_ITEMS = 192;  // mel work items (filters cut into <= LM_CH-bin chunks; 80 slaney filters over 257 bins: ~110)
+constexpr int LM_MAX_ITEMS = 256;  // mel work items (filters cut into <= LM_CH-bin chunks; <= (2 * 513 + 8 * 96) / 8 = 225 for 96 filters over 513 bins)
 // Mel work items of one filterbank: filter m = items cb[m] .. cb[m+1]-1, item n = bins k0[n] .. k0[n]+7 with zero-padded weights.
 // Built once per call by logmel_items_kernel (a few microseconds), copied into LDS by every workgroup of the fast path.
 struct LmTables {
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void logmel_stft_kernel(LogmelArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// n_fft = 512: wave-per-frame radix-4 FFT
+// n_fft = 512 / 1024: wave-per-frame radix-4 FFT
 // ------------------------------------------------------------------------------------------------------------------
 typedef float cf2 __attribute__((ext_vector_type(2)));       // complex (re, im): adds / scalings compile to v_pk_*_f32
 __device__ __forceinline__ cf2 cmul(cf2 a, cf2 w) { return (cf2){a.x, a.x} * w + (cf2){-a.y, a.y} * (cf2){w.y, w.x}; }
@@ -198,16 +198,20 @@ __global__ __launch_bounds__(256) void logmel_items_kernel(wseg_logmel_desc d, L
   }
 }
 
-__global__ __launch_bounds__(256) void logmel_fft256_kernel(LogmelArgs a) {
-  constexpr int NC = 256;
-  __shared__ __attribute__((aligned(16))) cf2 s_z[4][NC];          // wave-private FFT buffers
-  __shared__ float s_pw[4][NC + 4 + LM_CH];                        // wave-private power spectra (257 bins + zero pad for whole items)
+// NC = n_fft / 2 packed complex points per frame: 256 (n_fft 512) or 512 (n_fft 1024: one radix-2 DIF step in registers,
+// z[n] +- z[n + 256], turns the frame into two 256-point FFTs — the even and the odd bins — run through the same core).
+template <int NC>
+__global__ __launch_bounds__(256) void logmel_fft_kernel(LogmelArgs a) {
+  constexpr int R = NC / 256;                                      // 256-point FFTs per frame
+  constexpr int SC = 2 * R;                                        // table index of W_256^1 (table: e^{-2 pi i k / n_fft}, k < NC)
+  __shared__ __attribute__((aligned(16))) cf2 s_z[4][NC];          // wave-private FFT buffers (R of 256 entries)
+  __shared__ float s_pw[4][NC + 4 + LM_CH];                        // wave-private power spectra (NC + 1 bins + zero pad for whole items)
   __shared__ float s_part[4][LM_MAX_ITEMS];                        // wave-private partial mel sums
   __shared__ float s_tile[96][LM_FB + 1];                          // [filter][frame of the workgroup]
   __shared__ __attribute__((aligned(16))) float s_w[LM_MAX_ITEMS][LM_CH];     // mel weights per item, zero padded
   __shared__ int s_ik0[LM_MAX_ITEMS], s_cb[97];
   __shared__ int s_nitems;
-  __shared__ cf2 s_tw[NC];                                         // e^{-2 pi i k / 512}: unpack twiddles
+  __shared__ cf2 s_tw[NC];                                         // the twiddle table: unpack twiddles
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int w = blockIdx.y, f0 = blockIdx.x * LM_FB;
   const int n_mels = a.d.n_mels, hop = a.d.hop;
@@ -220,40 +224,84 @@ __global__ __launch_bounds__(256) void logmel_fft256_kernel(LogmelArgs a) {
   for (int i = tid; i < LM_MAX_ITEMS * LM_CH / 4; i += 256) ((float4*)&s_w[0][0])[i] = ((const float4*)&a.tables->w[0][0])[i];
   __syncthreads();
   const int n_items = s_nitems;
-  s_tw[tid] = ((const cf2*)a.d.twiddle)[tid];
+  for (int i = tid; i < NC; i += 256) s_tw[i] = ((const cf2*)a.d.twiddle)[i];
   for (int i = tid; i < 4 * (4 + LM_CH); i += 256) s_pw[i / (4 + LM_CH)][NC + i % (4 + LM_CH)] = 0.f;      // pad stays zero
   // ---- per-lane constants: window, twiddles ----
-  const cf2* twt = (const cf2*)a.d.twiddle;                    // e^{-2 pi i k / 512}, k < 256
-  auto tw512 = [&](int k) -> cf2 { const cf2 t = twt[k & 255]; return (k & 256) ? -t : t; };
-  cf2 win[4], w1[3], w2[3], w3[3];
+  const cf2* twt = (const cf2*)a.d.twiddle;                    // e^{-2 pi i k / n_fft}, k < NC; k in [NC, 2 NC): the negative
+  auto twn = [&](int k) -> cf2 { const cf2 t = twt[k & (NC - 1)]; return (k & NC) ? -t : t; };
+  cf2 win[4 * R], w1[3], w2[3], w3[3], wpre[R == 2 ? 4 : 1];
   const int r16 = lane & 15, r4 = lane & 3;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 4 * R; ++i) {
     const int n = lane + 64 * i;
     win[i] = (cf2){a.d.window[2 * n], a.d.window[2 * n + 1]};
   }
 #pragma unroll
-  for (int j = 1; j < 4; ++j) { w1[j - 1] = tw512(2 * j * lane); w2[j - 1] = tw512(8 * j * r16); w3[j - 1] = tw512(32 * j * r4); }
+  for (int j = 1; j < 4; ++j) { w1[j - 1] = twn(SC * j * lane); w2[j - 1] = twn(4 * SC * j * r16); w3[j - 1] = twn(16 * SC * j * r4); }
+  if constexpr (R == 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wpre[i] = twn(2 * (lane + 64 * i));      // W_512^n of the radix-2 step
+  }
   __syncthreads();
 
-  cf2* zb = s_z[wave];
   float* pw = s_pw[wave];
+  // 256-point FFT of v (v[i] = point lane + 64 i) into zb in natural order
+  auto fft256 = [&](cf2 v[4], cf2* zb) {
+    bfly4(v);                                                  // stage 1 (stride 64, in registers)
+#pragma unroll
+    for (int j = 1; j < 4; ++j) v[j] = cmul(v[j], w1[j - 1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) zb[fsw(j * 64 + lane)] = v[j];
+    wave_lds_sync();
+    const int g1 = (lane >> 4) * 64;                           // stage 2 (stride 16): lane = (j' = lane >> 4, r = lane & 15)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = zb[fsw(g1 + r16 + 16 * q)];
+    bfly4(v);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) v[j] = cmul(v[j], w2[j - 1]);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) zb[fsw(g1 + j * 16 + r16)] = v[j];
+    wave_lds_sync();
+    const int g2 = g1 + ((lane >> 2) & 3) * 16;                // stage 3 (stride 4): lane = (j', j2 = (lane >> 2) & 3, r3 = lane & 3)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = zb[fsw(g2 + r4 + 4 * q)];
+    bfly4(v);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) v[j] = cmul(v[j], w3[j - 1]);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) zb[fsw(g2 + j * 4 + r4)] = v[j];
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = zb[fsw(g2 + r4 * 4 + q)];      // stage 4: lane = (j', j2, j3' = lane & 3): one 4-point FFT
+    bfly4(v);
+    wave_lds_sync();
+    const int k0 = (lane >> 4) + 4 * ((lane >> 2) & 3) + 16 * r4;     // natural order: k = j' + 4 j2 + 16 j3' + 64 j4
+#pragma unroll
+    for (int j = 0; j < 4; ++j) zb[fsw(k0 + 64 * j)] = v[j];
+  };
+  // bin k of the NC-point FFT: R == 1: zb[k]; R == 2: even bins in the first, odd bins in the second 256-entry buffer
+  auto zget = [&](int k) -> cf2 {
+    if constexpr (R == 1) return s_z[wave][fsw(k)];
+    else return s_z[wave][(k & 1) * 256 + fsw(k >> 1)];
+  };
   float lmax = -3.0e38f, lmin = 3.0e38f;
   for (int fi = 0; fi < LM_FB / 4; ++fi) {
     const int fr = wave * (LM_FB / 4) + fi, f = f0 + fr;       // wave-uniform
     if (f >= a.n_frames) break;
     // ---- A. load + window: z[n] = x[2n] + i x[2n+1], n = lane + 64 i ----
-    cf2 v[4];
+    cf2 v[4 * R];
     const int64_t base = (int64_t)f * hop - NC;                // window-local index of sample 0 of the frame
     const int64_t abase = wstart + base;
     if (base >= 0 && base + 2 * NC <= L && abase >= 0 && abase + 2 * NC <= a.n_audio) {      // wave-uniform: the frame is interior
       typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
       const float* src = a.audio + abase + 2 * lane;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const f2u t = *(const f2u*)(src + 128 * i); v[i] = (cf2){t.x, t.y} * win[i]; }
+      for (int i = 0; i < 4 * R; ++i) { const f2u t = *(const f2u*)(src + 128 * i); v[i] = (cf2){t.x, t.y} * win[i]; }
     } else
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4 * R; ++i) {
       float xs[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -265,55 +313,28 @@ __global__ __launch_bounds__(256) void logmel_fft256_kernel(LogmelArgs a) {
       }
       v[i] = (cf2){xs[0], xs[1]} * win[i];
     }
-    // ---- B. 256-point FFT: stage 1 (stride 64, in registers) ----
-    bfly4(v);
+    // ---- B. FFT ----
+    if constexpr (R == 1) {
+      fft256(v, s_z[wave]);
+    } else {
+      cf2 ev[4], od[4];
 #pragma unroll
-    for (int j = 1; j < 4; ++j) v[j] = cmul(v[j], w1[j - 1]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) zb[fsw(j * 64 + lane)] = v[j];
+      for (int i = 0; i < 4; ++i) { ev[i] = v[i] + v[i + 4]; od[i] = cmul(v[i] - v[i + 4], wpre[i]); }
+      fft256(ev, s_z[wave]);
+      wave_lds_sync();
+      fft256(od, s_z[wave] + 256);
+    }
     wave_lds_sync();
-    // stage 2 (stride 16): lane = (j' = lane >> 4, r = lane & 15)
-    const int g1 = (lane >> 4) * 64;
+    // ---- C. unpack the real FFT, |X[k]|^2 for k = lane + 64 i (and k = NC in lane 0) ----
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = zb[fsw(g1 + r16 + 16 * q)];
-    bfly4(v);
-#pragma unroll
-    for (int j = 1; j < 4; ++j) v[j] = cmul(v[j], w2[j - 1]);
-    wave_lds_sync();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) zb[fsw(g1 + j * 16 + r16)] = v[j];
-    wave_lds_sync();
-    // stage 3 (stride 4): lane = (j', j2 = (lane >> 2) & 3, r3 = lane & 3)
-    const int g2 = g1 + ((lane >> 2) & 3) * 16;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = zb[fsw(g2 + r4 + 4 * q)];
-    bfly4(v);
-#pragma unroll
-    for (int j = 1; j < 4; ++j) v[j] = cmul(v[j], w3[j - 1]);
-    wave_lds_sync();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) zb[fsw(g2 + j * 4 + r4)] = v[j];
-    wave_lds_sync();
-    // stage 4: lane = (j', j2, j3' = lane & 3) holds the four points of one 4-point FFT
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = zb[fsw(g2 + r4 * 4 + q)];
-    bfly4(v);
-    wave_lds_sync();
-    // natural order: k = j' + 4 j2 + 16 j3' + 64 j4
-    const int k0 = (lane >> 4) + 4 * ((lane >> 2) & 3) + 16 * r4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) zb[fsw(k0 + 64 * j)] = v[j];
-    wave_lds_sync();
-    // ---- C. unpack the real FFT, |X[k]|^2 for k = lane + 64 i (and k = 256 in lane 0) ----
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4 * R; ++i) {
       const int k = lane + 64 * i;
-      const cf2 zk = zb[fsw(k)], zm = zb[fsw((NC - k) & (NC - 1))];
+      const cf2 zk = zget(k), zm = zget((NC - k) & (NC - 1));
       const cf2 e = (cf2){0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y)};        // E = (Z[k] + conj Z[nc-k]) / 2
       const cf2 o = (cf2){0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x)};       // O = (Z[k] - conj Z[nc-k]) / (2i)
       const cf2 x = e + cmul(o, s_tw[k]);
       pw[k] = x.x * x.x + x.y * x.y;
-      if (k == 0) { const cf2 z0 = zk; const float xn = z0.x - z0.y; pw[NC] = xn * xn; }   // X[256] = Re Z[0] - Im Z[0]
+      if (k == 0) { const float xn = zk.x - zk.y; pw[NC] = xn * xn; }         // X[NC] = Re Z[0] - Im Z[0]
     }
     wave_lds_sync();
     // ---- D. mel projection: items of <= LM_CH bins, then each filter sums its items in order ----
@@ -432,11 +453,12 @@ extern "C" int wseg_logmel_f32(const wseg_logmel_desc* d, const float* audio, in
   const int nc = d->n_fft / 2;
   const size_t smem = (size_t)nc * 8 + (size_t)a.fpb * nc * 8 + (size_t)a.fpb * (nc + 1) * 4;
   static const bool generic_only = getenv("WSEG_LOGMEL_GENERIC") != nullptr;       // A/B + test knob
-  bool fast_ok = d->n_fft == 512 && d->n_mels <= 96 && !generic_only;
+  bool fast_ok = (d->n_fft == 512 || d->n_fft == 1024) && d->n_mels <= 96 && !generic_only;
   if (a.n_frames > 0 && fast_ok) {
     dim3 grid(cdiv(a.n_frames, LM_FB), n_windows);
     hipLaunchKernelGGL(logmel_items_kernel, dim3(1), dim3(256), 0, stream, *d, (LmTables*)a.tables);
-    hipLaunchKernelGGL(logmel_fft256_kernel, grid, dim3(256), 0, stream, a);
+    if (d->n_fft == 512) hipLaunchKernelGGL(logmel_fft_kernel<256>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(logmel_fft_kernel<512>, grid, dim3(256), 0, stream, a);
     WSEG_LAUNCH_CHECK();
   } else if (a.n_frames > 0) {
     dim3 grid(cdiv(a.n_frames, a.fpb), n_windows);

@@ -383,17 +383,19 @@ class WhisperSegmenter(SegmenterBase):
 
 
 class WhisperSegmenterFast(WhisperSegmenter):
-    """reference model.py:678-746 is the CTranslate2 backend, which computes in float16 on a GPU (model.py:691).  Here it is
-    the same engine pinned to IEEE half ("f16": half storage, MFMA, fp32 accumulation) — the 16-bit mode with the better
-    parity margin (profiles/: boundary deviations vs the fp32 reference).  A CTranslate2-converted directory (binary
-    `model.bin` + `hf_model/` without HF weights) cannot be read and raises, which makes `scripts/segment.py`'s
-    try-Fast-then-fallback idiom (reference scripts/segment.py:34-37) behave as it does upstream when ctranslate2 is
-    missing."""
+    """reference model.py:678-746 is the CTranslate2 backend (float16 on a GPU, model.py:691), which the reference's CLI and
+    evaluation try first (scripts/segment.py:34-37, evaluate.py:62-65).  Here it is the same MI355X engine as WhisperSegmenter and
+    — because those call sites make it the DEFAULT path of the CLI — it defaults to the same split-precision mode ("f16x3": rows
+    identical to the fp32 reference on the whole parity sweep).  `dtype="f16"` (or $WHISPERSEG_AMD_DTYPE=f16) selects what CT2
+    computes in: plain IEEE half, 1.9x faster, 96 % of the sweep recordings within +-1 mel frame.  A CTranslate2-converted
+    directory (binary `model.bin` + `hf_model/` without HF weights) cannot be read and raises, which makes the try-Fast-then-
+    fallback idiom behave as it does upstream when ctranslate2 is missing."""
 
-    def __init__(self, model_path, device=None, device_ids=[0, ]):
+    def __init__(self, model_path, device=None, device_ids=[0, ], dtype=None):
         model_dir = resolve_model_dir(model_path)
         checkpoint_files(model_dir)      # raises FileNotFoundError for a CTranslate2-only directory
-        super().__init__(model_path, device=device, device_ids=device_ids, dtype=os.environ.get("WHISPERSEG_AMD_DTYPE", "f16"))
+        super().__init__(model_path, device=device, device_ids=device_ids,
+                         dtype=dtype or os.environ.get("WHISPERSEG_AMD_DTYPE", DEFAULT_DTYPE))
 
 
 class WhisperSegmenterForEval(SegmenterBase):
