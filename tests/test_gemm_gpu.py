@@ -178,3 +178,23 @@ def test_f32_gemm_kernels_are_bit_identical(gpu_lib, tmp_path):
     for mode in ("mfma64", "valu128", "valu64"):
         for a, b in zip(outs["mfma"], outs[mode]):
             assert torch.equal(a, b), mode
+
+
+def test_f16x3_gemm_operands_saturate(gpu_lib):
+    """A GELU output (the fc2 operand) beyond the fp16 range saturates at 65504 in the f16x3 mode instead of poisoning the row
+    with inf - inf: epilogue 1 (GELU) writes operand rows, which are read back here."""
+    from whisperseg_amd import _lib
+    from whisperseg_amd.engine import DTYPES, split_operand, unsplit_operand
+    M, N, K = 256, 128, 64
+    A = torch.zeros(M, K, device="cuda"); A[:, 0] = 300.0
+    W = torch.zeros(N, K, device="cuda"); W[:, 0] = 300.0            # products of 90 000 > 65 504
+    W[1, 0] = 1.0
+    bias = torch.zeros(N, device="cuda")
+    out = torch.zeros((M, 2 * N), device="cuda", dtype=torch.int16)
+    ws = torch.empty(16 << 20, dtype=torch.uint8, device="cuda")
+    _lib.check(gpu_lib.wseg_debug_gemm(DTYPES["f16x3"][0], 1, M, N, K, split_operand(A, torch.float16).data_ptr(),
+                                       split_operand(W, torch.float16).data_ptr(), bias.data_ptr(), None, out.data_ptr(), ws.data_ptr(),
+                                       ws.numel(), _lib.stream_ptr()))
+    got = unsplit_operand(out, torch.float16)
+    assert torch.isfinite(got).all()
+    assert float(got[0, 0]) == 65504.0 and abs(float(got[0, 1]) - 300.0) < 1e-2

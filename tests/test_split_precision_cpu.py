@@ -42,3 +42,13 @@ def test_engine_layout_splits_only_gemm_matrices():
     plain = to_engine_layout(w, "f16")
     assert all(v.dtype == torch.float16 for v in plain.values())
     assert DTYPES["bf16x3"][0] == 3 and DTYPES["f16x3"][0] == 4
+
+
+def test_half_split_saturates_instead_of_overflowing():
+    """An operand beyond the fp16 range must not become inf - inf = NaN: it saturates at 65504 (what HF's own half path does to
+    its hidden states); bfloat16 halves have the fp32 range and keep the value."""
+    w = torch.tensor([[1.0e5, -3.0e6, 65504.0, 1.0] + [0.0] * 28])
+    back = unsplit_operand(split_operand(w, torch.float16), torch.float16)
+    assert torch.isfinite(back).all() and back[0, :4].tolist() == [65504.0, -65504.0, 65504.0, 1.0]
+    back = unsplit_operand(split_operand(w, torch.bfloat16), torch.bfloat16)
+    assert torch.allclose(back[0, :2], w[0, :2], rtol=2 ** -16)

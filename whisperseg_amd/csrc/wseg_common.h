@@ -56,6 +56,7 @@ template <> struct H16<bf16_t> {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_bf16x2));
   }
   static __device__ __forceinline__ bf16_t from(float f) { return (bf16_t)(pack(f, 0.f) & 0xffffu); }
+  static __device__ __forceinline__ float sat(float f) { return f; }      // bfloat16 has the fp32 exponent range
   static __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
   static __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
@@ -70,6 +71,9 @@ template <> struct H16<f16_t> {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_f16x2));
   }
   static __device__ __forceinline__ f16_t from(float f) { f16_t r; r.bits = (uint16_t)(pack(f, 0.f) & 0xffffu); return r; }
+  // split-precision operands saturate at the largest finite half instead of becoming inf - inf = NaN (v_med3_f32); HF's own
+  // half path clamps its hidden states the same way (modeling_whisper.py encoder layer)
+  static __device__ __forceinline__ float sat(float f) { return __builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f); }
   static __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(hw_f16x8, a), __builtin_bit_cast(hw_f16x8, b), c, 0, 0, 0);
   }
@@ -129,11 +133,13 @@ __host__ __device__ __forceinline__ int x3_col(int c) { return ((c >> 5) << 6) |
 
 // 8 consecutive logical columns (c % 8 == 0) <-> the two 16-byte pieces of a split row
 template <typename HT> __device__ __forceinline__ void split8(const float v[8], uint4& hi, uint4& lo) {
-  hi = pack8<HT>(v);
-  float h[8], r[8];
+  float s[8], h[8], r[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = H16<HT>::sat(v[e]);
+  hi = pack8<HT>(s);
   unpack8<HT>(hi, h);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) r[e] = v[e] - h[e];
+  for (int e = 0; e < 8; ++e) r[e] = s[e] - h[e];
   lo = pack8<HT>(r);
 }
 // Operand stores / loads.  base: start of the operand matrix, ld: LOGICAL row length, c: logical column.
@@ -144,6 +150,7 @@ template <typename T> struct Op {        // plain element types (float / 16-bit)
 template <typename HT> struct Op<X3<HT>> {
   static __device__ __forceinline__ void st1(void* base, size_t row, int ld, int c, float v) {
     uint16_t* p = (uint16_t*)base + row * (size_t)(2 * ld) + x3_col(c);
+    v = H16<HT>::sat(v);
     const HT h = H16<HT>::from(v);
     const HT l = H16<HT>::from(v - H16<HT>::one(h));
     p[0] = __builtin_bit_cast(uint16_t, h);
@@ -174,8 +181,9 @@ template <typename T> __device__ __forceinline__ void op_st4(void* base, size_t 
   if constexpr (IO<T>::split) {
     typedef typename IO<T>::H HT;
     uint16_t* p = (uint16_t*)base + row * (size_t)(2 * ld) + x3_col(c);
-    uint2 hi = make_uint2(H16<HT>::pack(v[0], v[1]), H16<HT>::pack(v[2], v[3]));
-    const float r0 = v[0] - H16<HT>::lo(hi.x), r1 = v[1] - H16<HT>::hi(hi.x), r2 = v[2] - H16<HT>::lo(hi.y), r3 = v[3] - H16<HT>::hi(hi.y);
+    const float s0 = H16<HT>::sat(v[0]), s1 = H16<HT>::sat(v[1]), s2 = H16<HT>::sat(v[2]), s3 = H16<HT>::sat(v[3]);
+    uint2 hi = make_uint2(H16<HT>::pack(s0, s1), H16<HT>::pack(s2, s3));
+    const float r0 = s0 - H16<HT>::lo(hi.x), r1 = s1 - H16<HT>::hi(hi.x), r2 = s2 - H16<HT>::lo(hi.y), r3 = s3 - H16<HT>::hi(hi.y);
     *(uint2*)p = hi;
     *(uint2*)(p + 32) = make_uint2(H16<HT>::pack(r0, r1), H16<HT>::pack(r2, r3));
   } else if constexpr (sizeof(T) == 4) {

@@ -34,6 +34,8 @@ def split_operand(w, base):
     if k % 32:
         raise ValueError("split_operand: K must be a multiple of 32")
     w = w.float()
+    if base == torch.float16:      # saturate instead of inf - inf = NaN (as the device-side producers do)
+        w = w.clamp(-65504.0, 65504.0)
     hi = w.to(base)
     lo = (w - hi.float()).to(base)
     out = torch.stack([hi.view(n, k // 32, 32), lo.view(n, k // 32, 32)], dim=2)
