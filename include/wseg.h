@@ -213,6 +213,12 @@ int wseg_last_timing(const wseg_model* m, float out[4]);
 int wseg_debug_gemm(int32_t dtype, int32_t epi, int32_t M, int32_t N, int32_t K, const void* A, const void* W,
                     const void* bias, const void* resid, void* out, void* splitk_ws, size_t splitk_ws_bytes, void* stream);
 
+/* Test / tuning tap of the decoder's fused step x += A W^T + bias; y = LayerNorm(x) * gamma + beta (x: fp32 residual stream [M][N],
+ * in place; y: GEMM operand rows of the dtype; bias / gamma / beta: parameter type of the dtype).  Same operand rules as
+ * wseg_debug_gemm.  Used by tests/test_gemm_gpu.py and tools/gemm_bench.py --resid-ln. */
+int wseg_debug_gemm_resid_ln(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, const void* W, const void* bias, void* x,
+                             const void* gamma, const void* beta, void* y, void* splitk_ws, size_t splitk_ws_bytes, void* stream);
+
 /* Live per-launch timing of the dominant kernel (the 256x256 ping-pong bf16 MFMA GEMM; 128x128 persistent for narrow problems) with HIP events recorded on
  * the launching stream.  Between begin and end every launch of that kernel is bracketed by two events;
  * end synchronises and returns the sums: algorithmic FLOPs (2*M*N*K of the real, un-padded problem),

@@ -198,3 +198,46 @@ def test_f16x3_gemm_operands_saturate(gpu_lib):
     got = unsplit_operand(out, torch.float16)
     assert torch.isfinite(got).all()
     assert float(got[0, 0]) == 65504.0 and abs(float(got[0, 1]) - 300.0) < 1e-2
+
+
+RESID_LN_SHAPES = [  # M, N, K: skinny split-K + fused reduction (<= 1024 rows), 256x256 ping-pong split-K (long K, 2048+ rows:
+    # uneven K-tile shares 27/27/26, 13/13/.., ragged last row tile), un-split GEMM + separate LayerNorm
+    (32, 1280, 1280), (480, 1280, 5120), (1024, 1280, 5120), (2048, 1280, 5120), (4096, 1280, 5120), (4000, 1280, 5120),
+    (3072, 1280, 5120), (4096, 1280, 1280), (2100, 768, 3072), (5120, 1280, 5120),
+]
+
+
+@pytest.mark.parametrize("M,N,K", RESID_LN_SHAPES)
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f16x3", "f32"])
+def test_gemm_resid_layernorm_step(gpu_lib, M, N, K, dtype):
+    """The decoder's fused step x += A W^T + b; y = LayerNorm(x) through every kernel family the row count selects."""
+    from whisperseg_amd import _lib
+    from whisperseg_amd.engine import DTYPES, SPLIT_BASE, split_operand, unsplit_operand
+    if dtype == "f32" and M * N * K > 3e9:
+        pytest.skip("f32 exact kernel is for small problems")
+    x3 = dtype in SPLIT_BASE
+    td = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f16x3": torch.float32}[dtype]
+    g = torch.Generator(device="cuda").manual_seed(M * 13 + N * 5 + K)
+    Mp = (M + 255) // 256 * 256
+    A = (torch.rand(Mp, K, device="cuda", generator=g) * 2 - 1).to(td)
+    W = ((torch.rand(N, K, device="cuda", generator=g) * 2 - 1) * K ** -0.5).to(td)
+    bias = (torch.rand(N, device="cuda", generator=g) - 0.5).to(td)
+    gam = (torch.rand(N, device="cuda", generator=g) + 0.5).to(td)
+    bet = (torch.rand(N, device="cuda", generator=g) - 0.5).to(td)
+    x0 = (torch.rand(Mp, N, device="cuda", generator=g) - 0.5)
+    x = x0.clone()
+    Ao, Wo = (split_operand(A, SPLIT_BASE[dtype]), split_operand(W, SPLIT_BASE[dtype])) if x3 else (A, W)
+    y = torch.full((Mp, 2 * N if x3 else N), float("nan"), device="cuda", dtype=td) if not x3 else \
+        torch.full((Mp, 2 * N), 0x7e00, device="cuda", dtype=torch.int16)        # NaN halves
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    _lib.check(gpu_lib.wseg_debug_gemm_resid_ln(DTYPES[dtype][0], M, N, K, Ao.data_ptr(), Wo.data_ptr(), bias.data_ptr(), x.data_ptr(),
+                                                gam.data_ptr(), bet.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+    xr = x0[:M].double() + A[:M].double() @ W.double().T + bias.double()
+    yr = torch.nn.functional.layer_norm(xr, (N,), gam.double(), bet.double(), 1e-5)
+    tol = {"bf16": 2e-2, "f16": 3e-3, "f32": 2e-5, "f16x3": 2e-5}[dtype]
+    # x is the fp32 residual stream in every mode: products of exactly representable operands, fp32 accumulation
+    assert (x[:M].double() - xr).abs().max().item() <= 2e-5 * max(1.0, xr.abs().max().item())
+    got = (unsplit_operand(y[:M], SPLIT_BASE[dtype]) if x3 else y[:M]).double()
+    assert torch.isfinite(got).all()
+    assert (got - yr).abs().max().item() <= tol * max(1.0, yr.abs().max().item())
+    assert torch.equal(x[M:], x0[M:])                                    # rows beyond M untouched

@@ -38,7 +38,7 @@ def two_layer():
     cfg = large_cfg(2)
     rc = R.RefConfig.from_hf_dict(cfg)
     sd = {k: v.to(torch.bfloat16).float() for k, v in R.random_state_dict(rc, seed=31, fast=True).items()}
-    engines = {dt: Engine.from_state_dict(sd, cfg, "cuda:0", dt) for dt in ("f32", "bf16", "f16")}
+    engines = {dt: Engine.from_state_dict(sd, cfg, "cuda:0", dt) for dt in ("f32", "bf16", "f16", "f16x3", "bf16x3")}
     return cfg, rc, sd, engines
 
 
@@ -93,6 +93,11 @@ def test_two_layer_8_windows_vs_oracle(gpu_lib, two_layer):
             assert (got16 - want_logits).abs().max().item() <= rel * max(1.0, want_logits.abs().max().item()), dt
             if nb == 4:
                 assert torch.equal(got16[0::4], got16[1::4]) and torch.equal(got16[0::4], got16[3::4])
+        # split-precision modes (8 slots x 20 heads: the few-slot cross-attention, 4 workgroups per (slot, head) over 24-bit K / V)
+        for dt, rel in (("f16x3", 1e-4), ("bf16x3", 1e-3)):
+            t3, l3, got3 = gen(engines[dt], x, nb, 10, return_first_logits=True)
+            assert (got3.cpu() - want_logits).abs().max().item() <= rel * max(1.0, want_logits.abs().max().item()), dt
+            assert all(int(t3[i, 3]) == int(want_tok[i][3]) for i in range(8)), (dt, nb)
 
 
 def test_two_layer_256_windows_1024_rows_vs_oracle(gpu_lib, two_layer):

@@ -12,7 +12,7 @@ ap.add_argument("--encoder-only", action="store_true")
 ap.add_argument("--decoder-only", action="store_true")
 ap.add_argument("--rotate", type=int, default=1, help="cycle through this many weight copies (cold weights, as in a decode step)")
 ap.add_argument("--vs-torch", action="store_true", help="also time torch's F.linear (hipBLASLt) on the same operands: calibration of what the box can do, never a product path")
-ap.add_argument("--shapes", default="", help="custom list 'M,N,K,epi;M,N,K,epi;...' (epi 0 bias, 1 bias+gelu, 2 bias+residual)")
+ap.add_argument("--shapes", default="", help="custom list 'M,N,K,epi;M,N,K,epi;...' (epi 0 bias, 1 bias+gelu, 2 bias+residual, 3 the decoder's fused bias+residual+LayerNorm step)")
 a = ap.parse_args()
 lib = _lib.load(require_device=True)
 d, f = 1280, 5120
@@ -27,7 +27,7 @@ if a.decoder_only:
     shapes = [sh for sh in shapes if sh[0].startswith('dec') or sh[0].startswith('lm')]
 if a.shapes:
     shapes = [("custom",) + tuple(int(v) for v in item.split(",")) for item in a.shapes.split(";") if item]
-ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+ws = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
 for name, m, n, k, epi in shapes:
     mp = (m + 255) // 256 * 256
     A = (torch.rand(mp, k, device="cuda") * 2 - 1).to(torch.bfloat16)
@@ -35,13 +35,19 @@ for name, m, n, k, epi in shapes:
     Ws = [W] + [W.clone() for _ in range(a.rotate - 1)]
     call = [0]
     bias = torch.rand(n, device="cuda").to(torch.bfloat16)
-    od = torch.float32 if epi == 2 else torch.bfloat16       # the residual-stream epilogue reads / writes fp32
+    od = torch.float32 if epi >= 2 else torch.bfloat16       # the residual-stream epilogue reads / writes fp32
+    gam, bet = torch.rand(n, device="cuda").to(torch.bfloat16), torch.rand(n, device="cuda").to(torch.bfloat16)
+    y = torch.empty(mp, n, device="cuda", dtype=torch.bfloat16)
     res = torch.rand(mp, n, device="cuda").to(od)
     out = torch.empty(mp, n, device="cuda", dtype=od)
     st = _lib.stream_ptr()
 
     def run():
         call[0] += 1
+        if epi == 3:
+            _lib.check(lib.wseg_debug_gemm_resid_ln(1, m, n, k, A.data_ptr(), Ws[call[0] % len(Ws)].data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                                    gam.data_ptr(), bet.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), st))
+            return
         _lib.check(lib.wseg_debug_gemm(1, epi, m, n, k, A.data_ptr(), Ws[call[0] % len(Ws)].data_ptr(), bias.data_ptr(), res.data_ptr(),
                                        out.data_ptr(), ws.data_ptr(), ws.numel(), st))
     for _ in range(3):
@@ -52,9 +58,11 @@ for name, m, n, k, epi in shapes:
         run()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / a.iters * 1e3
+    if epi == 3:
+        out.copy_(res); run()
     ref = (A[:m].float() @ W.float().T + bias.float())
     if epi == 1: ref = torch.nn.functional.gelu(ref)
-    if epi == 2: ref = ref + res[:m].float()
+    if epi >= 2: ref = ref + res[:m].float()
     err = (out[:m].float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-9)
     gb = (m * k + n * k + m * n * (2 if epi == 2 else 1)) * 2 / 1e9
     lt = ""

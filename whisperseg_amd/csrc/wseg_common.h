@@ -213,14 +213,38 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 template <typename T> __device__ __forceinline__ float gelu_for(float x) { return gelu_erf_fast(x); }      // 16-bit modes
 template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }
 
+// Value of lane (l ^ M) of a wave64 WITHOUT the LDS crossbar: __shfl_xor compiles to ds_bpermute_b32 + s_waitcnt, ~60-100 cycles
+// of exposed latency each — the 96 of them that close a cross-attention workgroup were 5.7 of its 14 us at 8 slots (in-kernel
+// s_memrealtime stamps).  M = 1, 2: DPP quad_perm; 4: row_shl:4 / row_shr:4 under bank masks; 8: row_ror:8; 16, 32: gfx950's
+// v_permlane16_swap / v_permlane32_swap.  Every one is the exact exchange, so a + lane_xor<M>(a) is bit-equal to the shuffle form.
+template <int M> __device__ __forceinline__ unsigned lane_xor_u(unsigned v) {
+  static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "power of two below the wave size");
+  const int x = (int)v;
+  if constexpr (M == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+  else if constexpr (M == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  else if constexpr (M == 4) {
+    const int t = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xF, 0x5, false);                             // row_shl:4 -> banks 0, 2 (lanes 0-3, 8-11 take l + 4)
+    return (unsigned)__builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);                          // row_shr:4 -> banks 1, 3 (lanes 4-7, 12-15 take l - 4)
+  } else if constexpr (M == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, true); // row_ror:8
+  else if constexpr (M == 16) {
+    // swap(first.row1, second.row0) per half: first -> {row0, row0}, second -> {row1, row1}; lane l of row r wants row r ^ 1
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (__lane_id() & 16) ? r[0] : r[1];
+  } else {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (__lane_id() & 32) ? r[0] : r[1];
+  }
+}
+template <int M> __device__ __forceinline__ float lane_xor(float v) { return __uint_as_float(lane_xor_u<M>(__float_as_uint(v))); }
+template <int M> __device__ __forceinline__ int lane_xor(int v) { return (int)lane_xor_u<M>((unsigned)v); }
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += lane_xor<32>(v); v += lane_xor<16>(v); v += lane_xor<8>(v); v += lane_xor<4>(v); v += lane_xor<2>(v); v += lane_xor<1>(v);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = fmaxf(v, lane_xor<32>(v)); v = fmaxf(v, lane_xor<16>(v)); v = fmaxf(v, lane_xor<8>(v));
+  v = fmaxf(v, lane_xor<4>(v)); v = fmaxf(v, lane_xor<2>(v)); v = fmaxf(v, lane_xor<1>(v));
   return v;
 }
 

@@ -120,6 +120,23 @@ __device__ __forceinline__ void reduce8(const PartialInfo& pi, int row, int col,
   }
 }
 
+// One value, same sum (z = 0, 1, ... then the bias): every split's load is issued before the first add.  reduce8 above walks the
+// splits two at a time — with 10 splits that is five DEPENDENT round trips to partials the previous kernel left in memory, per
+// call; at 8 slots the four per-beam calls of the cross-attention made up most of its 23.5 us.  The attention kernels now
+// reduce one value per thread (all loads in flight at once) and hand the result round through LDS.
+template <typename T>
+__device__ __forceinline__ float reduce1(const PartialInfo& pi, int row, int col, const T* bias) {
+  const float* pp = pi.part + (size_t)row * pi.n + col;
+  const size_t zs = (size_t)pi.m_pad * pi.n;
+  float t[16];                                           // plan_skinny: at most 16 splits
+#pragma unroll
+  for (int z = 0; z < 16; ++z) t[z] = pp[(size_t)min(z, pi.splits - 1) * zs];
+  float v = 0.f;
+#pragma unroll
+  for (int z = 0; z < 16; ++z) { if (z < pi.splits) v += t[z]; }
+  return bias ? v + El<T>::ld(bias + col) : v;
+}
+
 template <typename T> __device__ __forceinline__ void store8(T* p, const float v[8]) { *(uint4*)p = pack8<T>(v); }
 template <> __device__ __forceinline__ void store8<float>(float* p, const float v[8]) {
   ((float4*)p)[0] = make_float4(v[0], v[1], v[2], v[3]);
@@ -143,6 +160,7 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
   __shared__ float sp[512];
   __shared__ int srow[512];
   __shared__ float snk[64], snv[64];        // this step's own key / value (fused-reduction path)
+  __shared__ float sq[64];                  // ... and query
   const int lane = threadIdx.x, sub = lane & 7, rowl = lane >> 3;
   const int r = blockIdx.x / H, h = blockIdx.x - r * H;
   const int w = r / st.nb;
@@ -152,28 +170,28 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
   float qv[8];
   const bool fused = pi.part != nullptr;
   if (fused) {
-    // finish the split-K reduction of q | k | v for this (row, head); values are rounded to the storage type
-    // exactly as the unfused epilogue would have stored and re-loaded them
-    reduce8<T>(pi, r, h * 64 + sub * 8, qkv_bias, qv);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) qv[e] = El<T>::rnd(qv[e] * scale);
-    if (rowl < 2) {
-      float nv[8];
-      reduce8<T>(pi, r, (rowl + 1) * d + h * 64 + sub * 8, qkv_bias, nv);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) nv[e] = El<T>::rnd(nv[e]);
-      T* dst = (rowl == 0 ? kc : vc) + (((size_t)r * H + h) * L + (n - 1)) * 64 + sub * 8;
-      store8<T>(dst, nv);
-      float* sh = rowl == 0 ? snk : snv;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) sh[sub * 8 + e] = nv[e];
-    }
+    // finish the split-K reduction of q | k | v for this (row, head): lane e owns dim e of each (all 3 x splits loads in flight
+    // together, reduce1); values are rounded to the storage type exactly as the unfused epilogue would have stored and
+    // re-loaded them.  The query slices are read back from LDS behind the barrier below.
+    const float q1 = reduce1<T>(pi, r, h * 64 + lane, qkv_bias);
+    const float k1 = El<T>::rnd(reduce1<T>(pi, r, d + h * 64 + lane, qkv_bias));
+    const float v1 = El<T>::rnd(reduce1<T>(pi, r, 2 * d + h * 64 + lane, qkv_bias));
+    sq[lane] = El<T>::rnd(q1 * scale);
+    const size_t at = (((size_t)r * H + h) * L + (n - 1)) * 64 + lane;
+    El<T>::st(kc + at, k1);
+    El<T>::st(vc + at, v1);
+    snk[lane] = k1;
+    snv[lane] = v1;
   } else {
     load8<T>(q + (size_t)r * d + h * 64 + sub * 8, qv);
   }
   const unsigned char* anc = st.anc + (size_t)r * L;
   for (int t = lane; t < n; t += 64) srow[t] = w * st.nb + (t == n - 1 ? (r - w * st.nb) : (int)anc[t]);
   __syncthreads();
+  if (fused) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] = sq[sub * 8 + e];
+  }
   // The V rows of the first 32 positions are requested together with the K rows (both depend only on the ancestry
   // table): a wave is one chain of dependent HBM round trips, and this removes one of them for sequences <= 32.
   float vfirst[4][8];
@@ -242,9 +260,9 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     float a = acc[e];
-    a += __shfl_xor(a, 8, 64);
-    a += __shfl_xor(a, 16, 64);
-    a += __shfl_xor(a, 32, 64);
+    a += lane_xor<8>(a);
+    a += lane_xor<16>(a);
+    a += lane_xor<32>(a);
     acc[e] = a;
   }
   if (rowl == 0) {
@@ -278,12 +296,13 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_kernel(DecodeState st, 
   // this lane's 8-dim slice of every beam's (pre-scaled) query
   float qv[NB][8];
   if (pi.part != nullptr) {
+    __shared__ float sq[NB][64];                        // thread (j, e) finishes dim e of beam j (reduce1), slices come back from LDS
+    if (tid < NB * 64) sq[tid >> 6][tid & 63] = El<T>::rnd(reduce1<T>(pi, w * nb + min(tid >> 6, nb - 1), h * 64 + (tid & 63), q_bias) * scale);
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      reduce8<T>(pi, w * nb + min(j, nb - 1), h * 64 + sub * 8, q_bias, qv[j]);
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) qv[j][e] = El<T>::rnd(qv[j][e] * scale);
-    }
+      for (int e = 0; e < 8; ++e) qv[j][e] = sq[j][sub * 8 + e];
   } else {
 #pragma unroll
     for (int j = 0; j < NB; ++j) load8<T>(q + (size_t)(w * nb + min(j, nb - 1)) * d + h * 64 + sub * 8, qv[j]);
@@ -354,9 +373,9 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_kernel(DecodeState st, 
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float a = acc[j][e];
-      a += __shfl_xor(a, 8, 64);
-      a += __shfl_xor(a, 16, 64);
-      a += __shfl_xor(a, 32, 64);
+      a += lane_xor<8>(a);
+      a += lane_xor<16>(a);
+      a += lane_xor<32>(a);
       acc[j][e] = a;
     }
   if (rowl == 0) {
@@ -404,16 +423,28 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
   const HT* Vb = cv + ((size_t)w * H + h) * Tk * 64;
   // this lane's 8-dim slice of every beam's (pre-scaled) query, fp32, beams paired for v_pk_fma_f32: qq[e][j2] holds
   // dim e of beams 2*j2 and 2*j2+1
+  // rows t0 + u*32 + wave*8 + rowl (clamped: out-of-range rows are discarded where they are used), 16 bytes per lane
+  auto load_rows = [&](const HT* base, int t0, raw16 (&r)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = min(t0 + u * 32 + wave * 8 + rowl, Tk - 1);
+      r[u] = __builtin_nontemporal_load((const raw16*)(base + (size_t)t * 64 + sub * 8));
+    }
+  };
   constexpr int NP = (NB + 1) / 2;
   f2 qq[8][NP];
+  __shared__ float sq[NB][64];                          // thread (j, e) finishes dim e of beam j (reduce1), slices come back from LDS
+  if (pi.part != nullptr) {
+    if (tid < NB * 64) sq[tid >> 6][tid & 63] = El<HT>::rnd(reduce1<HT>(pi, w * nb + min(tid >> 6, nb - 1), h * 64 + (tid & 63), q_bias) * scale);
+    __syncthreads();
+  }
   {
     float qv[8];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       if (pi.part != nullptr) {
-        reduce8<HT>(pi, w * nb + min(j, nb - 1), h * 64 + sub * 8, q_bias, qv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) qv[e] = El<HT>::rnd(qv[e] * scale);
+        for (int e = 0; e < 8; ++e) qv[e] = sq[j][sub * 8 + e];
       } else {
         load8<HT>(q + (size_t)(w * nb + min(j, nb - 1)) * d + h * 64 + sub * 8, qv);
       }
@@ -440,11 +471,7 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
   }
   for (int t0 = 0; t0 < Tk; t0 += 32 * U) {
     raw16 kr[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int t = min(t0 + u * 32 + wave * 8 + rowl, Tk - 1);      // clamped: out-of-range rows are discarded below
-      kr[u] = __builtin_nontemporal_load((const raw16*)(Kb + (size_t)t * 64 + sub * 8));
-    }
+    load_rows(Kb, t0, kr);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int t = t0 + u * 32 + wave * 8 + rowl;
@@ -509,11 +536,7 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
     for (int e = 0; e < 4; ++e) acc[j][e] = (f2){0.f, 0.f};
   for (int t0 = 0; t0 < Tk; t0 += 32 * U) {
     raw16 vr[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int t = min(t0 + u * 32 + wave * 8 + rowl, Tk - 1);
-      vr[u] = __builtin_nontemporal_load((const raw16*)(Vb + (size_t)t * 64 + sub * 8));
-    }
+    load_rows(Vb, t0, vr);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int t = t0 + u * 32 + wave * 8 + rowl;
@@ -549,9 +572,9 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float a = acc[j][e >> 1][e & 1];
-      a += __shfl_xor(a, 8, 64);
-      a += __shfl_xor(a, 16, 64);
-      a += __shfl_xor(a, 32, 64);
+      a += lane_xor<8>(a);
+      a += lane_xor<16>(a);
+      a += lane_xor<32>(a);
       if (rowl == 0) red[wave][j][sub * 8 + e] = a;
     }
   __syncthreads();
@@ -591,14 +614,18 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_k24_kernel(DecodeState 
   const unsigned char* Vl = Vb + (size_t)Tk * 128;
   constexpr int NP = (NB + 1) / 2;
   f2 qq[8][NP];
+  __shared__ float sq[NB][64];                          // thread (j, e) finishes dim e of beam j (reduce1), slices come back from LDS
+  if (pi.part != nullptr) {
+    if (tid < NB * 64) sq[tid >> 6][tid & 63] = reduce1<float>(pi, w * nb + min(tid >> 6, nb - 1), h * 64 + (tid & 63), q_bias) * scale;
+    __syncthreads();
+  }
   {
     float qv[8];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       if (pi.part != nullptr) {
-        reduce8<float>(pi, w * nb + min(j, nb - 1), h * 64 + sub * 8, q_bias, qv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) qv[e] *= scale;
+        for (int e = 0; e < 8; ++e) qv[e] = sq[j][sub * 8 + e];
       } else {
         load8<float>(q + (size_t)(w * nb + min(j, nb - 1)) * d + h * 64 + sub * 8, qv);
       }
@@ -705,9 +732,9 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_k24_kernel(DecodeState 
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float a = acc[j][e >> 1][e & 1];
-      a += __shfl_xor(a, 8, 64);
-      a += __shfl_xor(a, 16, 64);
-      a += __shfl_xor(a, 32, 64);
+      a += lane_xor<8>(a);
+      a += lane_xor<16>(a);
+      a += lane_xor<32>(a);
       if (rowl == 0) red[wave][j][sub * 8 + e] = a;
     }
   __syncthreads();

@@ -697,9 +697,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h16_persist_kernel(const ty
 // leaves buffer e & 1 to the epilogue as its staging area: the B pair of K tile e+2 is held back to phase 1 of K tile
 // e+1, which both groups reach only after the barrier that closes the (shared) epilogue interval.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int EPI, bool STAGED_RESID = false>
+// SPLITK (decoder rows, too few 256x256 output tiles for the chip): the tile space is S copies of the m x n tile grid; copy z
+// multiplies K tiles [z nk / S, (z + 1) nk / S) and stores its fp32 partial tile at out_f32 + z M N (EPI_F32, no bias); the
+// caller's reduction kernel (splitk_reduce_resid_ln_kernel) sums the S planes.
+template <typename T, int EPI, bool STAGED_RESID = false, bool SPLITK = false>
 __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::H* __restrict__ A, int lda, const typename IO<T>::H* __restrict__ W,
-                                                          int ldw, int M, int N, int K, EpiParams ep, int ntm, int GM) {
+                                                          int ldw, int M, int N, int K, EpiParams ep, int ntm, int GM, int S) {
   typedef typename IO<T>::H HT;
   constexpr bool X3M = IO<T>::split;      // hi | lo K tiles: 24 instead of 16 MFMAs per phase, (W hi, A hi) (W hi, A lo) (W lo, A hi)
   // Residual epilogue without LDS and without barriers (EPI_RESID, opt-in: WSEG_PP_DIRECT_RESID=1; the LDS-staged one is the
@@ -719,14 +722,22 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int fr = lane & 15, fg = lane >> 4;
-  const int ntn = N / BN, ntiles = ntm * ntn, nk = K / BK;
+  const int ntn = N / BN, ntmn = ntm * ntn, ntiles = SPLITK ? ntmn * S : ntmn, nk = K / BK;
   const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3, bpx = gridDim.x >> 3;
   const int q = ntiles >> 3, r = ntiles & 7;
   const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   const int count = q + (xcd < r ? 1 : 0);
   if (loc >= count) return;
-  const int KT = ((count - loc + bpx - 1) / bpx) * nk;      // K tiles this workgroup consumes
+  // split-K: copy z of the tile grid owns K tiles [k_first(z), k_first(z + 1))
+  auto tile_z = [&](int swz) { return SPLITK ? swz / ntmn : 0; };
+  auto k_first = [&](int z) { return SPLITK ? z * nk / S : 0; };
+  int KT = ((count - loc + bpx - 1) / bpx) * nk;            // K tiles this workgroup consumes
+  if constexpr (SPLITK) {
+    KT = 0;
+    for (int i = loc; i < count; i += bpx) { const int z = tile_z(start + i); KT += k_first(z + 1) - k_first(z); }
+  }
   auto tile_coords = [&](int swz, int& m0, int& n0) {
+    if constexpr (SPLITK) swz -= tile_z(swz) * ntmn;
     const int per_group = GM * ntn, grp = swz / per_group, rem = swz - grp * per_group;
     const int gm = min(GM, ntm - grp * GM);
     m0 = (grp * GM + rem % gm) * BM;
@@ -742,36 +753,39 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   int tm, tn;
   tile_coords(start + loc, tm, tn);
   size_t ca_row = (size_t)tm * lda, cb_row = (size_t)tn * ldw;                    // scalar
+  int ca_k0 = k_first(tile_z(start + loc)), ca_nk = SPLITK ? k_first(tile_z(start + loc) + 1) - ca_k0 : nk, cb_k0 = ca_k0, cb_nk = ca_nk;
   auto issue_a = [&](int half) {                       // half-tile A<half> of K tile ca_g; the cursor advances after A1
     HT* dst = smem + (ca_g & 1) * BUF + half * HTILE + wave * 512;
-    const HT* src = A + (ca_row + (size_t)(half * 128) * lda + ca_kt * BK) + a_lane;
+    const HT* src = A + (ca_row + (size_t)(half * 128) * lda + ((SPLITK ? ca_k0 : 0) + ca_kt) * BK) + a_lane;
     WSEG_GLDS16(src, dst);
     WSEG_GLDS16(src + (size_t)64 * lda, dst + 4096);
     if (half == 1) {
       ++ca_g;
-      if (++ca_kt == nk) {
+      if (++ca_kt == (SPLITK ? ca_nk : nk)) {
         ca_kt = 0;
         ca_idx += bpx;
         if (ca_idx < count) {
           tile_coords(start + ca_idx, tm, tn);
           ca_row = (size_t)tm * lda;
+          if constexpr (SPLITK) { const int z = tile_z(start + ca_idx); ca_k0 = k_first(z); ca_nk = k_first(z + 1) - ca_k0; }
         }
       }
     }
   };
   auto issue_b = [&](int half) {
     HT* dst = smem + (cb_g & 1) * BUF + (2 + half) * HTILE + wave * 512;
-    const HT* src = W + (cb_row + (size_t)(half * 128) * ldw + cb_kt * BK) + w_lane;
+    const HT* src = W + (cb_row + (size_t)(half * 128) * ldw + ((SPLITK ? cb_k0 : 0) + cb_kt) * BK) + w_lane;
     WSEG_GLDS16(src, dst);
     WSEG_GLDS16(src + (size_t)64 * ldw, dst + 4096);
     if (half == 1) {
       ++cb_g;
-      if (++cb_kt == nk) {
+      if (++cb_kt == (SPLITK ? cb_nk : nk)) {
         cb_kt = 0;
         cb_idx += bpx;
         if (cb_idx < count) {
           tile_coords(start + cb_idx, tm, tn);
           cb_row = (size_t)tn * ldw;
+          if constexpr (SPLITK) { const int z = tile_z(start + cb_idx); cb_k0 = k_first(z); cb_nk = k_first(z + 1) - cb_k0; }
         }
       }
     }
@@ -827,6 +841,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   for (int idx = loc; idx < count; idx += bpx) {
   int m0, n0;
   tile_coords(start + idx, m0, n0);
+  const int tz = tile_z(start + idx), nkt = SPLITK ? k_first(tz + 1) - k_first(tz) : nk;
   if (!(DIRECT && direct)) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -834,9 +849,9 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
       for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 #pragma nounroll
-  for (int kt = 0; kt < nk; ++kt, ++g) {
+  for (int kt = 0; kt < nkt; ++kt, ++g) {
     // direct epilogue: the K-tile stream never pauses at an output-tile boundary (no staging buffer to protect)
-    const bool first = !(DIRECT && direct) && kt == 0 && g > 0, final = !(DIRECT && direct) && kt == nk - 1;
+    const bool first = !(DIRECT && direct) && kt == 0 && g > 0, final = !(DIRECT && direct) && kt == nkt - 1;
     const HT* cur = smem + (g & 1) * BUF;
     bf16x8 afr[4][2], bfr[NI][2];
     // ---- phase 0: b0, a0 -> quadrant (a0, b0) ----
@@ -912,7 +927,13 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
         }
   } else {
     if (wr == 0) __builtin_amdgcn_s_barrier();
-    staged_epilogue<T, EPI, MI, NI>(acc, (float*)(smem + ((g - 1) & 1) * BUF), ep, M, m0 + wr * TM, n0 + wc * TN, lane, wave);
+    if constexpr (SPLITK) {
+      EpiParams epz = ep;
+      epz.out_f32 = ep.out_f32 + (size_t)tz * M * N;
+      staged_epilogue<T, EPI, MI, NI>(acc, (float*)(smem + ((g - 1) & 1) * BUF), epz, M, m0 + wr * TM, n0 + wc * TN, lane, wave);
+    } else {
+      staged_epilogue<T, EPI, MI, NI>(acc, (float*)(smem + ((g - 1) & 1) * BUF), ep, M, m0 + wr * TM, n0 + wc * TN, lane, wave);
+    }
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();
   }
@@ -1371,10 +1392,10 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
         static const bool resid_staged = getenv("WSEG_PP_DIRECT_RESID") == nullptr;
         if (EPI == EPI_RESID && resid_staged)
           hipLaunchKernelGGL((gemm_h16_pp_kernel<T, EPI, true>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K, g.ep, ntm,
-                             group_m);
+                             group_m, 1);
         else
           hipLaunchKernelGGL((gemm_h16_pp_kernel<T, EPI, false>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K, g.ep, ntm,
-                             group_m);
+                             group_m, 1);
       } else if (persist) {
         int grid = ntiles < n_cu ? ntiles : n_cu;
         grid &= ~7;
@@ -1489,11 +1510,49 @@ int launch_gemm_partial(int dtype, const GemmArgs& g, PartialInfo* info, bool* o
 
 // x = x + (A W^T + bias); y = LayerNorm(x) * gamma + beta.   MFMA decoder rows: split-K partials + ONE fused
 // reduction/residual/LayerNorm kernel; otherwise the generic GEMM (EPI_RESID) followed by launch_layernorm.
+// Split-K on the 256x256 ping-pong kernel for decoder rows with a long K and too few output tiles for the chip (fc2 at 4096
+// rows: 16 x 5 = 80 tiles on 256 CUs; the 128x64 stream kernel needs 99 us for it, hipBLASLt 56): S = n_cu / tiles copies of the
+// tile grid, each multiplying 1/S of the K tiles into an fp32 partial plane.  Returns 0 when the shape does not qualify.
+template <typename T> static int pp_splitk_plan(const GemmArgs& g) {
+  static const int min_rows = getenv("WSEG_PP_SPLITK_MIN_ROWS") ? atoi(getenv("WSEG_PP_SPLITK_MIN_ROWS")) : 2048;   // tuning knobs
+  static const int min_kt = getenv("WSEG_PP_SPLITK_MIN_KT") ? atoi(getenv("WSEG_PP_SPLITK_MIN_KT")) : 40;
+  if (g.M < min_rows || g.N % 256 || g.K % 64 || g.K / 64 < min_kt || !g.splitk_ws) return 0;
+  const int nt = cdiv(g.M, 256) * (g.N / 256), nk = g.K / 64, n_cu = device_cu_count();
+  int S = n_cu / nt;
+  while (S >= 2 && ((nt * S) % 8 || nk / S < 4 || (size_t)S * g.M * g.N * sizeof(float) > g.splitk_ws_bytes)) --S;
+  return S >= 2 ? S : 0;
+}
+
+template <typename T> static int launch_pp_splitk(const GemmArgs& g, int S, hipStream_t s) {
+  typedef typename IO<T>::H HT;
+  static const int group_m = getenv("WSEG_GEMM_GROUP_M") ? atoi(getenv("WSEG_GEMM_GROUP_M")) : 4;
+  const int ntm = cdiv(g.M, 256), ntiles = ntm * (g.N / 256) * S, n_cu = device_cu_count();
+  int grid = ntiles < n_cu ? ntiles : n_cu;
+  grid &= ~7;
+  EpiParams ep;
+  ep.out_f32 = g.splitk_ws; ep.ldc = g.N;
+  hipLaunchKernelGGL((gemm_h16_pp_kernel<T, EPI_F32, false, true>), dim3(grid), dim3(512), 0, s, (const HT*)g.A, g.lda, (const HT*)g.W, g.ldw,
+                     g.M, g.N, g.K, ep, ntm, group_m, S);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+
 template <typename T>
 static int gemm_resid_ln_t(const GemmArgs& g0, const void* gamma, const void* beta, void* y, bool* done, hipStream_t s) {
   typedef typename IO<T>::P PT;
   const GemmArgs g = kernel_view<T>(g0);
   const int d = g.N;
+  if (d % 8 == 0 && d <= 2048 && g.ep.bias && g.ep.resid == g.ep.out && g.ep.ldc == d && !big_tile_path(g)) {
+    const int S = pp_splitk_plan<T>(g);
+    if (S) {
+      WSEG_TRY_(launch_pp_splitk<T>(g, S, s));
+      hipLaunchKernelGGL(splitk_reduce_resid_ln_kernel<T>, dim3(g.M), dim3(256), 0, s, g.splitk_ws, S, g.M, g.M, d, (const PT*)g.ep.bias,
+                         (float*)g.ep.out, (const PT*)gamma, (const PT*)beta, y);
+      WSEG_LAUNCH_CHECK();
+      *done = true;
+      return WSEG_OK;
+    }
+  }
   if (big_tile_path(g) || !g.splitk_ws || d % 8 || d > 2048 || !g.ep.bias || g.ep.resid != g.ep.out || g.ep.ldc != d || g.K % 64 ||
       g.N % 64)
     return WSEG_OK;
@@ -1553,6 +1612,18 @@ extern "C" int wseg_debug_gemm(int32_t dtype, int32_t epi, int32_t M, int32_t N,
   g.ep.bias = bias; g.ep.out = out; g.ep.ldc = N; g.ep.resid = resid;
   g.splitk_ws = (float*)splitk_ws; g.splitk_ws_bytes = splitk_ws_bytes;
   return launch_gemm(dtype, epi == 0 ? EPI_STORE : (epi == 1 ? EPI_GELU : EPI_RESID), g, (hipStream_t)stream);
+}
+
+extern "C" int wseg_debug_gemm_resid_ln(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, const void* W, const void* bias,
+                                        void* x, const void* gamma, const void* beta, void* y, void* splitk_ws, size_t splitk_ws_bytes,
+                                        void* stream) {
+  using namespace wseg;
+  if (!A || !W || !bias || !x || !gamma || !beta || !y || M <= 0 || N <= 0 || K <= 0) { set_error("wseg_debug_gemm_resid_ln: bad argument"); return WSEG_ERR_INVALID; }
+  GemmArgs g;
+  g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K;
+  g.ep.bias = bias; g.ep.out = x; g.ep.resid = x; g.ep.ldc = N;
+  g.splitk_ws = (float*)splitk_ws; g.splitk_ws_bytes = splitk_ws_bytes;
+  return launch_gemm_resid_ln(dtype, g, gamma, beta, y, (hipStream_t)stream);
 }
 
 extern "C" int wseg_profile_begin(void) {
