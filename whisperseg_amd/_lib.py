@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libwseg.so")
+# WSEG_LIB: measurement builds only (tools/stamps.py loads lib/libwseg_stamps<N>.so); the product path is the default
+LIB_PATH = os.environ.get("WSEG_LIB") or os.path.join(_HERE, "lib", "libwseg.so")
 ABI_VERSION = 4
 
 

@@ -1,9 +1,13 @@
 """Build libwseg.so (hand-written HIP for gfx950) in-tree with hipcc.
 
-    python -m whisperseg_amd.build [--force]
+    python -m whisperseg_amd.build [--force] [--stamps N]
 
 The shared library lands in whisperseg_amd/lib/libwseg.so; it is git-ignored but travels with the
 gpurun snapshot.  hipcc cross-compiles without a GPU.
+
+--stamps N builds a SECOND library, lib/libwseg_stamps<N>.so, with -DWSEG_STAMPS=N: decode kernel N (1 self-attention,
+2 packed cross-attention, 3 24-bit cross-attention) records s_memrealtime stamps at its phase boundaries (tools/stamps.py
+loads it through WSEG_LIB).  The product library never carries them.
 """
 import os
 import subprocess
@@ -27,9 +31,11 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, stamps=0):
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" if not stamps else "build/stamps%d" % stamps)
+    lib = LIB if not stamps else os.path.join(LIBDIR, "libwseg_stamps%d.so" % stamps)
+    flags = FLAGS + (["-DWSEG_STAMPS=%d" % stamps] if stamps else [])
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "wseg.h"))
@@ -43,7 +49,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         s, o = job
-        cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        cmd = [HIPCC] + flags + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -51,14 +57,14 @@ def build(force=False, verbose=True):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(cc, jobs))
-    if jobs or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if jobs or not os.path.exists(lib):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    n = int(sys.argv[sys.argv.index("--stamps") + 1]) if "--stamps" in sys.argv else 0
+    print(build(force="--force" in sys.argv, stamps=n))

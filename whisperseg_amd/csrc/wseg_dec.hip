@@ -12,6 +12,15 @@
 
 namespace wseg {
 
+// Measurement builds (python -m whisperseg_amd.build --stamps N; never the product library): decode kernel N records the
+// 100-MHz s_memrealtime counter at its phase boundaries, one workgroup's thread 0, into g_stamps; tools/stamps.py reads them.
+#ifdef WSEG_STAMPS
+__device__ unsigned long long g_stamps[32];
+#define WSEG_STAMP(K, I) do { if (WSEG_STAMPS == (K) && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_stamps[I] = wall_clock64(); } while (0)
+#else
+#define WSEG_STAMP(K, I) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 __global__ void decode_reset_kernel(DecodeState st) {
   for (int w = blockIdx.x * 256 + threadIdx.x; w < st.W; w += gridDim.x * 256) { st.pos[w] = 0; st.done[w] = 1; st.win[w] = -1; st.unsat[w] = 0; st.wmax[w] = st.max_length; }
@@ -163,8 +172,10 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
   __shared__ float sq[64];                  // ... and query
   const int lane = threadIdx.x, sub = lane & 7, rowl = lane >> 3;
   const int r = blockIdx.x / H, h = blockIdx.x - r * H;
+  WSEG_STAMP(1, 0);
   const int w = r / st.nb;
   if (st.done[w]) return;                         // idle slot: nothing to read, nothing to append
+  WSEG_STAMP(1, 1);
   const int L = st.L;
   const int n = st.pos[w] + 1;                    // keys 0 .. pos (the current token's K/V were just appended)
   float qv[8];
@@ -186,8 +197,10 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
     load8<T>(q + (size_t)r * d + h * 64 + sub * 8, qv);
   }
   const unsigned char* anc = st.anc + (size_t)r * L;
+  WSEG_STAMP(1, 2);                                     // q | k | v reduced (fused path), cache rows appended
   for (int t = lane; t < n; t += 64) srow[t] = w * st.nb + (t == n - 1 ? (r - w * st.nb) : (int)anc[t]);
   __syncthreads();
+  WSEG_STAMP(1, 3);
   if (fused) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) qv[e] = sq[sub * 8 + e];
@@ -223,6 +236,7 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
       if (sub == 0 && t < n) sp[t] = s;
     }
   }
+  WSEG_STAMP(1, 4);                                     // scores
   __syncthreads();
   float mx = -3.0e38f;
   for (int t = lane; t < n; t += 64) mx = fmaxf(mx, sp[t]);
@@ -231,6 +245,7 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
   for (int t = lane; t < n; t += 64) { const float p = expf(sp[t] - mx); sp[t] = p; sum += p; }
   sum = wave_sum(sum);
   __syncthreads();
+  WSEG_STAMP(1, 5);                                     // softmax
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int t0 = 0; t0 < n; t0 += 32) {
     float vv[4][8];
@@ -265,6 +280,7 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
     a += lane_xor<32>(a);
     acc[e] = a;
   }
+  WSEG_STAMP(1, 6);                                     // P V + lane reduction
   if (rowl == 0) {
     const float inv = 1.0f / sum;
     float o8[8];
@@ -272,6 +288,7 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
     for (int e = 0; e < 8; ++e) o8[e] = acc[e] * inv;
     op_st8<TO>(out, (size_t)r, d, h * 64 + sub * 8, o8);
   }
+  WSEG_STAMP(1, 7);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -415,8 +432,10 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
   __shared__ float red[4][NB][64];
   __shared__ float sinv[NB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  WSEG_STAMP(2, 0);
   const int w = blockIdx.x / H, h = blockIdx.x - w * H;
   if (st.done[w]) return;                              // idle slot: its 128 KiB of K/V are not streamed
+  WSEG_STAMP(2, 1);
   const int nb = st.nb;
   const int sub = lane & 7, rowl = lane >> 3;
   const HT* Kb = ck + ((size_t)w * H + h) * Tk * 64;
@@ -438,6 +457,7 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
     if (tid < NB * 64) sq[tid >> 6][tid & 63] = El<HT>::rnd(reduce1<HT>(pi, w * nb + min(tid >> 6, nb - 1), h * 64 + (tid & 63), q_bias) * scale);
     __syncthreads();
   }
+  WSEG_STAMP(2, 2);                                 // query reduced
   {
     float qv[8];
 #pragma unroll
@@ -516,7 +536,9 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
       if (sub < nb && t < Tk) sc[sub][t] = mine;
     }
   }
+  WSEG_STAMP(2, 3);                                 // scores
   __syncthreads();
+  WSEG_STAMP(2, 4);
   for (int j = wave; j < nb; j += 4) {
     float mx = -3.0e38f;
     for (int t = lane; t < Tk; t += 64) mx = fmaxf(mx, sc[j][t]);
@@ -527,6 +549,7 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
     if (lane == 0) sinv[j] = 1.0f / sum;
   }
   __syncthreads();
+  WSEG_STAMP(2, 5);                                 // softmax
   static_assert(NB == 1 || NB == 2 || NB == 4, "beam tiles");
   const unsigned sc_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&sc[0][0];
   f2 acc[NB][4];
@@ -567,6 +590,7 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
     }
   }
   // reduce over the 8 row-lanes of the wave (lanes with equal `sub`), then over the 4 waves through LDS
+  WSEG_STAMP(2, 6);                                 // P V
 #pragma unroll
   for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -583,6 +607,7 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
     const float o = ((red[0][j][e] + red[1][j][e]) + red[2][j][e]) + red[3][j][e];
     El<HT>::st(out + (size_t)(w * nb + j) * d + h * 64 + e, o * sinv[j]);
   }
+  WSEG_STAMP(2, 7);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -604,8 +629,10 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_k24_kernel(DecodeState 
   __shared__ float red[4][NB][64];
   __shared__ float sinv[NB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  WSEG_STAMP(3, 0);
   const int w = blockIdx.x / H, h = blockIdx.x - w * H;
   if (st.done[w]) return;                              // idle slot: its 96 KiB of K/V are not streamed
+  WSEG_STAMP(3, 1);
   const int nb = st.nb;
   const int sub = lane & 7, rowl = lane >> 3;
   const unsigned char* Kb = ck + ((size_t)w * H + h) * Tk * 192;
@@ -619,6 +646,7 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_k24_kernel(DecodeState 
     if (tid < NB * 64) sq[tid >> 6][tid & 63] = reduce1<float>(pi, w * nb + min(tid >> 6, nb - 1), h * 64 + (tid & 63), q_bias) * scale;
     __syncthreads();
   }
+  WSEG_STAMP(3, 2);                                 // query reduced
   {
     float qv[8];
 #pragma unroll
@@ -685,7 +713,9 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_k24_kernel(DecodeState 
       if (sub < nb && t < Tk) sc[sub][t] = mine;
     }
   }
+  WSEG_STAMP(3, 3);                                 // scores
   __syncthreads();
+  WSEG_STAMP(3, 4);
   for (int j = wave; j < nb; j += 4) {
     float mx = -3.0e38f;
     for (int t = lane; t < Tk; t += 64) mx = fmaxf(mx, sc[j][t]);
@@ -696,6 +726,7 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_k24_kernel(DecodeState 
     if (lane == 0) sinv[j] = 1.0f / sum;
   }
   __syncthreads();
+  WSEG_STAMP(3, 5);                                 // softmax
   static_assert(NB == 1 || NB == 2 || NB == 4, "beam tiles");
   f2 acc[NB][4];
 #pragma unroll
@@ -727,6 +758,7 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_k24_kernel(DecodeState 
       }
     }
   }
+  WSEG_STAMP(3, 6);                                 // P V
 #pragma unroll
   for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -743,6 +775,7 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_k24_kernel(DecodeState 
     const float o = ((red[0][j][e] + red[1][j][e]) + red[2][j][e]) + red[3][j][e];
     Op<TO>::st1(out, (size_t)(w * nb + j), d, h * 64 + e, o * sinv[j]);
   }
+  WSEG_STAMP(3, 7);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -845,12 +878,10 @@ __global__ __launch_bounds__(256) void row_topk_partial_kernel(DecodeState st, c
   for (int k = 0; k < KC; ++k) {
     float bv = tv[0];
     int bi = ti[0], bt = tid;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o, 64);
-      const int oi = __shfl_xor(bi, o, 64), ot = __shfl_xor(bt, o, 64);
-      if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; bt = ot; }
-    }
+#define WSEG_ARGMAX_STEP(O) { const float ov = lane_xor<O>(bv); const int oi = lane_xor<O>(bi), ot = lane_xor<O>(bt); \
+                             if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; bt = ot; } }
+    WSEG_ARGMAX_STEP(32) WSEG_ARGMAX_STEP(16) WSEG_ARGMAX_STEP(8) WSEG_ARGMAX_STEP(4) WSEG_ARGMAX_STEP(2) WSEG_ARGMAX_STEP(1)
+#undef WSEG_ARGMAX_STEP
     if (lane == 0) { s_bv[wave] = bv; s_bi[wave] = bi; s_bt[wave] = bt; }
     __syncthreads();
     if (tid == 0) {
@@ -901,12 +932,10 @@ __global__ __launch_bounds__(64) void row_topk_merge_kernel(DecodeState st, int 
 #pragma unroll
     for (int u = 1; u < 4; ++u) if (better(cv[u], ci[u], bv, bi)) { bv = cv[u]; bi = ci[u]; bu = u; }
     float wv = bv; int wi = bi, wl = lane;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(wv, o, 64);
-      const int oi = __shfl_xor(wi, o, 64), ol = __shfl_xor(wl, o, 64);
-      if (better(ov, oi, wv, wi)) { wv = ov; wi = oi; wl = ol; }
-    }
+#define WSEG_ARGMAX_STEP(O) { const float ov = lane_xor<O>(wv); const int oi = lane_xor<O>(wi), ol = lane_xor<O>(wl); \
+                             if (better(ov, oi, wv, wi)) { wv = ov; wi = oi; wl = ol; } }
+    WSEG_ARGMAX_STEP(32) WSEG_ARGMAX_STEP(16) WSEG_ARGMAX_STEP(8) WSEG_ARGMAX_STEP(4) WSEG_ARGMAX_STEP(2) WSEG_ARGMAX_STEP(1)
+#undef WSEG_ARGMAX_STEP
     if (lane == wl) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) if (u == bu) { cv[u] = -INFINITY; ci[u] = 0x7fffffff; }
@@ -1222,3 +1251,9 @@ int launch_finalize(const DecodeState& st, const int* slots, int n, int* out_tok
 }
 
 }  // namespace wseg
+
+#ifdef WSEG_STAMPS
+extern "C" int wseg_debug_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wseg::g_stamps), sizeof(unsigned long long) * 32);
+}
+#endif

@@ -254,13 +254,13 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
       float mx = s[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = fmaxf(mx, lane_xor<32>(mx));
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __expf(m_run - m_new);
       float ps = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - m_new); ps += s[r]; }
-      ps += __shfl_xor(ps, 32, 64);
+      ps += lane_xor<32>(ps);
       l_run = l_run * alpha + ps;
       m_run = m_new;
       if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {      // no query of this wave raised its maximum: 32 multiplies by 1.0 saved
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void enc_attention_f32_mfma_kernel(const float
       if (key < T) mx = fmaxf(mx, sc[r]);
     }
   }
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));       // the two lane halves hold the two key halves of a query
+  mx = fmaxf(mx, lane_xor<32>(mx));       // the two lane halves hold the two key halves of a query
   // pass 2: p = exp(s - max), l += p, O += p V — all in ascending key order
   f32x16 o0, o1, la;
 #pragma unroll
