@@ -245,6 +245,16 @@ __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, f
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),      \
                                    (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
 
+// Measurement builds only (python -m whisperseg_amd.build --stamps 4, tools/pp_stamps.py): the ping-pong kernel's workgroup 0 records
+// the shader clock (s_memtime) of wave 0 (row group 0) and wave 4 (row group 1) around the L and M parts of every phase of K tiles 8..11.
+#if defined(WSEG_STAMPS) && WSEG_STAMPS == 4
+__device__ unsigned long long g_pp_stamps[2 * 4 * 4 * 4];      // [group][K tile 8..11][phase][top, L issued, M start, M end]
+#define WSEG_PP_STAMP(P, I) do { if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && g >= 8 && g < 12) \
+    g_pp_stamps[((wr * 4 + (g - 8)) * 4 + (P)) * 4 + (I)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WSEG_PP_STAMP(P, I) do { } while (0)
+#endif
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // Barrier that closes the fragment reads of an LDS stage: every ds_read this wave has issued must have RETURNED before
@@ -721,6 +731,11 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
+#if defined(WSEG_STAMPS) && WSEG_STAMPS == 4
+  // timing experiment (wrong results): GM bit 8 (WSEG_PP_SOLO) = row group 1 leaves at once, group 0 runs its L and M parts alone
+  if ((GM & 0x100) && wr == 1) return;
+  GM &= 0xff;
+#endif
   const int fr = lane & 15, fg = lane >> 4;
   const int ntn = N / BN, ntmn = ntm * ntn, ntiles = SPLITK ? ntmn * S : ntmn, nk = K / BK;
   const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3, bpx = gridDim.x >> 3;
@@ -805,8 +820,10 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
 
 #define WSEG_PP_MFMA(JA, IB)                                                                                          \
   do {                                                                                                                \
+    WSEG_PP_STAMP(pp_phase, 1);                                                                                       \
     __builtin_amdgcn_s_barrier();                                                                                     \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                \
+    WSEG_PP_STAMP(pp_phase, 2);                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                                \
     __builtin_amdgcn_s_setprio(1);                                                                                    \
     _Pragma("unroll") for (int kk = 0; kk < (X3M ? 3 : 2); ++kk)                                                      \
@@ -815,6 +832,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
           acc[i][4 * (JA) + j] = H16<HT>::mfma16(bfr[i][X3M ? (kk >> 1) : kk], afr[j][X3M ? (kk & 1) : kk], acc[i][4 * (JA) + j]); \
     __builtin_amdgcn_s_setprio(0);                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                                \
+    WSEG_PP_STAMP(pp_phase, 3);                                                                                       \
   } while (0)
 
   int g = 0;                                           // K tiles consumed so far
@@ -855,6 +873,8 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
     const HT* cur = smem + (g & 1) * BUF;
     bf16x8 afr[4][2], bfr[NI][2];
     // ---- phase 0: b0, a0 -> quadrant (a0, b0) ----
+    [[maybe_unused]] int pp_phase = 0;
+    WSEG_PP_STAMP(0, 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       bfr[i][0] = *(const bf16x8*)(cur + i * 16 * BK + fb0);
@@ -870,6 +890,8 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
     WSEG_PP_MFMA(0, 0);
     __builtin_amdgcn_s_barrier();
     // ---- phase 1: b1 -> quadrant (a0, b1) ----
+    pp_phase = 1;
+    WSEG_PP_STAMP(1, 0);
 #pragma unroll
     for (int i = 2; i < 4; ++i) {
       bfr[i][0] = *(const bf16x8*)(cur + i * 16 * BK + fb0);
@@ -881,6 +903,8 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
     WSEG_PP_MFMA(0, 1);
     __builtin_amdgcn_s_barrier();
     // ---- phase 2: a1 -> quadrant (a1, b1) ----
+    pp_phase = 2;
+    WSEG_PP_STAMP(2, 0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       afr[j][0] = *(const bf16x8*)(cur + (4 + j) * 16 * BK + fa0);
@@ -890,6 +914,8 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
     WSEG_PP_MFMA(1, 1);
     __builtin_amdgcn_s_barrier();
     // ---- phase 3: quadrant (a1, b0); B pair of K tile g+2, retire K tile g+1 ----
+    pp_phase = 3;
+    WSEG_PP_STAMP(3, 0);
     if (!final && g + 2 < KT) { issue_b(0); issue_b(1); wait_vmcnt<4>(); }      // B pair of K tile g+2
     else wait_vmcnt<0>();
     __builtin_amdgcn_sched_barrier(0);
@@ -1372,7 +1398,11 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
     // weight tiles, the smallest operand footprint for 32 tiles (a + b = 12 operand tiles; 2-row groups re-stream the
     // whole weight matrix per tile pair: PMC FETCH_SIZE 2-3x the algorithmic bytes, profiles/).  Measured at 256
     // windows: 4 beats 2 by 2-8 % on the K = 1280 shapes, 6 and 8 lose on K = 5120.
+#if defined(WSEG_STAMPS) && WSEG_STAMPS == 4
+    static const int group_m = (getenv("WSEG_GEMM_GROUP_M") ? atoi(getenv("WSEG_GEMM_GROUP_M")) : 4) | (getenv("WSEG_PP_SOLO") ? 0x100 : 0);
+#else
     static const int group_m = getenv("WSEG_GEMM_GROUP_M") ? atoi(getenv("WSEG_GEMM_GROUP_M")) : 4;
+#endif
     const int n_cu = device_cu_count();
     // 256x256 tiles need whole rounds of the chip: with fewer than 4 rounds, a last round that leaves more than a fifth of
     // the CUs idle costs more than the smaller tile's lower arithmetic intensity (decoder fc1 at 4096 rows: 320 tiles =
@@ -1649,3 +1679,9 @@ extern "C" int wseg_profile_end(double* total_flops, double* total_ms, int64_t* 
   *total_flops = fl; *total_ms = ms; *launches = (int64_t)g_prof.flops.size();
   return WSEG_OK;
 }
+
+#if defined(WSEG_STAMPS) && WSEG_STAMPS == 4
+extern "C" int wseg_debug_pp_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wseg::g_pp_stamps), sizeof(unsigned long long) * 128);
+}
+#endif
