@@ -1,7 +1,8 @@
 """Cycle stamps of the 256x256 ping-pong GEMM kernel (measurement build: python -m whisperseg_amd.build --stamps 4, then on the GPU box
 WSEG_LIB=whisperseg_amd/lib/libwseg_stamps4.so python tools/pp_stamps.py [--shape M,N,K,epi]).  Workgroup 0, wave 0 (row group 0)
-and wave 4 (row group 1), K tiles 8..11: per phase the L part (fragment ds_reads + LDS-DMA issue), the wait at the barrier
-(+ lgkmcnt(0)), the M part (16 MFMAs; 24 in the split-precision modes), in shader cycles (s_memtime)."""
+and wave 4 (row group 1), K tiles 8..11: per phase (A, B) the L part (fragment ds_reads + LDS-DMA issue), the wait (lgkmcnt(0) +
+barrier), the M part (32 MFMAs; 48 in the split-precision modes), in shader cycles (s_memtime).  A stamp itself costs ~100 cycles
+(s_memtime returns through the scalar data path): subtract it from every span before reading absolute numbers."""
 import argparse, ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -31,10 +32,10 @@ print(f"shape M={m} N={n} K={k} epi={epi}")
 for g in range(2):
     for t in range(1, 3):
         row = []
-        for p in range(4):
+        for p in range(2):
             s = S[g][t][p]
-            nxt = S[g][t][p + 1][0] if p < 3 else S[g][t + 1][0][0]
-            row.append(f"ph{p}: L {s[1] - s[0]:4d} wait {s[2] - s[1]:4d} M {s[3] - s[2]:4d} tail {nxt - s[3]:4d}")
+            nxt = S[g][t][p + 1][0] if p < 1 else S[g][t + 1][0][0]
+            row.append(f"phase {'AB'[p]}: L {s[1] - s[0]:4d} wait {s[2] - s[1]:4d} M {s[3] - s[2]:4d} tail {nxt - s[3]:4d}")
         print(f"group {g} K tile {8 + t}: " + " | ".join(row) + f" | K tile {S[g][t + 1][0][0] - S[g][t][0][0]} cycles")
 t0 = S[0][1][0][0]
 print("group 1 lags group 0 by", S[1][1][0][0] - t0, "cycles at the top of K tile 9")

@@ -246,7 +246,7 @@ __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, f
                                    (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
 
 // Measurement builds only (python -m whisperseg_amd.build --stamps 4, tools/pp_stamps.py): the ping-pong kernel's workgroup 0 records
-// the shader clock (s_memtime) of wave 0 (row group 0) and wave 4 (row group 1) around the L and M parts of every phase of K tiles 8..11.
+// the shader clock (s_memtime) of wave 0 (row group 0) and wave 4 (row group 1) around the L and M parts of both phases of K tiles 8..11.
 #if defined(WSEG_STAMPS) && WSEG_STAMPS == 4
 __device__ unsigned long long g_pp_stamps[2 * 4 * 4 * 4];      // [group][K tile 8..11][phase][top, L issued, M start, M end]
 #define WSEG_PP_STAMP(P, I) do { if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && g >= 8 && g < 12) \
@@ -682,29 +682,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h16_persist_kernel(const ty
 // Ping-pong persistent kernel for the large encoder GEMMs (256x256 tile, 8 waves = 2 row groups x 4 column waves,
 // wave tile 128x64, K tiles of 64, two 64-KB LDS buffers of four 16-KB half-tiles [A0 | A1 | B0 | B1]).
 //
-// A K tile is four phases, one 64x32 quadrant of the wave tile each (16 MFMAs).  A phase is
-//     L part: fragment ds_reads + LDS-DMA prefetch issue      | s_barrier |
-//     M part: 16 MFMAs at raised priority                     | s_barrier |
+// A K tile is two phases, one 128x32 half of the wave tile each (32 MFMAs).  A phase is
+//     L part: fragment ds_reads + LDS-DMA prefetch issue, s_waitcnt lgkmcnt(0)      | s_barrier |
+//     M part: 32 MFMAs at raised priority                                           | s_barrier |
 // and row group 1 runs one barrier behind row group 0 (it takes one extra barrier at the start), so on every SIMD
 // one wave is in its M part while the other is in its L part: the matrix pipe is fed by one group while the other
 // issues its loads, instead of all 8 waves reading, then all 8 multiplying.
+// (Rounds 2-3 ran FOUR phases of 16 MFMAs.  Cycle stamps — build --stamps 4, tools/pp_stamps.py — showed the MFMAs themselves
+// at full rate, 16.5 cycles each, and every barrier interval bound by the OTHER group's L part plus the hand-over; two phases
+// halve the hand-overs: qkv / o-proj / fc1 / fc2 / conv2 at 256 windows -2.4 / -2.2 / -3.0 / -5.2 / -4.9 %.)
 //
-// Fragment reads of K tile g:  phase 0: b0, a0   phase 1: b1   phase 2: a1 (into a0's registers)   phase 3: none;
-// quadrants (a0,b0) (a0,b1) (a1,b1) (a1,b0).  Group x executes the L part of phase p in barrier interval 2p + x and
-// its reads are retired (lgkmcnt(0)) inside interval 2p + x + 1.  Hence, for the buffer of K tile g (p = 4g + i), the
-// half-tiles may be overwritten
-//     B0, B1 (read by both groups in phases 0-1): from interval 8g + 5
-//     A0 (read by group 0 only, phases 0 and 2):  from interval 8g + 6
-//     A1 (read by group 1 only):                  from interval 8g + 7
-// and the prefetch stream is      phase 3 of g: B pair of K tile g+2 (intervals 8g+6 / 8g+7), then s_waitcnt vmcnt(4)
-//                                 phase 1 of g: A pair of K tile g+1 (it overwrites K tile g-1: free since 8g - 1)
-// i.e. 4 LDS-DMA pieces in the phase that reads nothing and 4 in the phase that reads least (an LDS-DMA costs an L
-// part ~80 cycles; with 6 + 2 pieces in phases 3 + 0 the kernel was 3-5 % slower, with the pieces between the MFMAs
-// 7-9 % slower).  The counted wait in the L part of phase 3 retires K tile g+1 (A pair issued two phases, B pair four
-// phases earlier) and leaves the B pair of g+2 in flight across the barrier; it is two barriers before group 0 and
-// three before group 1 read K tile g+1.
+// Fragment reads of K tile g:  phase A: b0, b1, a0    phase B: a1 (into a0's registers);  quadrants (a0,b0) (a0,b1) | (a1,b1) (a1,b0).
+// Group x executes the L part of phase p (A = 0, B = 1) in barrier interval 2p + x and RETIRES its reads (lgkmcnt(0)) before
+// it arrives at the barrier that closes that interval.  Hence, for the buffer of K tile g (intervals 4g + i), the half-tiles
+// may be overwritten
+//     B0, B1 (read by both groups in phase A):     from interval 4g + 2
+//     A0 (read by group 0 only, phases A and B):   from interval 4g + 3
+//     A1 (read by group 1 only):                   from interval 4g + 4
+// and the prefetch stream is      phase B of g: B pair of K tile g+2 (intervals 4g+2 / 4g+3), then s_waitcnt vmcnt(4)
+//                                 phase A of g: A pair of K tile g+1 (it overwrites K tile g-1: free since 4g - 1 / 4g)
+// The counted wait in the L part of phase B retires K tile g+1 (A pair issued one phase, B pair two phases earlier) and
+// leaves the B pair of g+2 in flight across the barrier; group 1's wait (interval 4g+3) is followed by the barrier that
+// opens interval 4g+4, in which group 0 is the first to read K tile g+1.
 // The K-tile stream is continuous across the output tiles a workgroup owns.  The last K tile e of an output tile
-// leaves buffer e & 1 to the epilogue as its staging area: the B pair of K tile e+2 is held back to phase 1 of K tile
+// leaves buffer e & 1 to the epilogue as its staging area: the B pair of K tile e+2 is held back to phase A of K tile
 // e+1, which both groups reach only after the barrier that closes the (shared) epilogue interval.
 // ------------------------------------------------------------------------------------------------
 // SPLITK (decoder rows, too few 256x256 output tiles for the chip): the tile space is S copies of the m x n tile grid; copy z
@@ -818,18 +819,23 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   const int fa0 = wr * HTILE + frag0, fa1 = fa0 ^ 32;
   const int fb0 = (2 + (wc >> 1)) * HTILE + (wc & 1) * 64 * BK + frag0, fb1 = fb0 ^ 32;
 
-#define WSEG_PP_MFMA(JA, IB)                                                                                          \
+#define WSEG_PP_QUADRANT(JA, IB)                                                                                      \
+  _Pragma("unroll") for (int kk = 0; kk < (X3M ? 3 : 2); ++kk)                                                        \
+    _Pragma("unroll") for (int i = 2 * (IB); i < 2 * (IB) + 2; ++i)                                                   \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                   \
+        acc[i][4 * (JA) + j] = H16<HT>::mfma16(bfr[i][X3M ? (kk >> 1) : kk], afr[j][X3M ? (kk & 1) : kk], acc[i][4 * (JA) + j]);
+  // closes an L part (this wave's fragment reads have RETURNED before it signals: the stage may be refilled behind this barrier)
+  // and runs the M part of two quadrants
+#define WSEG_PP_MFMA(JA, IB0, IB1)                                                                                    \
   do {                                                                                                                \
     WSEG_PP_STAMP(pp_phase, 1);                                                                                       \
-    __builtin_amdgcn_s_barrier();                                                                                     \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                \
+    __builtin_amdgcn_s_barrier();                                                                                     \
     WSEG_PP_STAMP(pp_phase, 2);                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                                \
     __builtin_amdgcn_s_setprio(1);                                                                                    \
-    _Pragma("unroll") for (int kk = 0; kk < (X3M ? 3 : 2); ++kk)                                                      \
-      _Pragma("unroll") for (int i = 2 * (IB); i < 2 * (IB) + 2; ++i)                                                 \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
-          acc[i][4 * (JA) + j] = H16<HT>::mfma16(bfr[i][X3M ? (kk >> 1) : kk], afr[j][X3M ? (kk & 1) : kk], acc[i][4 * (JA) + j]); \
+    WSEG_PP_QUADRANT(JA, IB0)                                                                                         \
+    WSEG_PP_QUADRANT(JA, IB1)                                                                                         \
     __builtin_amdgcn_s_setprio(0);                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                                \
     WSEG_PP_STAMP(pp_phase, 3);                                                                                       \
@@ -872,11 +878,11 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
     const bool first = !(DIRECT && direct) && kt == 0 && g > 0, final = !(DIRECT && direct) && kt == nkt - 1;
     const HT* cur = smem + (g & 1) * BUF;
     bf16x8 afr[4][2], bfr[NI][2];
-    // ---- phase 0: b0, a0 -> quadrant (a0, b0) ----
+    // ---- phase A: b0, b1, a0 -> quadrants (a0, b0), (a0, b1); A pair of K tile g+1 ----
     [[maybe_unused]] int pp_phase = 0;
     WSEG_PP_STAMP(0, 0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
       bfr[i][0] = *(const bf16x8*)(cur + i * 16 * BK + fb0);
       bfr[i][1] = *(const bf16x8*)(cur + i * 16 * BK + fb1);
     }
@@ -886,47 +892,30 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
       afr[j][1] = *(const bf16x8*)(cur + j * 16 * BK + fa1);
     }
     if (DIRECT && direct && kt == 0) wait_vmcnt<0>();        // this tile's residual rows have landed in acc
-    __builtin_amdgcn_sched_barrier(0);
-    WSEG_PP_MFMA(0, 0);
-    __builtin_amdgcn_s_barrier();
-    // ---- phase 1: b1 -> quadrant (a0, b1) ----
-    pp_phase = 1;
-    WSEG_PP_STAMP(1, 0);
-#pragma unroll
-    for (int i = 2; i < 4; ++i) {
-      bfr[i][0] = *(const bf16x8*)(cur + i * 16 * BK + fb0);
-      bfr[i][1] = *(const bf16x8*)(cur + i * 16 * BK + fb1);
-    }
     if (first && g + 1 < KT) { issue_b(0); issue_b(1); }        // B pair of K tile g+1, held back over the epilogue
     if (g + 1 < KT) { issue_a(0); issue_a(1); }                 // A pair of K tile g+1
     __builtin_amdgcn_sched_barrier(0);
-    WSEG_PP_MFMA(0, 1);
+    WSEG_PP_MFMA(0, 0, 1);
     __builtin_amdgcn_s_barrier();
-    // ---- phase 2: a1 -> quadrant (a1, b1) ----
-    pp_phase = 2;
-    WSEG_PP_STAMP(2, 0);
+    // ---- phase B: a1 -> quadrants (a1, b1), (a1, b0); B pair of K tile g+2, retire K tile g+1 ----
+    pp_phase = 1;
+    WSEG_PP_STAMP(1, 0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       afr[j][0] = *(const bf16x8*)(cur + (4 + j) * 16 * BK + fa0);
       afr[j][1] = *(const bf16x8*)(cur + (4 + j) * 16 * BK + fa1);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    WSEG_PP_MFMA(1, 1);
-    __builtin_amdgcn_s_barrier();
-    // ---- phase 3: quadrant (a1, b0); B pair of K tile g+2, retire K tile g+1 ----
-    pp_phase = 3;
-    WSEG_PP_STAMP(3, 0);
     if (!final && g + 2 < KT) { issue_b(0); issue_b(1); wait_vmcnt<4>(); }      // B pair of K tile g+2
     else wait_vmcnt<0>();
     __builtin_amdgcn_sched_barrier(0);
-    WSEG_PP_MFMA(1, 0);
+    WSEG_PP_MFMA(1, 1, 0);
     if (!final) __builtin_amdgcn_s_barrier();
   }
   // Epilogue: group 0 gives up its one-barrier lead (it idles while group 1 finishes its last 16 MFMAs), both groups run
   // their epilogues in the SAME interval — back to back they cost two epilogue times with the matrix pipe idle, side by
   // side the loads / stores of 8 waves overlap (o-proj 459 -> 441 us, fc1 1653 -> 1598 us at 256 windows) — and group 1
   // then drops one barrier behind again.  Every wave stages in its own strip of the buffer the last K tile left; nothing
-  // is prefetched into that buffer before phase 1 of the next K tile, which both groups reach only after the barrier
+  // is prefetched into that buffer before phase A of the next K tile, which both groups reach only after the barrier
   // below.  (Requesting group 0's residual rows before its idle interval measured no further gain.)
   if constexpr (DIRECT) {
     typedef typename IO<T>::P PT;
@@ -965,6 +954,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   }
   }
 #undef WSEG_PP_MFMA
+#undef WSEG_PP_QUADRANT
   if (wr == 0) __builtin_amdgcn_s_barrier();          // pair group 1's extra barrier
 }
 
