@@ -25,7 +25,7 @@ for it in range(3):
     _lib.check(lib.wseg_debug_gemm(1, epi, m, n, k, A.data_ptr(), W.data_ptr(), bias.data_ptr(), res.data_ptr(), out.data_ptr(), ws.data_ptr(),
                                    ws.numel(), _lib.stream_ptr()))
     torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 128)()
+buf = (ctypes.c_ulonglong * 132)()
 raw.wseg_debug_pp_stamps(buf)
 S = [[[[buf[((g * 4 + t) * 4 + p) * 4 + i] for i in range(4)] for p in range(4)] for t in range(4)] for g in range(2)]
 print(f"shape M={m} N={n} K={k} epi={epi}")
@@ -39,3 +39,5 @@ for g in range(2):
         print(f"group {g} K tile {8 + t}: " + " | ".join(row) + f" | K tile {S[g][t + 1][0][0] - S[g][t][0][0]} cycles")
 t0 = S[0][1][0][0]
 print("group 1 lags group 0 by", S[1][1][0][0] - t0, "cycles at the top of K tile 9")
+dc, dt = buf[130] - buf[128], (buf[131] - buf[129]) / 100.0
+print(f"K tiles 2..18 of workgroup 0: {dc} shader cycles in {dt:.2f} us = {dc / dt / 1e3:.3f} GHz effective clock, {dt / 16:.3f} us per K tile (stamped workgroup)")

@@ -248,11 +248,15 @@ __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, f
 // Measurement builds only (python -m whisperseg_amd.build --stamps 4, tools/pp_stamps.py): the ping-pong kernel's workgroup 0 records
 // the shader clock (s_memtime) of wave 0 (row group 0) and wave 4 (row group 1) around the L and M parts of both phases of K tiles 8..11.
 #if defined(WSEG_STAMPS) && WSEG_STAMPS == 4
-__device__ unsigned long long g_pp_stamps[2 * 4 * 4 * 4];      // [group][K tile 8..11][phase][top, L issued, M start, M end]
+__device__ unsigned long long g_pp_stamps[2 * 4 * 4 * 4 + 4];  // [group][K tile 8..11][phase][top, L issued, M start, M end]; then (cycles, 100-MHz ticks) at K tiles 2 and 18
 #define WSEG_PP_STAMP(P, I) do { if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && g >= 8 && g < 12) \
     g_pp_stamps[((wr * 4 + (g - 8)) * 4 + (P)) * 4 + (I)] = __builtin_readcyclecounter(); } while (0)
+// effective shader clock under this kernel's own load: the cycle counter against the constant 100-MHz counter over 16 K tiles
+#define WSEG_PP_CLOCK() do { if (blockIdx.x == 0 && wave == 0 && lane == 0 && (g == 2 || g == 18)) { \
+    g_pp_stamps[128 + (g == 18 ? 2 : 0)] = __builtin_readcyclecounter(); g_pp_stamps[129 + (g == 18 ? 2 : 0)] = wall_clock64(); } } while (0)
 #else
 #define WSEG_PP_STAMP(P, I) do { } while (0)
+#define WSEG_PP_CLOCK() do { } while (0)
 #endif
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -881,6 +885,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
     // ---- phase A: b0, b1, a0 -> quadrants (a0, b0), (a0, b1); A pair of K tile g+1 ----
     [[maybe_unused]] int pp_phase = 0;
     WSEG_PP_STAMP(0, 0);
+    WSEG_PP_CLOCK();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       bfr[i][0] = *(const bf16x8*)(cur + i * 16 * BK + fb0);
@@ -1672,6 +1677,6 @@ extern "C" int wseg_profile_end(double* total_flops, double* total_ms, int64_t* 
 
 #if defined(WSEG_STAMPS) && WSEG_STAMPS == 4
 extern "C" int wseg_debug_pp_stamps(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wseg::g_pp_stamps), sizeof(unsigned long long) * 128);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wseg::g_pp_stamps), sizeof(unsigned long long) * 132);
 }
 #endif
