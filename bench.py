@@ -652,7 +652,8 @@ def extra_lines(args, eng, step, main_in, make_extractor, device, W, slots):
             t0 = time.perf_counter()
             step(audio=audio_4, win_starts=st_4, **dict(kw))
             torch.cuda.synchronize()
-            conc[name] = {"audio_sec_per_s": 4 * W * 1000 * args.spec_time_step / (time.perf_counter() - t0)}
+            conc[name] = {"audio_sec_per_s": 4 * W * 1000 * args.spec_time_step / (time.perf_counter() - t0),
+                          "slots_used": int(eng.last_stats()["n_slots"])}
         out["concurrency"] = dict(conc, windows=4 * W, note="whole step() incl. log-mel and the CPU epilogue")
     try:      # the two long-queue lines need the 1024-slot workspace (154 GB): report instead of failing when it does not fit
         big_queues()

@@ -219,6 +219,12 @@ int wseg_debug_gemm(int32_t dtype, int32_t epi, int32_t M, int32_t N, int32_t K,
 int wseg_debug_gemm_resid_ln(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, const void* W, const void* bias, void* x,
                              const void* gamma, const void* beta, void* y, void* splitk_ws, size_t splitk_ws_bytes, void* stream);
 
+/* Test tap of the cross-lane exchanges every wave reduction of the library is built on (csrc/wseg_common.h lane_xor<M>: DPP
+ * quad_perm / row_shl / row_shr / row_ror, v_permlane16_swap, v_permlane32_swap instead of ds_bpermute): out[m][l] = the value
+ * lane l ^ (1 << m) holds, for m = 0..5 and l = 0..63, where lane l holds 7 l + 3.  out: device, 6 * 64 uint32.
+ * tests/test_gemm_gpu.py::test_lane_exchanges. */
+int wseg_debug_lane_xor(uint32_t* out, void* stream);
+
 /* Live per-launch timing of the dominant kernel (the 256x256 ping-pong bf16 MFMA GEMM; 128x128 persistent for narrow problems) with HIP events recorded on
  * the launching stream.  Between begin and end every launch of that kernel is bracketed by two events;
  * end synchronises and returns the sums: algorithmic FLOPs (2*M*N*K of the real, un-padded problem),

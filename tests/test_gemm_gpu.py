@@ -241,3 +241,15 @@ def test_gemm_resid_layernorm_step(gpu_lib, M, N, K, dtype):
     assert torch.isfinite(got).all()
     assert (got - yr).abs().max().item() <= tol * max(1.0, yr.abs().max().item())
     assert torch.equal(x[M:], x0[M:])                                    # rows beyond M untouched
+
+
+def test_lane_exchanges(gpu_lib):
+    """lane_xor<M> (DPP / v_permlane swaps; every wave_sum / wave_max / attention lane reduction of the library) is the exact
+    exchange l <-> l ^ M that __shfl_xor was."""
+    from whisperseg_amd import _lib
+    out = torch.zeros(6 * 64, dtype=torch.int32, device="cuda")
+    _lib.check(gpu_lib.wseg_debug_lane_xor(out.data_ptr(), _lib.stream_ptr()))
+    got = out.cpu().view(6, 64)
+    lanes = torch.arange(64)
+    for m in range(6):
+        assert torch.equal(got[m], ((lanes ^ (1 << m)) * 7 + 3).to(torch.int32)), 1 << m

@@ -10,6 +10,7 @@ from whisperseg_amd import _lib
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="128000,1280,1280,2")
+ap.add_argument("--iters", type=int, default=40, help="launches before the stamps are read (the clock settles within a few ms of load)")
 a = ap.parse_args()
 m, n, k, epi = (int(v) for v in a.shape.split(","))
 lib = _lib.load(require_device=True)
@@ -21,10 +22,10 @@ od = torch.float32 if epi == 2 else torch.bfloat16
 res = torch.rand(m, n, device="cuda").to(od)
 out = torch.empty(m, n, device="cuda", dtype=od)
 ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
-for it in range(3):
+for it in range(a.iters):
     _lib.check(lib.wseg_debug_gemm(1, epi, m, n, k, A.data_ptr(), W.data_ptr(), bias.data_ptr(), res.data_ptr(), out.data_ptr(), ws.data_ptr(),
                                    ws.numel(), _lib.stream_ptr()))
-    torch.cuda.synchronize()
+torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 132)()
 raw.wseg_debug_pp_stamps(buf)
 S = [[[[buf[((g * 4 + t) * 4 + p) * 4 + i] for i in range(4)] for p in range(4)] for t in range(4)] for g in range(2)]

@@ -61,6 +61,7 @@ SYMBOLS = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "wseg_debug_gemm_resid_ln": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "wseg_debug_lane_xor": (C.c_int, [C.c_void_p, C.c_void_p]),
     "wseg_profile_begin": (C.c_int, []),
     "wseg_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

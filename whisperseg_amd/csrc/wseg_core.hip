@@ -35,3 +35,23 @@ extern "C" int wseg_device_info(char* name_out, size_t name_cap, int* cu_count_o
   }
   return WSEG_OK;
 }
+
+namespace wseg {
+__global__ void lane_xor_probe_kernel(uint32_t* out) {
+  const unsigned v = threadIdx.x * 7 + 3;
+  out[0 * 64 + threadIdx.x] = lane_xor_u<1>(v);
+  out[1 * 64 + threadIdx.x] = lane_xor_u<2>(v);
+  out[2 * 64 + threadIdx.x] = lane_xor_u<4>(v);
+  out[3 * 64 + threadIdx.x] = lane_xor_u<8>(v);
+  out[4 * 64 + threadIdx.x] = lane_xor_u<16>(v);
+  out[5 * 64 + threadIdx.x] = lane_xor_u<32>(v);
+}
+}  // namespace wseg
+
+extern "C" int wseg_debug_lane_xor(uint32_t* out, void* stream) {
+  using namespace wseg;
+  if (!out) { set_error("wseg_debug_lane_xor: null argument"); return WSEG_ERR_INVALID; }
+  hipLaunchKernelGGL(lane_xor_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}

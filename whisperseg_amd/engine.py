@@ -286,7 +286,12 @@ class Engine:
             raise _lib.WsegError("wseg_workspace_bytes rejected the request")
         # grow when too small; give a much larger one back (a single long file must not pin ~100 GB for every later short call)
         if self._ws is None or self._ws.numel() < need or (self._ws.numel() > 4 * need and self._ws.numel() > (2 << 30)):
+            old = 0 if self._ws is None else self._ws.numel()
             self._ws = None
+            if old >= (1 << 30):
+                # hand the old block back to the driver first: kept in torch's cache it could neither be reused for the larger
+                # request nor be seen by pick_slots' free-memory query (a 118-GiB block beside a 140-GiB one does not fit)
+                torch.cuda.empty_cache()
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
@@ -303,7 +308,10 @@ class Engine:
         cap = int(n_slots or os.environ.get("WSEG_SLOTS", 0) or DEFAULT_SLOTS)
         s = max(1, min(int(n_windows), cap))
         free, _ = torch.cuda.mem_get_info(self.device)
-        budget = 0.8 * (free + (self._ws.numel() if self._ws is not None else 0))
+        # blocks torch's allocator has cached but not handed out are as good as free (empty_cache returns them)
+        free += max(0, torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device))
+        own = self._ws.numel() if self._ws is not None else 0
+        budget = max(own, 0.8 * (free + own))          # what this engine already holds is always available to it
         while s > 1 and self.lib.wseg_workspace_bytes(self.handle, s, num_beams, max_length) > budget:
             s = (s + 1) // 2
         return s
