@@ -97,42 +97,10 @@ template <> __device__ __forceinline__ void load8<float>(const float* p, float v
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 
-// sum_z part[z][row][col .. col+8) + bias[col .. col+8)   (fixed order z = 0, 1, ...: deterministic)
-template <typename T>
-__device__ __forceinline__ void reduce8(const PartialInfo& pi, int row, int col, const T* bias, float v[8]) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = 0.f;
-  const float* pp = pi.part + (size_t)row * pi.n + col;
-  const size_t zs = (size_t)pi.m_pad * pi.n;
-  // two splits (4 independent 16-byte loads) in flight at a time; loads are unconditional (clamped), the adds are masked
-  for (int z0 = 0; z0 < pi.splits; z0 += 2) {
-    float4 a[2], b[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int zc = min(z0 + u, pi.splits - 1);
-      a[u] = *(const float4*)(pp + zc * zs);
-      b[u] = *(const float4*)(pp + zc * zs + 4);
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (z0 + u < pi.splits) {
-        v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w;
-        v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
-      }
-    }
-  }
-  if (bias) {
-    float bb[8];
-    load8<T>(bias + col, bb);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] += bb[e];
-  }
-}
-
-// One value, same sum (z = 0, 1, ... then the bias): every split's load is issued before the first add.  reduce8 above walks the
-// splits two at a time — with 10 splits that is five DEPENDENT round trips to partials the previous kernel left in memory, per
-// call; at 8 slots the four per-beam calls of the cross-attention made up most of its 23.5 us.  The attention kernels now
-// reduce one value per thread (all loads in flight at once) and hand the result round through LDS.
+// sum_z part[z][row][col] + bias[col] in the fixed order z = 0, 1, ... (deterministic), ONE value per thread with every split's load
+// issued before the first add; the attention kernels hand the results round through LDS.  (Until round 3 every lane reduced its own
+// 8-dim slice, two splits at a time: with 10 splits five DEPENDENT round trips to partials the previous kernel left in memory, per
+// call — at 8 slots the four per-beam calls of the cross-attention were most of its 23.5 us.)
 template <typename T>
 __device__ __forceinline__ float reduce1(const PartialInfo& pi, int row, int col, const T* bias) {
   const float* pp = pi.part + (size_t)row * pi.n + col;

@@ -200,6 +200,14 @@ __global__ __launch_bounds__(256) void logmel_items_kernel(wseg_logmel_desc d, L
 
 // NC = n_fft / 2 packed complex points per frame: 256 (n_fft 512) or 512 (n_fft 1024: one radix-2 DIF step in registers,
 // z[n] +- z[n + 256], turns the frame into two 256-point FFTs — the even and the odd bins — run through the same core).
+// Measurement builds only (python -m whisperseg_amd.build --stamps 5, tools/logmel_stamps.py): shader-cycle stamps of one wave over one frame
+#if defined(WSEG_STAMPS) && WSEG_STAMPS == 5
+__device__ unsigned long long g_lm_stamps[16];
+#define WSEG_LM_STAMP(I) do { if (blockIdx.x == 3 && blockIdx.y == 1 && tid == 0 && fi == 2) g_lm_stamps[I] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WSEG_LM_STAMP(I) do { } while (0)
+#endif
+
 template <int NC>
 __global__ __launch_bounds__(256) void logmel_fft_kernel(LogmelArgs a) {
   constexpr int R = NC / 256;                                      // 256-point FFTs per frame
@@ -290,6 +298,7 @@ __global__ __launch_bounds__(256) void logmel_fft_kernel(LogmelArgs a) {
   for (int fi = 0; fi < LM_FB / 4; ++fi) {
     const int fr = wave * (LM_FB / 4) + fi, f = f0 + fr;       // wave-uniform
     if (f >= a.n_frames) break;
+    WSEG_LM_STAMP(0);
     // ---- A. load + window: z[n] = x[2n] + i x[2n+1], n = lane + 64 i ----
     cf2 v[4 * R];
     const int64_t base = (int64_t)f * hop - NC;                // window-local index of sample 0 of the frame
@@ -313,6 +322,7 @@ __global__ __launch_bounds__(256) void logmel_fft_kernel(LogmelArgs a) {
       }
       v[i] = (cf2){xs[0], xs[1]} * win[i];
     }
+    WSEG_LM_STAMP(1);
     // ---- B. FFT ----
     if constexpr (R == 1) {
       fft256(v, s_z[wave]);
@@ -325,6 +335,7 @@ __global__ __launch_bounds__(256) void logmel_fft_kernel(LogmelArgs a) {
       fft256(od, s_z[wave] + 256);
     }
     wave_lds_sync();
+    WSEG_LM_STAMP(2);
     // ---- C. unpack the real FFT, |X[k]|^2 for k = lane + 64 i (and k = NC in lane 0) ----
 #pragma unroll
     for (int i = 0; i < 4 * R; ++i) {
@@ -337,6 +348,7 @@ __global__ __launch_bounds__(256) void logmel_fft_kernel(LogmelArgs a) {
       if (k == 0) { const float xn = zk.x - zk.y; pw[NC] = xn * xn; }         // X[NC] = Re Z[0] - Im Z[0]
     }
     wave_lds_sync();
+    WSEG_LM_STAMP(3);
     // ---- D. mel projection: items of <= LM_CH bins, then each filter sums its items in order ----
     for (int it = lane; it < n_items; it += 64) {
       const int kk = s_ik0[it];
@@ -348,6 +360,7 @@ __global__ __launch_bounds__(256) void logmel_fft_kernel(LogmelArgs a) {
       s_part[wave][it] = acc;
     }
     wave_lds_sync();
+    WSEG_LM_STAMP(4);
     for (int m = lane; m < n_mels; m += 64) {
       float acc = 0.f;
       for (int c = s_cb[m]; c < s_cb[m + 1]; ++c) acc += s_part[wave][c];
@@ -358,6 +371,7 @@ __global__ __launch_bounds__(256) void logmel_fft_kernel(LogmelArgs a) {
       if (f < a.d.n_cols) lmin = fminf(lmin, val);
     }
     wave_lds_sync();
+    WSEG_LM_STAMP(5);
   }
   lmax = wave_max(lmax);
   lmin = -wave_max(-lmin);
@@ -481,3 +495,9 @@ extern "C" int wseg_logmel_f32(const wseg_logmel_desc* d, const float* audio, in
   }
   return WSEG_OK;
 }
+
+#if defined(WSEG_STAMPS) && WSEG_STAMPS == 5
+extern "C" int wseg_debug_logmel_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wseg::g_lm_stamps), sizeof(unsigned long long) * 16);
+}
+#endif
