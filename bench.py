@@ -578,6 +578,19 @@ def extra_lines(args, eng, step, main_in, make_extractor, device, W, slots):
         line["segment_api_1h_recording"] = {"audio_sec_per_s": 3600.0 / dt, "seconds": dt, "windows": 120,
                                             "note": "host numpy PCM -> segment() in the default (split-precision) mode"}
         del segp
+        # the default mode at the engine's default concurrency (4 x W windows through up to 1 024 slots: 24-bit cross K/V and fp32
+        # activations need ~2x the 16-bit workspace, so the main engine's workspace is handed back first)
+        if engp is not eng:
+            eng.release_workspace()
+            torch.cuda.empty_cache()
+        try:
+            feats4 = torch.cat([feats] * 4)
+            dt4, _ = timed(lambda: engp.generate(feats4, PROMPT, EOS, EOS, n_slots=4 * W, **gen_kw))
+            line[f"at_{4 * W}_windows"] = {"audio_sec_per_s": 4 * W * 1000 * args.spec_time_step / dt4, "ms_per_step": dt4 * 1e3,
+                                           "slots_used": int(engp.last_stats()["n_slots"])}
+            del feats4
+        except Exception as exc:
+            line[f"at_{4 * W}_windows"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         out["split_precision_mode"] = line
         if engp is not eng:
             del engp
