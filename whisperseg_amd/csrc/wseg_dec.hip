@@ -142,12 +142,22 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
   const int r = blockIdx.x / H, h = blockIdx.x - r * H;
   WSEG_STAMP(1, 0);
   const int w = r / st.nb;
-  if (st.done[w]) return;                         // idle slot: nothing to read, nothing to append
-  WSEG_STAMP(1, 1);
   const int L = st.L;
-  const int n = st.pos[w] + 1;                    // keys 0 .. pos (the current token's K/V were just appended)
+  // ONE round trip for everything that depends on nothing: the idle flag, the position, the first 64 ancestry bytes and (unfused
+  // path) the query.  A wave of this kernel is a chain of dependent loads at full occupancy (81 920 single-wave workgroups at
+  // 1 024 slots, ten rounds of ~7 us): as separate steps the flag, the position and the ancestry were three links of it.
+  const unsigned char* anc = st.anc + (size_t)r * L;
+  const int idle = st.done[w];
+  const int pos = st.pos[w];
+  int anc0 = anc[min(lane, L - 1)];
   float qv[8];
+  qv[0] = 0.f;
   const bool fused = pi.part != nullptr;
+  if (!fused) load8<T>(q + (size_t)r * d + h * 64 + sub * 8, qv);
+  asm volatile("" : "+v"(anc0), "+v"(qv[0]));     // keeps the loads above the branch (the compiler would sink them to their uses)
+  if (idle) return;                               // idle slot: nothing to append
+  WSEG_STAMP(1, 1);
+  const int n = pos + 1;                          // keys 0 .. pos (the current token's K/V were just appended)
   if (fused) {
     // finish the split-K reduction of q | k | v for this (row, head): lane e owns dim e of each (all 3 x splits loads in flight
     // together, reduce1); values are rounded to the storage type exactly as the unfused epilogue would have stored and
@@ -161,12 +171,9 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
     El<T>::st(vc + at, v1);
     snk[lane] = k1;
     snv[lane] = v1;
-  } else {
-    load8<T>(q + (size_t)r * d + h * 64 + sub * 8, qv);
   }
-  const unsigned char* anc = st.anc + (size_t)r * L;
   WSEG_STAMP(1, 2);                                     // q | k | v reduced (fused path), cache rows appended
-  for (int t = lane; t < n; t += 64) srow[t] = w * st.nb + (t == n - 1 ? (r - w * st.nb) : (int)anc[t]);
+  for (int t = lane; t < n; t += 64) srow[t] = w * st.nb + (t == n - 1 ? (r - w * st.nb) : (t < 64 ? anc0 : (int)anc[t]));
   __syncthreads();
   WSEG_STAMP(1, 3);
   if (fused) {
