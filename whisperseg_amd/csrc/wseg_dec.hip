@@ -129,9 +129,23 @@ __device__ __forceinline__ float row8_sum(float a) {
   return a;
 }
 
+// A K / V cache row slice as loaded (16 bytes of 16-bit elements, or 8 floats), unpacked where it is used: at 1 024 slots the kernel is
+// 81 920 single-wave workgroups of dependent loads, so what counts is how many of them a SIMD holds — rows kept as floats cost 77
+// registers (6 waves), kept raw 64 (8 waves).
+template <typename T> struct Row8 {
+  uint4 r;
+  __device__ __forceinline__ void ld(const T* p) { r = *(const uint4*)p; }
+  __device__ __forceinline__ void get(float v[8]) const { unpack8<T>(r, v); }
+};
+template <> struct Row8<float> {
+  float4 a, b;
+  __device__ __forceinline__ void ld(const float* p) { a = ((const float4*)p)[0]; b = ((const float4*)p)[1]; }
+  __device__ __forceinline__ void get(float v[8]) const { v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; }
+};
+
 // T: storage type of q / the K / V cache / the bias; TO: tag of the output (the o-proj GEMM's operand: T, or X3<HT> with T = float)
 template <typename T, typename TO>
-__global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const T* __restrict__ q, T* __restrict__ kc,
+__global__ __launch_bounds__(64, sizeof(T) == 2 ? 8 : 5) void dec_self_attn_kernel(DecodeState st, const T* __restrict__ q, T* __restrict__ kc,
                                                            T* __restrict__ vc, void* __restrict__ out, int H, int d,
                                                            PartialInfo pi, const T* __restrict__ qkv_bias, float scale) {
   __shared__ float sp[512];
@@ -182,31 +196,32 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
   }
   // The V rows of the first 32 positions are requested together with the K rows (both depend only on the ancestry
   // table): a wave is one chain of dependent HBM round trips, and this removes one of them for sequences <= 32.
-  float vfirst[4][8];
+  Row8<T> vfirst[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int tl = min(u * 8 + rowl, fused ? max(n - 2, 0) : n - 1);
-    load8<T>(vc + (((size_t)srow[tl] * H + h) * L + tl) * 64 + sub * 8, vfirst[u]);
+    vfirst[u].ld(vc + (((size_t)srow[tl] * H + h) * L + tl) * 64 + sub * 8);
   }
   for (int t0 = 0; t0 < n; t0 += 32) {
-    float kv[4][8];
+    Row8<T> kr[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       // unconditional clamped loads (see the cross-attention kernel); the fused step's own key is patched in after
-      const int t = t0 + u * 8 + rowl;
-      const int tl = min(t, fused ? max(n - 2, 0) : n - 1);
-      load8<T>(kc + (((size_t)srow[tl] * H + h) * L + tl) * 64 + sub * 8, kv[u]);
-      if (fused && t == n - 1) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) kv[u][e] = snk[sub * 8 + e];
-      }
+      const int tl = min(t0 + u * 8 + rowl, fused ? max(n - 2, 0) : n - 1);
+      kr[u].ld(kc + (((size_t)srow[tl] * H + h) * L + tl) * 64 + sub * 8);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int t = t0 + u * 8 + rowl;
+      float kv[8];
+      kr[u].get(kv);
+      if (fused && t == n - 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kv[e] = snk[sub * 8 + e];
+      }
       float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s = fmaf(qv[e], kv[u][e], s);
+      for (int e = 0; e < 8; ++e) s = fmaf(qv[e], kv[e], s);
       s = row8_sum(s);
       if (sub == 0 && t < n) sp[t] = s;
     }
@@ -223,28 +238,25 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(DecodeState st, const
   WSEG_STAMP(1, 5);                                     // softmax
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int t0 = 0; t0 < n; t0 += 32) {
-    float vv[4][8];
+    if (t0 > 0) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int t = t0 + u * 8 + rowl;
-      const int tl = min(t, fused ? max(n - 2, 0) : n - 1);
-      if (t0 == 0) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) vv[u][e] = vfirst[u][e];
-      } else {
-        load8<T>(vc + (((size_t)srow[tl] * H + h) * L + tl) * 64 + sub * 8, vv[u]);
-      }
-      if (fused && t == n - 1) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) vv[u][e] = snv[sub * 8 + e];
+      for (int u = 0; u < 4; ++u) {
+        const int tl = min(t0 + u * 8 + rowl, fused ? max(n - 2, 0) : n - 1);
+        vfirst[u].ld(vc + (((size_t)srow[tl] * H + h) * L + tl) * 64 + sub * 8);
       }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int t = t0 + u * 8 + rowl;
+      float vv[8];
+      vfirst[u].get(vv);
+      if (fused && t == n - 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vv[e] = snv[sub * 8 + e];
+      }
       const float p = t < n ? sp[t] : 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, vv[u][e], acc[e]);
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, vv[e], acc[e]);
     }
   }
 #pragma unroll
