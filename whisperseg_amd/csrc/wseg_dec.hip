@@ -145,7 +145,7 @@ template <> struct Row8<float> {
 
 // T: storage type of q / the K / V cache / the bias; TO: tag of the output (the o-proj GEMM's operand: T, or X3<HT> with T = float)
 template <typename T, typename TO>
-__global__ __launch_bounds__(64, sizeof(T) == 2 ? 8 : 5) void dec_self_attn_kernel(DecodeState st, const T* __restrict__ q, T* __restrict__ kc,
+__global__ __launch_bounds__(64, 8) void dec_self_attn_kernel(DecodeState st, const T* __restrict__ q, T* __restrict__ kc,
                                                            T* __restrict__ vc, void* __restrict__ out, int H, int d,
                                                            PartialInfo pi, const T* __restrict__ qkv_bias, float scale) {
   __shared__ float sp[512];
@@ -196,11 +196,14 @@ __global__ __launch_bounds__(64, sizeof(T) == 2 ? 8 : 5) void dec_self_attn_kern
   }
   // The V rows of the first 32 positions are requested together with the K rows (both depend only on the ancestry
   // table): a wave is one chain of dependent HBM round trips, and this removes one of them for sequences <= 32.
+  constexpr bool kPrefetchV = sizeof(T) == 2;          // fp32 rows: the prefetch would cost the 8th wave per SIMD (32 more registers)
   Row8<T> vfirst[4];
+  if constexpr (kPrefetchV) {
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int tl = min(u * 8 + rowl, fused ? max(n - 2, 0) : n - 1);
-    vfirst[u].ld(vc + (((size_t)srow[tl] * H + h) * L + tl) * 64 + sub * 8);
+    for (int u = 0; u < 4; ++u) {
+      const int tl = min(u * 8 + rowl, fused ? max(n - 2, 0) : n - 1);
+      vfirst[u].ld(vc + (((size_t)srow[tl] * H + h) * L + tl) * 64 + sub * 8);
+    }
   }
   for (int t0 = 0; t0 < n; t0 += 32) {
     Row8<T> kr[4];
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(64, sizeof(T) == 2 ? 8 : 5) void dec_self_attn_kern
   WSEG_STAMP(1, 5);                                     // softmax
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int t0 = 0; t0 < n; t0 += 32) {
-    if (t0 > 0) {
+    if (t0 > 0 || !kPrefetchV) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int tl = min(t0 + u * 8 + rowl, fused ? max(n - 2, 0) : n - 1);
