@@ -230,3 +230,125 @@ def test_per_recording_parameters_in_segment_batch_cpu():
     assert pooled == per_file_reference()
     with pytest.raises(ValueError):
         seg.segment_batch(make_batch(), [b[0] for b in BATCH], spec_time_step=[0.01, 0.01])      # list shorter than the batch
+
+
+# ---- world 4: one rank receives ZERO windows, the batch holds an EMPTY recording, and grouping bounds the pooled list -------------
+SMALL = [  # sr, seconds, spec_time_step, num_trials  -> 1 + 1 + 1 = 3 windows for 4 ranks
+    (16000, 4.0, 0.01, 1),
+    (16000, 0.0, 0.01, 1),          # an empty recording: ONE all-zero window ("this loop must be executed once even for zero
+                                    # length audio", reference model.py:145-146)
+    (16000, 7.5, 0.01, 1),
+]
+
+
+def make_small():
+    rng = np.random.default_rng(23)
+    return [(0.1 * rng.standard_normal(int(sr * sec))).astype(np.float32) for sr, sec, *_ in SMALL]
+
+
+def small_kwargs(**extra):
+    return dict(spec_time_step=[b[2] for b in SMALL], num_trials=[b[3] for b in SMALL], batch_size=2, max_length=L, **extra)
+
+
+def small_worker(rank, world, port, q, pool_windows):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from whisperseg_amd import dist as wd
+    wd.init_from_env(backend="gloo")
+    seg = FakeSegmenter()
+    audios = make_small() if rank == 0 else None
+    srs = [b[0] for b in SMALL] if rank == 0 else None
+    kw = small_kwargs(pool_windows=pool_windows) if rank == 0 else dict(batch_size=2, max_length=L, pool_windows=pool_windows)
+    res = wd.segment_batch_distributed(seg, audios, srs, **kw)
+    q.put((rank, res, seg.pcm_samples_seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("pool_windows", [None, 1])
+def test_world4_idle_rank_and_empty_recording_gloo(pool_windows):
+    """4 ranks, 3 windows, one of three recordings empty: rank 3 decodes nothing and still takes part in every collective;
+    pool_windows=1 forces one GROUP per recording (the bounded-memory path evaluate() uses on whole datasets)."""
+    from whisperseg_amd import dist as wd
+    from whisperseg_amd.windows import window_table
+    counts = [len(window_table(int(sr * sec), sr, sts, nt, 1000)) for sr, sec, sts, nt in SMALL]
+    assert counts[1] == 1 and sum(counts) < 4
+    seg = FakeSegmenter()
+    want = [wd.segment_distributed(seg, a, sr, spec_time_step=sts, num_trials=nt, batch_size=2, max_length=L)
+            for a, (sr, _, sts, nt) in zip(make_small(), SMALL)]
+    assert len(want[1]["onset"]) == 0 and len(want[2]["onset"]) > 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000 + (7 if pool_windows else 0)
+    procs = [ctx.Process(target=small_worker, args=(r, 4, port, q, pool_windows)) for r in range(4)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=200) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    seen = {}
+    for rank, res, pcm_seen in results:
+        assert res == want, rank
+        seen[rank] = pcm_seen
+    if pool_windows is None:
+        assert seen[3] == 0                 # the rank without windows received no PCM at all
+
+
+def eval_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from whisperseg_amd import dist as wd
+    from whisperseg_amd.evaluate import evaluate
+    from whisperseg_amd.model import SegmenterBase
+    wd.init_from_env(backend="gloo")
+
+    class Seg(SegmenterBase):            # our segment(), device stages stubbed; has decode_shard_tokens, i.e. COULD go distributed
+        def __init__(self):
+            super().__init__()
+            self.fs = FakeSegmenter()
+            self.total_spec_columns = 1000
+            self.cluster_codebook = {"a": 0, "b": 1, "c": 2}
+            self.default_segmentation_config = {"spec_time_step": 0.01, "min_frequency": 0}
+            self.device_list = [torch.device("cpu")]
+            self.sliced_features_from_device_pcm = self.fs.sliced_features_from_device_pcm
+            self.decode_shard_tokens = self.fs.decode_shard_tokens
+            self.tokens_to_texts = self.fs.tokens_to_texts
+
+        def get_sliced_audios_features(self, audio, sr, min_frequency, spec_time_step, num_trials):
+            pcm = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32))
+            return self.fs.sliced_features_from_device_pcm(pcm, sr, min_frequency, spec_time_step, num_trials)["shard"]
+
+        def generate_segment_text(self, sliced, *a, **k):
+            return self.fs.tokens_to_texts(*[t.numpy() for t in self.fs.decode_shard_tokens(sliced)])
+
+    seg = Seg()
+    audios = make_batch()[:2]
+    labels = [dict(onset=[0.1], offset=[0.3], cluster=["a"], sr=BATCH[i][0], spec_time_step=BATCH[i][2]) for i in range(2)]
+    out = None
+    if rank == 0:                          # the training-loop idiom (reference train.py:250): ONLY rank 0 evaluates
+        out = evaluate(audios, labels, seg, 2, L, 1)
+    dist.barrier()
+    both = evaluate(audios if rank == 0 else None, labels, seg, 2, L, 1, distributed=True)      # opt-in: every rank calls
+    q.put((rank, out, both))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_rank0_only_evaluate_does_not_block_gloo():
+    """an initialised process group must not turn evaluate() into a collective.  Rank 0 alone calls it (it would
+    hang for ever in broadcast_object_list if it went distributed); with distributed=True both ranks call it and agree."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=120) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0][1] is not None and results[1][1] is None
+    assert results[0][2] == results[1][2] == results[0][1]

@@ -134,3 +134,45 @@ def test_evaluate_accumulates_like_reference(tmp_path):
     lab = read_label(str(tmp_path / "y.csv"))
     assert lab["onset"] == [0.5] and lab["cluster"] == ["3"] and lab["species"] == "unknown"
     assert read_label(str(tmp_path / "x.json"))["cluster"] == ["Vocal"]
+
+
+def test_in_process_device_fan_out_two_stub_devices():
+    """a-6 (reference model.py:169-189): the thread-per-device fan-out with TWO devices in one process — contiguous
+    ceil(N / n_devices) shards, one thread per device with its own replica index, results re-joined in device order, a worker's
+    exception re-raised (the reference loses it).  Device stages are stubs: no GPU has ever run this with two devices."""
+    import threading
+    import time
+    import pytest
+    from whisperseg_amd.model import SegmenterBase
+
+    class TwoDevices(SegmenterBase):
+        def __init__(self, fail_on=None):
+            super().__init__()
+            self.device_list = ["stub:0", "stub:1"]
+            self.seen = {}
+            self.fail_on = fail_on
+            self.barrier = threading.Barrier(2, timeout=20)
+
+        def generate_segment_text_core(self, sliced, batch_size, max_length, num_beams, top_k, top_p, length_penalty,
+                                       generated_texts_dict, thread_id, status_monitor=None):
+            self.barrier.wait()                                  # both device threads are alive at the same time
+            self.seen[thread_id] = (threading.get_ident(), [s[0] for s in sliced], status_monitor is not None)
+            if thread_id == 0:
+                time.sleep(0.05)                                 # device 0 finishes LAST: order must come from the device index
+            if self.fail_on == thread_id:
+                raise RuntimeError("device %d failed" % thread_id)
+            generated_texts_dict[thread_id] = ["w%d@%d" % (s[0], thread_id) for s in sliced]
+
+    seg = TwoDevices()
+    windows = [(i, 0.0, None, 1.0) for i in range(7)]
+    texts = seg.generate_segment_text(windows, 4, 448, 4, status_monitor={})
+    assert texts == ["w0@0", "w1@0", "w2@0", "w3@0", "w4@1", "w5@1", "w6@1"]          # ceil(7 / 2) = 4 | 3, device order
+    assert seg.seen[0][0] != seg.seen[1][0]                                            # two threads
+    assert seg.seen[0][2] and not seg.seen[1][2]                                       # the monitor goes to device 0 only
+    for bad in (0, 1):
+        with pytest.raises(RuntimeError, match="device %d failed" % bad):
+            TwoDevices(fail_on=bad).generate_segment_text(windows, 4, 448, 4)
+    # fewer windows than devices: the second device gets an empty shard or no thread at all, never an index error
+    one = TwoDevices()
+    one.barrier = threading.Barrier(1)
+    assert one.generate_segment_text(windows[:1], 4, 448, 4) == ["w0@0"]

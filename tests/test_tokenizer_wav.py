@@ -63,3 +63,21 @@ def test_tokenizer_equals_huggingface_on_both_layouts(golden_dir):
     from whisperseg_amd import postprocess
     segs = postprocess.extract_segments(cases["decoded"][0], 0.01, {str(i): i for i in range(100000)})
     assert len(segs) >= 1 and all(len(r) == 3 for r in segs)
+
+
+def test_tok_fixture_is_byte_reproducible(golden_dir, tmp_path):
+    """A pinned fixture must be reproducible from its committed generator: tools/make_tok_fixture.py run
+    here (transformers is a wheel of the image) must rewrite tests/golden/tok_fixture byte for byte."""
+    import filecmp
+    import subprocess
+    import sys
+    import pytest
+    pytest.importorskip("transformers")
+    from conftest import ROOT
+    env = dict(os.environ, WSEG_TOK_FIXTURE_OUT=str(tmp_path), HF_HUB_OFFLINE="1")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_tok_fixture.py")], check=True, env=env, capture_output=True)
+    root = os.path.join(golden_dir, "tok_fixture")
+    names = ["decode_cases.json", "slow/vocab.json", "slow/added_tokens.json", "slow/merges.txt", "slow/special_tokens_map.json",
+             "hf/tokenizer.json", "hf/tokenizer_config.json"]
+    for name in names:
+        assert filecmp.cmp(os.path.join(root, name), os.path.join(str(tmp_path), name), shallow=False), name

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tools import tiny_model as TM  # noqa: E402
 
-OUT = os.path.join(ROOT, "tests", "golden", "tok_fixture")
+OUT = os.environ.get("WSEG_TOK_FIXTURE_OUT") or os.path.join(ROOT, "tests", "golden", "tok_fixture")
 SPECIALS = ["<|endoftext|>", "<|startoftranscript|>", "<|en|>", "<|de|>", "<|translate|>", "<|transcribe|>", "<|startoflm|>",
             "<|startofprev|>", "<|nospeech|>", "<|notimestamps|>"]
 SPECIES = ["<|zebra_finch|>", "<|bengalese_finch|>", "<|mouse|>", "<|marmoset|>", "<|human|>", "<|unknown|>", "<|animal|>"]
@@ -58,7 +58,9 @@ def main():
     os.makedirs(os.path.join(OUT, "hf"), exist_ok=True)
     os.makedirs(os.path.join(OUT, "slow"), exist_ok=True)
     tok.save_pretrained(os.path.join(OUT, "hf"))
-    full = tok.get_vocab()
+    # get_vocab() of a fast tokenizer iterates a Rust hash map (a different order every process): everything derived from it is
+    # ordered by token id, so that two runs of this script write the same bytes (tests/test_tokenizer_wav.py asserts it)
+    full = dict(sorted(tok.get_vocab().items(), key=lambda kv: kv[1]))
     bpe = {t: i for t, i in full.items() if i < n_bpe}
     added = {t: i for t, i in full.items() if i >= n_bpe}
     with open(os.path.join(OUT, "slow", "vocab.json"), "w", encoding="utf-8") as f:
@@ -73,7 +75,7 @@ def main():
     # tokens, plus rows of arbitrary ids (bytes incl. non-ASCII continuation bytes, merged words, specials anywhere)
     rng = np.random.default_rng(0)
     ids_of = tok.convert_tokens_to_ids
-    digit_tokens = [i for t, i in bpe.items() if t.isdigit()]
+    digit_tokens = sorted(i for t, i in bpe.items() if t.isdigit())
     prompt = ids_of(["<|startoftranscript|>", "<|en|>", "<|notimestamps|>"])
     rows = []
     for r in range(160):

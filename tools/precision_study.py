@@ -13,6 +13,9 @@ POLICY = comma-separated  class=fmt  pairs, classes:
     ckv    cross-attention K / V storage (ck / cv: one of them)                (x2 = hi + lo pair, i.e. ~16 / ~22 mantissa bits)
     skv    decoder self-attention K / V cache
     dq     decoder attention queries (self + cross) and attention outputs are GEMM operands -> class gemm; dq = the query
+    egemm / dgemm / ckvg / lm   per-STAGE override of `gemm`: encoder Linears + convs / decoder-layer Linears / the cross-K|V
+           projections / the LM head.  Extra formats for the GEMM classes: f16x2w | bf16x2w (weights hi + lo, activations rounded
+           once: 2 MFMAs per product) and f16x2a | bf16x2a (activations hi + lo, weights rounded once)
     all    shorthand: every class
 e.g.  "all=f16"   "gemm=bf16x3"   "gemm=bf16x3,ckv=f16"   "gemm=bf16x3,eattn=f16,ckv=f16,skv=f16"
 The special policy "margins" dumps the histogram of top-1 / top-2 logit margins of the fp32 oracle over the sweep.
@@ -55,21 +58,53 @@ def rnd(x, fmt):
     raise ValueError(fmt)
 
 
+STAGES = ("egemm", "dgemm", "ckvg", "lm")
+
+
 class Policy:
     def __init__(self, text):
         self.fmt = dict(gemm="f32", eattn="f32", ck="f32", cv="f32", skv="f32", dq="f32")
+        stage = {}
         for part in filter(None, text.split(",")):
             k, v = part.split("=")
+            if k in STAGES:
+                stage[k] = v
+                continue
             for kk in (self.fmt if k == "all" else (["ck", "cv"] if k == "ckv" else [k])):
                 self.fmt[kk] = v if not (kk != "gemm" and v.endswith("x3")) else v[:-1] + "2"
+        for k in STAGES:
+            self.fmt[k] = stage.get(k, self.fmt["gemm"])
         self.wcache = {}
 
+    @staticmethod
+    def stage_of(prefix):
+        if prefix.startswith("model.encoder."):
+            return "egemm"
+        if prefix.endswith("encoder_attn.k_proj") or prefix.endswith("encoder_attn.v_proj"):
+            return "ckvg"
+        if prefix.endswith("embed_tokens"):
+            return "lm"
+        return "dgemm"
+
     def linear(self, x, sd, prefix, bias=True):
-        fmt = self.fmt["gemm"]
+        fmt = self.fmt[self.stage_of(prefix)]
         w = sd[prefix + ".weight"]
         b = sd[prefix + ".bias"] if bias else None
         if fmt == "f32":
             return F.linear(x, w, b)
+        if fmt.endswith("x2w") or fmt.endswith("x2a"):
+            base = torch.bfloat16 if fmt.startswith("bf16") else torch.float16
+            key = (prefix, fmt)
+            if key not in self.wcache:
+                wh = w.to(base).float()
+                self.wcache[key] = (wh, (w - wh).to(base).float())
+            wh, wl = self.wcache[key]
+            xh = x.to(base).float()
+            if fmt.endswith("x2w"):
+                y = F.linear(xh, wh) + F.linear(xh, wl)
+            else:
+                y = F.linear(xh, wh) + F.linear((x - xh).to(base).float(), wh)
+            return y + b if b is not None else y
         if fmt.endswith("x3"):
             base = torch.bfloat16 if fmt.startswith("bf16") else torch.float16
             key = (prefix, fmt)
@@ -84,9 +119,15 @@ class Policy:
         return F.linear(rnd(x, fmt), rnd(w, fmt), b)
 
     def conv(self, x, w, b, **kw):
-        fmt = self.fmt["gemm"]
+        fmt = self.fmt["egemm"]
         if fmt == "f32":
             return F.conv1d(x, w, b, **kw)
+        if fmt.endswith("x2w") or fmt.endswith("x2a"):
+            base = torch.bfloat16 if fmt.startswith("bf16") else torch.float16
+            wh = w.to(base).float(); xh = x.to(base).float()
+            if fmt.endswith("x2w"):
+                return F.conv1d(xh, wh, b, **kw) + F.conv1d(xh, (w - wh).to(base).float(), None, **kw)
+            return F.conv1d(xh, wh, b, **kw) + F.conv1d((x - xh).to(base).float(), wh, None, **kw)
         if fmt.endswith("x3"):
             base = torch.bfloat16 if fmt.startswith("bf16") else torch.float16
             wh = w.to(base).float(); wl = (w - wh).to(base).float()
@@ -251,7 +292,7 @@ class OracleSegmenter(SegmenterBase):
 
 def main():
     from tools.parity_sweep import score
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("STUDY_THREADS", 8)))
     dest = sys.argv[1]
     with open(os.path.join(ROOT, "tests", "golden", "tiny_sweep.json")) as f:
         sweep = json.load(f)

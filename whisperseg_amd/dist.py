@@ -198,7 +198,8 @@ def segment_batch_distributed(segmenter, audios, srs=None, decode_shard=None, **
     as SegmenterBase.segment_batch takes them); other ranks may pass None.  Exchange: (1) the recordings' metadata (lengths,
     rates, resolved parameters: a small pickled list, broadcast), (2) PCM point-to-point from rank 0 to the ranks whose
     windows read it, (3) all_gather of token ids + lengths.  Every rank then holds all tokens and parses every recording
-    (host work, milliseconds); returns the list of prediction dicts on every rank, equal to per-file segment()."""
+    (host work, milliseconds); returns the list of prediction dicts on every rank, equal to per-file segment().
+    `pool_windows` (default model.POOL_WINDOWS): recordings are processed in groups of at most ~pool_windows x world windows."""
     from . import postprocess
     from .audio_utils import get_n_fft_given_sr
     from .model import _per_item
@@ -226,30 +227,48 @@ def segment_batch_distributed(segmenter, audios, srs=None, decode_shard=None, **
     meta = _broadcast_object(meta)
     cols = segmenter.total_spec_columns
     counts = [len(window_table(m["n"], m["sr"], m["spec_time_step"], m["num_trials"], cols)) for m in meta]
-    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-    n_total = int(offs[-1])
-    bounds = [my_shard(n_total, r, world) for r in range(world)]
-    need = [[i for i in range(len(meta)) if offs[i] < hi and offs[i + 1] > lo] for lo, hi in bounds]
-    pcm = _scatter_recordings(audios, meta, need, device, rank, world) if not _single() else \
-        {i: torch.as_tensor(np.ascontiguousarray(audios[i], dtype=np.float32)).to(device) for i in need[0]}
-    lo, hi = bounds[rank]
-    shard = []
-    for i in need[rank]:
-        m = meta[i]
-        part = segmenter.sliced_features_from_device_pcm(pcm[i], m["sr"], m["min_frequency"], m["spec_time_step"], m["num_trials"],
-                                                         window_range=(lo - int(offs[i]), hi - int(offs[i])))
-        shard += part["shard"]
+    # Recordings are processed in GROUPS of at most ~pool_windows x world windows (every rank derives the same grouping from the
+    # metadata): scatter, front-end, decode and gather run per group, so a rank never holds more than ~pool_windows windows of
+    # log-mel features (320 KB each) however large the dataset is — evaluate() sends whole datasets through here.
+    from .model import POOL_WINDOWS
+    cap = max(1, int(kwargs.get("pool_windows") or POOL_WINDOWS)) * world
+    groups, cur, cur_n = [], [], 0
+    for i, c in enumerate(counts):
+        if cur and cur_n + c > cap:
+            groups.append(cur)
+            cur, cur_n = [], 0
+        cur.append(i)
+        cur_n += c
+    if cur:
+        groups.append(cur)
     fn = decode_shard or segmenter.decode_shard_tokens
-    tokens, lengths = fn(shard, **_decode_kwargs(kwargs))
-    tokens, lengths = gather_rows(tokens, lengths, n_total)
-    tokens, lengths = tokens.cpu().numpy(), lengths.cpu().numpy()
-    texts = segmenter.tokens_to_texts(tokens, lengths)
     out = []
-    for i, m in enumerate(meta):
-        rows = [(w.trial_id, w.offset_time, None, w.clip_seconds)
-                for w in window_table(m["n"], m["sr"], m["spec_time_step"], m["num_trials"], cols)]
-        pred = segmenter.parse_generation(texts[int(offs[i]):int(offs[i + 1])], rows, m["min_segment_length"], m["n"] / m["sr"],
-                                          m["spec_time_step"], m["num_trials"], m["eps"], m["frame"], m["method"])
-        pred = postprocess.correct_fft_blur(pred, get_n_fft_given_sr(m["sr"]), m["sr"])
-        out.append(postprocess.drop_consecutive_duplicates(pred))
+    for members in groups:
+        offs = np.concatenate([[0], np.cumsum([counts[i] for i in members])]).astype(np.int64)
+        n_total = int(offs[-1])
+        bounds = [my_shard(n_total, r, world) for r in range(world)]
+        need = [[i for k, i in enumerate(members) if offs[k] < hi and offs[k + 1] > lo] for lo, hi in bounds]
+        first = {i: int(offs[k]) for k, i in enumerate(members)}
+        pcm = _scatter_recordings(audios, meta, need, device, rank, world) if not _single() else \
+            {i: torch.as_tensor(np.ascontiguousarray(audios[i], dtype=np.float32)).to(device) for i in need[0]}
+        lo, hi = bounds[rank]
+        shard = []
+        for i in need[rank]:
+            m = meta[i]
+            part = segmenter.sliced_features_from_device_pcm(pcm[i], m["sr"], m["min_frequency"], m["spec_time_step"], m["num_trials"],
+                                                             window_range=(lo - first[i], hi - first[i]))
+            shard += part["shard"]
+        tokens, lengths = fn(shard, **_decode_kwargs(kwargs))
+        del shard, pcm
+        tokens, lengths = gather_rows(tokens, lengths, n_total)
+        tokens, lengths = tokens.cpu().numpy(), lengths.cpu().numpy()
+        texts = segmenter.tokens_to_texts(tokens, lengths)
+        for k, i in enumerate(members):
+            m = meta[i]
+            rows = [(w.trial_id, w.offset_time, None, w.clip_seconds)
+                    for w in window_table(m["n"], m["sr"], m["spec_time_step"], m["num_trials"], cols)]
+            pred = segmenter.parse_generation(texts[int(offs[k]):int(offs[k + 1])], rows, m["min_segment_length"], m["n"] / m["sr"],
+                                              m["spec_time_step"], m["num_trials"], m["eps"], m["frame"], m["method"])
+            pred = postprocess.correct_fft_blur(pred, get_n_fft_given_sr(m["sr"]), m["sr"])
+            out.append(postprocess.drop_consecutive_duplicates(pred))
     return out

@@ -55,15 +55,20 @@ def _prf(tp, n_pred, n_label):
     return [tp, n_pred, n_label, precision, recall, 2 / (1 / max(precision, 1e-12) + 1 / max(recall, 1e-12))]
 
 
-def evaluate(audio_list, label_list, segmenter, batch_size, max_length, num_trials, num_beams=4, target_cluster=None):
+def evaluate(audio_list, label_list, segmenter, batch_size, max_length, num_trials, num_beams=4, target_cluster=None,
+             distributed=None):
     """reference evaluate.py:9-51 -> {"segment_wise": [TP, P_pred, P_label, precision, recall, f1], "frame_wise": [...]}
 
     The reference segments file by file with each label's own sr / min_frequency / spec_time_step (evaluate.py:15-24).  Here
-    all recordings go through ONE pooled decode with those per-recording parameters (SegmenterBase.segment_batch) — sharded
-    over the ranks of the default process group when one is active (dist.segment_batch_distributed: every rank must call
-    evaluate(); rank 0's audio_list is used) — which yields the per-file predictions of segment() (pooling only changes the
-    batch a window is decoded in).  A segmenter without segment_batch (any object with the reference's interface) is driven
-    file by file as upstream."""
+    all recordings go through ONE pooled decode with those per-recording parameters (SegmenterBase.segment_batch), which yields
+    the per-file predictions of segment() (pooling only changes the batch a window is decoded in).  A segmenter without
+    segment_batch (any object with the reference's interface) is driven file by file as upstream.
+
+    `distributed` is OPT-IN (default: $WSEG_EVAL_DISTRIBUTED == "1", else False): the reference calls evaluate() from inside
+    its training loop (train.py:250), where the usual `if rank == 0: evaluate(...)` under DDP / torchrun must stay a purely
+    local call — an initialised process group alone never makes this function a collective.  With distributed=True EVERY rank
+    of the default group must call evaluate(); the clip batch is then sharded over the ranks
+    (dist.segment_batch_distributed; rank 0's audio_list is used)."""
     from . import dist as wdist
     kw = dict(min_frequency=[label.get("min_frequency", None) for label in label_list],
               spec_time_step=[label.get("spec_time_step", None) for label in label_list],
@@ -71,7 +76,9 @@ def evaluate(audio_list, label_list, segmenter, batch_size, max_length, num_tria
     srs = [label["sr"] for label in label_list]
     from .model import SegmenterBase
     ours = getattr(type(segmenter), "segment", None) is SegmenterBase.segment      # not a subclass with its own segment()
-    if ours and not wdist._single() and hasattr(segmenter, "decode_shard_tokens"):
+    if distributed is None:
+        distributed = os.environ.get("WSEG_EVAL_DISTRIBUTED") == "1"
+    if distributed and ours and not wdist._single() and hasattr(segmenter, "decode_shard_tokens"):
         predictions = wdist.segment_batch_distributed(segmenter, audio_list, srs, **kw)
     elif ours and hasattr(segmenter, "segment_batch"):
         predictions = segmenter.segment_batch(audio_list, srs, **kw)
