@@ -724,6 +724,26 @@ def extra_lines(args, eng, step, main_in, make_extractor, device, W, slots):
             return time.perf_counter() - t0, r, eng.last_stats()
         queued(n_slots=DEFAULT_SLOTS)                                # graph capture / workspace growth
         dtd, (tkd, lnd, _), statsd = queued(n_slots=DEFAULT_SLOTS)   # the engine's default slot count
+        # the SAME queue under the API's default max_length = 448 (reference model.py:406-409): with paged self-attention K/V the
+        # engine keeps its 1 024 slots (the pool holds 64 positions per slot on average instead of 448 reserved per slot)
+        def queued448():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = step(audio=audio_q, win_starts=st_q, gen_tokens=445, window_max_length=lens, n_slots=DEFAULT_SLOTS)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, r, eng.last_stats()
+        try:
+            queued448()
+            dt448, (tk448, ln448, _), st448 = queued448()
+            line448 = {"audio_sec_per_s": nq * 1000 * args.spec_time_step / dt448, "slots": st448["n_slots"],
+                       "relative_to_max_length_%d" % (2 * args.gen_tokens + 3): dtd / dt448,
+                       "kv_units_total": st448["kv_units_total"], "kv_units_peak": st448["kv_units_peak"], "n_preemptions": st448["n_preemptions"],
+                       "tokens_identical": bool(all(np.array_equal(tk448[i, :ln448[i]], tkd[i, :lnd[i]]) for i in range(nq)))}
+        except Exception as exc:
+            line448 = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            torch.cuda.synchronize()
+        eng.release_workspace()
+        torch.cuda.empty_cache()
         dt1, (tk, ln, _), stats = queued(n_slots=W)                  # W slots, as in the timed step
         # the same windows decoded batch by batch as the reference does (model.py:653): every batch runs to its longest window
         t0 = time.perf_counter()
@@ -738,6 +758,8 @@ def extra_lines(args, eng, step, main_in, make_extractor, device, W, slots):
                                     "audio_sec_per_s": asec / dtd, "slots": statsd["n_slots"],
                                     "occupancy_while_windows_are_queued": statsd["steady_occupancy"], "occupancy_overall": statsd["occupancy"],
                                     "steps": statsd["n_steps"], "admissions": statsd["n_admissions"],
+                                    "kv_units_total": statsd["kv_units_total"], "kv_units_peak": statsd["kv_units_peak"],
+                                    "with_max_length_448": line448,
                                     f"with_{W}_slots": {"audio_sec_per_s": asec / dt1, "occupancy_while_windows_are_queued": stats["steady_occupancy"],
                                                         "occupancy_overall": stats["occupancy"], "steps": stats["n_steps"],
                                                         "admissions": stats["n_admissions"],

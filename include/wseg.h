@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define WSEG_ABI_VERSION 4
+#define WSEG_ABI_VERSION 5
 
 typedef enum {
   WSEG_OK = 0,
@@ -128,8 +128,20 @@ int wseg_model_set_tensor(wseg_model* m, const char* name, const void* dev_ptr, 
 /* 0 when every tensor the geometry needs has been attached. */
 int wseg_model_ready(const wseg_model* m);
 
-/* Workspace (device bytes) for max_windows window slots (= windows per encoder pass and windows decoded concurrently). */
+/* Workspace (device bytes) for max_windows window slots (= windows decoded concurrently; the encoder runs over at most 256 of
+ * them per pass).
+ *
+ * The decoder's self-attention K / V are PAGED (ABI 5): pages of 8 positions are handed to a slot as its sequence grows and taken
+ * back when its window retires, from a pool carved out of the workspace.  wseg_workspace_bytes sizes that pool for the EXPECTED
+ * sequence length — min(max_length, 64) positions per slot on average — so the reference's default max_length = 448
+ * (model.py:406-409) no longer reserves 448 positions per slot up front (1.3 MiB per position per slot in the split-precision
+ * modes); wseg_workspace_bytes_kv takes the average number of positions per slot to provision (0: that default; >= max_length:
+ * every slot can reach max_length at once, the pre-ABI-5 behaviour).  wseg_generate uses whatever the caller's workspace has room
+ * for (at most a full set, at least one slot's worth); when the pool runs short it preempts the youngest window and decodes it
+ * again later (same tokens; wseg_generate_stats.n_preemptions). */
 size_t wseg_workspace_bytes(const wseg_model* m, int32_t max_windows, int32_t num_beams, int32_t max_length);
+size_t wseg_workspace_bytes_kv(const wseg_model* m, int32_t max_windows, int32_t num_beams, int32_t max_length,
+                               int32_t kv_positions_per_slot);
 
 /*
  * Encoder only: feats device float32 [n_windows][80][1000] -> enc_out device [n_windows][500][d_model]
@@ -179,7 +191,7 @@ typedef struct {
  * wseg_workspace_bytes(m, n_slots, ...): it does not grow with n_windows.  The host stays `lookahead` steps ahead of the
  * device and otherwise only waits on the small per-step status mirror; the call is stream-ordered on `stream`.
  * (ABI 3 had decode "lanes" — slot groups on separate streams; they measured exactly as one group with their total slot
- * count and were removed in ABI 4.)
+ * count and were removed in ABI 4.  ABI 5: paged self-attention K / V, see wseg_workspace_bytes.)
  */
 int wseg_generate(wseg_model* m, const float* feats, int32_t n_windows, const wseg_generate_params* p,
                   void* workspace, size_t workspace_bytes,
@@ -194,6 +206,10 @@ typedef struct {
   int64_t slot_steps_total;       /* steps * slots                                                                      */
   int64_t queued_slot_steps_active; /* the same two sums over the steps launched while windows were still queued, i.e.   */
   int64_t queued_slot_steps_total;  /* without the drain of the last windows (steady-state occupancy of the refill)      */
+  int32_t kv_units_total;         /* self-attention K/V pool of the call: units of (one 8-position page x all beams of a slot) */
+  int32_t kv_units_peak;          /* most units in use at once                                                           */
+  int32_t n_preemptions;          /* windows aborted for lack of pool units and decoded again later                       */
+  int32_t reserved_;
 } wseg_generate_stats;
 int wseg_last_stats(const wseg_model* m, wseg_generate_stats* out);
 

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     assert set(names) == set(_lib.SYMBOLS), set(names) ^ set(_lib.SYMBOLS)
     bound = _lib.load()
-    assert bound.wseg_abi_version() == 4
+    assert bound.wseg_abi_version() == 5
 
 
 def test_struct_layouts_match_header(tmp_path):
@@ -75,3 +75,32 @@ def test_fast_class_rejects_ct2_directory(tmp_path):
         WhisperSegmenterFast(str(tmp_path), device="cuda")
     with pytest.raises(FileNotFoundError):
         resolve_model_dir(str(tmp_path / "nope"))
+
+
+def test_workspace_sizing_is_host_arithmetic_and_fits_the_default_api_call():
+    """with paged self-attention K / V the workspace of the engine's default 1 024 slots at the reference's
+    default max_length = 448 (model.py:406-409), 4 beams, whisperseg-large in the split-precision mode must fit 80 % of a
+    288-GB MI355X.  wseg_workspace_bytes* are pure host arithmetic (no device needed)."""
+    import ctypes as C
+    from whisperseg_amd import _lib
+    lib = _lib.load()
+    out = {}
+    for name, dtype in (("bf16", 1), ("f16x3", 4)):
+        cfg = _lib.ModelConfig(d_model=1280, n_heads=20, enc_layers=32, dec_layers=32, ffn=5120, vocab=51865, n_mels=80,
+                               spec_cols=1000, enc_positions=500, dec_positions=448, dtype=dtype)
+        h = C.c_void_p()
+        assert lib.wseg_model_create(C.byref(cfg), C.byref(h)) == 0
+        try:
+            ws = lambda s, nb, L, per=0: lib.wseg_workspace_bytes_kv(h, s, nb, L, per)
+            assert lib.wseg_workspace_bytes(h, 1024, 4, 448) == ws(1024, 4, 448) == ws(1024, 4, 448, 64)
+            assert 0 <= ws(1024, 4, 448) - ws(1024, 4, 64) < 64e6          # the same pool; only the bookkeeping tables follow max_length
+            assert ws(1024, 4, 448, 448) > ws(1024, 4, 448) > ws(1024, 4, 35) > ws(512, 4, 35)
+            assert ws(1024, 4, 448, 9999) == ws(1024, 4, 448, 448)
+            assert ws(0, 4, 448) == 0 and ws(4, 9, 448) == 0 and ws(4, 4, 0) == 0 and ws(4, 4, 448, -1) == 0
+            out[name] = (ws(1024, 4, 448), ws(1024, 4, 448, 448), ws(1024, 4, 35))
+        finally:
+            lib.wseg_model_destroy(h)
+    weights_x3 = 6.2e9
+    assert out["f16x3"][0] + weights_x3 <= 0.8 * 288e9, out          # the API default call keeps 1 024 slots in the default mode
+    assert out["f16x3"][1] > 288e9                                    # ... which a fully provisioned cache could never do
+    assert out["bf16"][0] < 0.5 * 288e9

@@ -257,7 +257,10 @@ def test_slot_cap_and_workspace_lifecycle(gpu_lib):
     t, l = gen(eng, x, 4, n_slots=2)                      # 2 slots need less than a quarter of 23 slots' workspace ...
     assert eng.last_stats()["n_slots"] == 2
     assert torch.equal(l, ref_l) and torch.equal(t, ref_t)
-    if big > (2 << 30):                                   # ... but only workspaces above 2 GiB are worth re-allocating
+    assert eng._ws.numel() == big                         # ... but one small call never shrinks it (hysteresis)
+    if big > (2 << 30):                                   # and only workspaces above 2 GiB are worth re-allocating at all
+        for _ in range(4):
+            gen(eng, x, 4, n_slots=2)
         assert eng._ws.numel() < big
     eng.release_workspace()
     assert eng._ws is None
@@ -270,3 +273,83 @@ def test_slot_cap_and_workspace_lifecycle(gpu_lib):
     seg.max_slots = 1
     assert seg.segment(audio, TM.SR, batch_size=64) == want
     assert seg.model_list[0].last_stats()["n_slots"] == 1
+
+
+# ---- paged self-attention K / V (ABI 5) ---------------------------------------------------------------------------------------
+def _units(eng, slots, nb, ml, per):
+    """workspace bytes for `per` pooled positions per slot on average"""
+    return eng.lib.wseg_workspace_bytes_kv(eng.handle, slots, nb, ml, per)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16x3"])
+def test_paged_kv_default_pool_equals_full_pool(gpu_lib, dtype):
+    """max_length = 448 with the DEFAULT pool (64 positions per slot on average instead of 448 reserved per slot) gives exactly
+    the tokens of a fully provisioned pool — paging only changes where a K / V row lives — in a fraction of the workspace."""
+    eng = tiny_engine(dtype)
+    x = tiny_feats(23)
+    full_t, full_l = gen(eng, x, 4, 448, kv_positions=448)
+    st = eng.last_stats()
+    assert st["kv_units_total"] == 23 * 56 and st["n_preemptions"] == 0 and 0 < st["kv_units_peak"] <= st["kv_units_total"]
+    peak_positions = st["kv_units_peak"] * 8
+    assert peak_positions < 23 * 130                       # the trained model stops after 10-40 tokens: nowhere near 448 per slot
+    eng.release_workspace()                                # (the pool is whatever the workspace has room for: start from a fresh one)
+    t, l = gen(eng, x, 4, 448)                             # default pool
+    st = eng.last_stats()
+    assert st["kv_units_total"] == 23 * 8 and st["n_preemptions"] == 0
+    assert torch.equal(t, full_t) and torch.equal(l, full_l)
+    assert _units(eng, 23, 4, 448, 0) < _units(eng, 23, 4, 448, 448)
+    assert _units(eng, 23, 4, 448, 0) == _units(eng, 23, 4, 448, 64) >= _units(eng, 23, 4, 64, 0)
+
+
+@pytest.mark.parametrize("nb", [1, 4])
+def test_paged_kv_short_pool_preempts_and_still_gives_the_same_tokens(gpu_lib, nb):
+    """A pool far too small for the windows in flight: the scheduler preempts the youngest slot (device-side abort, window
+    re-queued, decoded again from scratch later) instead of failing, the oldest window always progresses, and every window
+    still gets exactly the tokens of the uncontended run (f32 mode: bit-exact whatever the slot history)."""
+    eng = tiny_engine("f32")
+    x = tiny_feats(23)
+    ref_t, ref_l = gen(eng, x, nb, 448, kv_positions=448)
+    longest = int(ref_l.max())
+    assert longest > 16
+    # 8 slots sharing 8 positions per slot on average: fewer units (8) than ONE long window needs (ceil(longest / 8)) would be
+    # refused, so give the pool exactly one slot's worth of max_length = 64 -> 8 units for 8 slots
+    eng.release_workspace()
+    t, l = gen(eng, x, nb, 64, n_slots=8, kv_positions=8)
+    st = eng.last_stats()
+    assert st["kv_units_total"] == 8 and st["n_preemptions"] > 0, st      # 8 slots x 1 page == one slot's worth of 64 positions
+    assert st["kv_units_peak"] <= 8
+    ref64_t, ref64_l = gen(eng, x, nb, 64, n_slots=8, kv_positions=64)
+    assert eng.last_stats()["n_preemptions"] == 0
+    assert torch.equal(t, ref64_t) and torch.equal(l, ref64_l)
+    if longest <= 64:
+        assert torch.equal(l, ref_l) and torch.equal(t[:, :64], ref_t[:, :64])
+    # a milder shortage with the refill running: 23 windows through 5 slots with 16 positions per slot on average
+    eng.release_workspace()
+    t2, l2 = gen(eng, x, nb, 448, n_slots=5, kv_positions=16, refill_min=1)
+    assert torch.equal(l2, ref_l) and torch.equal(t2, ref_t)
+    assert eng.last_stats()["kv_units_total"] == 56                      # max(5 slots x 2 pages, one slot's worth of 448 positions)
+    eng.release_workspace()
+    t3, l3 = gen(eng, x, nb, 100, n_slots=8, kv_positions=16, refill_min=1)
+    st3 = eng.last_stats()
+    assert st3["kv_units_total"] == 16 and st3["n_preemptions"] > 0, st3
+    r3t, r3l = gen(eng, x, nb, 100, n_slots=8, kv_positions=100, refill_min=1)
+    assert eng.last_stats()["n_preemptions"] == 0
+    assert torch.equal(l3, r3l) and torch.equal(t3, r3t)
+
+
+def test_paged_kv_workspace_too_small_is_an_error(gpu_lib):
+    """Less than one slot's worth of pages (a lone window could not reach max_length) is refused, not deadlocked."""
+    import ctypes as C
+    from whisperseg_amd import _lib
+    eng = tiny_engine("f32")
+    x = tiny_feats(2)
+    need = eng.lib.wseg_workspace_bytes(eng.handle, 2, 4, 448)
+    ws = torch.empty(need // 4, dtype=torch.uint8, device="cuda:0")
+    gp = _lib.GenerateParams()
+    for i, tok in enumerate(TM.PROMPT):
+        gp.prompt[i] = tok
+    gp.prompt_len, gp.eos_token_id, gp.pad_token_id, gp.max_length, gp.num_beams, gp.length_penalty = 3, TM.EOT, TM.EOT, 448, 4, 1.0
+    toks = torch.empty((2, 448), dtype=torch.int32, device="cuda:0")
+    lens = torch.empty((2,), dtype=torch.int32, device="cuda:0")
+    rc = eng.lib.wseg_generate(eng.handle, x.data_ptr(), 2, C.byref(gp), ws.data_ptr(), ws.numel(), toks.data_ptr(), lens.data_ptr(), None)
+    assert rc == -3 and b"workspace too small" in eng.lib.wseg_last_error()

@@ -61,6 +61,36 @@ def rnd(x, fmt):
 STAGES = ("egemm", "dgemm", "ckvg", "lm")
 
 
+def e5m2_quant(x, pre_scale=1.0):
+    """UNSCALED bf8 (e5m2: 2 mantissa bits, normals down to 2^-14, subnormal step 2^-16, max 57344) of x * pre_scale, returned at
+    the original magnitude: no block scales at all — the 5-bit exponent covers the range by itself."""
+    y = (x * pre_scale).clamp(-57344.0, 57344.0)
+    e = torch.floor(torch.log2(y.abs().clamp_min(1e-38))).clamp(min=-14, max=15)
+    step = torch.exp2(e - 2)
+    return torch.round(y / step) * step / pre_scale
+
+
+def mx_quant(x, fmt, block=32):
+    """Block-scaled micro-float quantisation along the last dim (blocks of 32, one power-of-two scale per block — what the gfx950
+    v_mfma_scale_f32_*_f8f6f4 instructions consume): fmt "e2m3" (fp6: max 7.5, 3 mantissa bits) or "e4m3" (fp8: max 448).  The
+    scale is the smallest power of two that brings the block's maximum inside the element range (no saturation), elements are
+    rounded to nearest even.  Returns the dequantised tensor."""
+    emax, vmax, emin = (2, 7.5, 0) if fmt == "e2m3" else (8, 448.0, -6)
+    shp = x.shape
+    k = shp[-1]
+    pad = (-k) % block
+    xp = F.pad(x, (0, pad)) if pad else x
+    xb = xp.reshape(*shp[:-1], -1, block)
+    amax = xb.abs().amax(dim=-1, keepdim=True).clamp_min(1e-38)
+    scale = torch.exp2(torch.ceil(torch.log2(amax / vmax)))
+    y = xb / scale
+    e = torch.floor(torch.log2(y.abs().clamp_min(1e-38))).clamp(min=emin, max=emax)
+    step = torch.exp2(e - 3)
+    q = torch.round(y / step) * step                      # torch.round is half-to-even
+    out = (q * scale).reshape(*shp[:-1], -1)
+    return out[..., :k] if pad else out
+
+
 class Policy:
     def __init__(self, text):
         self.fmt = dict(gemm="f32", eattn="f32", ck="f32", cv="f32", skv="f32", dq="f32")
@@ -92,6 +122,29 @@ class Policy:
         b = sd[prefix + ".bias"] if bias else None
         if fmt == "f32":
             return F.linear(x, w, b)
+        if fmt == "f16m8u":
+            # cross terms on UNSCALED bf8 (e5m2) copies: hi8 = e5m2(hi), lo8 = e5m2(lo * 2^11) (constant scale, undone by the MFMA's
+            # scale operand)
+            key = (prefix, fmt)
+            if key not in self.wcache:
+                wh = w.clamp(-65504, 65504).half().float()
+                self.wcache[key] = (wh, e5m2_quant(wh), e5m2_quant(w - wh, 2048.0))
+            wh, wh_q, wl_q = self.wcache[key]
+            xh = x.clamp(-65504, 65504).half().float()
+            y = F.linear(xh, wh) + (F.linear(e5m2_quant(xh), wl_q) + F.linear(e5m2_quant(x - xh, 2048.0), wh_q))
+            return y + b if b is not None else y
+        if fmt in ("f16m6", "f16m8"):
+            # hi x hi on the IEEE-half matrix cores; the two cross terms hi x lo + lo x hi on the block-scaled MX matrix cores
+            # (fp6 e2m3 at 4x / fp8 e4m3 at 2x the 16-bit rate): every operand of a cross term is an MX-quantised copy
+            ef = "e2m3" if fmt == "f16m6" else "e4m3"
+            key = (prefix, fmt)
+            if key not in self.wcache:
+                wh = w.clamp(-65504, 65504).half().float()
+                self.wcache[key] = (wh, mx_quant(wh, ef), mx_quant(w - wh, ef))
+            wh, wh_q, wl_q = self.wcache[key]
+            xh = x.clamp(-65504, 65504).half().float()
+            y = F.linear(xh, wh) + (F.linear(mx_quant(xh, ef), wl_q) + F.linear(mx_quant(x - xh, ef), wh_q))
+            return y + b if b is not None else y
         if fmt.endswith("x2w") or fmt.endswith("x2a"):
             base = torch.bfloat16 if fmt.startswith("bf16") else torch.float16
             key = (prefix, fmt)
@@ -122,6 +175,24 @@ class Policy:
         fmt = self.fmt["egemm"]
         if fmt == "f32":
             return F.conv1d(x, w, b, **kw)
+        if fmt == "f16m8u":
+            wh = w.half().float(); xh = x.half().float()
+            return F.conv1d(xh, wh, b, **kw) + (F.conv1d(e5m2_quant(xh), e5m2_quant(w - wh, 2048.0), None, **kw) +
+                                                 F.conv1d(e5m2_quant(x - xh, 2048.0), e5m2_quant(wh), None, **kw))
+        if fmt in ("f16m6", "f16m8"):
+            # as an im2col GEMM: K = tap * C + channel, blocks of 32 along K (the channel dim padded to a multiple of 32 per tap)
+            ef = "e2m3" if fmt == "f16m6" else "e4m3"
+            o, c, kt = w.shape
+            stride, padding = kw.get("stride", 1), kw.get("padding", 0)
+            cols = F.unfold(x.unsqueeze(-1), (kt, 1), padding=(padding, 0), stride=(stride, 1))      # [B, C * kt, T']
+            bsz, _, tt = cols.shape
+            cols = cols.reshape(bsz, c, kt, tt).permute(0, 3, 2, 1)                                   # [B, T', tap, C]
+            cp = (-c) % 32
+            cols = F.pad(cols, (0, cp)).reshape(bsz, tt, kt * (c + cp))
+            wm = F.pad(w.permute(0, 2, 1), (0, cp)).reshape(o, kt * (c + cp))
+            wh = wm.half().float(); xh = cols.half().float()
+            y = F.linear(xh, wh) + (F.linear(mx_quant(xh, ef), mx_quant(wm - wh, ef)) + F.linear(mx_quant(cols - xh, ef), mx_quant(wh, ef)))
+            return (y + b).permute(0, 2, 1)
         if fmt.endswith("x2w") or fmt.endswith("x2a"):
             base = torch.bfloat16 if fmt.startswith("bf16") else torch.float16
             wh = w.to(base).float(); xh = x.to(base).float()
@@ -303,6 +374,27 @@ def main():
         with open(dest) as f:
             res = json.load(f)
     for text in sys.argv[2:]:
+        if text.startswith("logiterr:"):
+            # first-step logits of 8 sweep recordings' first windows under the policy against the fp32 oracle
+            pol = text[len("logiterr:"):]
+            sego, segp = OracleSegmenter(Policy("")), OracleSegmenter(Policy(pol))
+            errs, scale = [], 0.0
+            for run in sweep[:32:4]:
+                audio = GI.tiny_recording(run["seed"], run["n_windows"])
+                sl = sego.get_sliced_audios_features(audio, TM.SR, 0, TM.STS, 1)
+                feats = torch.from_numpy(np.stack([s_[2] for s_ in sl[:2]]))
+                outs = []
+                for P_ in (sego.P, segp.P):
+                    enc = encoder_forward(P_, sego.sd, sego.cfg, feats)
+                    dec = Decoder(P_, sego.sd, sego.cfg, enc)
+                    outs.append(dec.step(torch.tensor([TM.PROMPT] * feats.shape[0])))
+                errs.append(float((outs[0] - outs[1]).abs().max()))
+                scale = max(scale, float(outs[0].abs().max()))
+            res[text] = {"max_abs_err": max(errs), "mean_max_abs_err": float(np.mean(errs)), "logit_scale": scale}
+            print(text, res[text], flush=True)
+            with open(dest, "w") as f:
+                json.dump(res, f, indent=1)
+            continue
         if text == "margins":
             seg = OracleSegmenter(Policy(""), collect_margins=True)
             r = score(seg, sweep)

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # WSEG_LIB: measurement builds only (tools/stamps.py loads lib/libwseg_stamps<N>.so); the product path is the default
 LIB_PATH = os.environ.get("WSEG_LIB") or os.path.join(_HERE, "lib", "libwseg.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class LogmelDesc(C.Structure):
@@ -33,7 +33,8 @@ class GenerateParams(C.Structure):
 class GenerateStats(C.Structure):
     _fields_ = [("n_windows", C.c_int32), ("n_slots", C.c_int32), ("n_steps", C.c_int32), ("n_admissions", C.c_int32),
                 ("slot_steps_active", C.c_int64), ("slot_steps_total", C.c_int64),
-                ("queued_slot_steps_active", C.c_int64), ("queued_slot_steps_total", C.c_int64)]
+                ("queued_slot_steps_active", C.c_int64), ("queued_slot_steps_total", C.c_int64),
+                ("kv_units_total", C.c_int32), ("kv_units_peak", C.c_int32), ("n_preemptions", C.c_int32), ("reserved_", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/wseg.h declares.
@@ -51,6 +52,7 @@ SYMBOLS = {
     "wseg_model_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
     "wseg_model_ready": (C.c_int, [C.c_void_p]),
     "wseg_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "wseg_workspace_bytes_kv": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "wseg_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "wseg_generate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(GenerateParams), C.c_void_p, C.c_size_t,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),

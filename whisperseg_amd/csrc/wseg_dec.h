@@ -33,6 +33,8 @@ struct DecodeState {
   int* fin_flag;                   // [W][nb]
   int* fin_len;                    // [W][nb]  generated length of each finished slot
   int* unsat;                      // [W]      is_early_stop_heuristic_unsatisfied (beam) / unfinished (greedy)
+  const int* kv_pt;                // [W][npg] pool unit holding positions [KV_PAGE k, KV_PAGE (k + 1)) of the slot's self K / V
+  int npg;                         // page-table entries per slot = ceil(L / KV_PAGE)
   unsigned char* anc;              // [W][nb][L] cache slot (beam index) that holds position p of this row's history
   float* cand_val;                 // [R][Kc]
   int* cand_tok;                   // [R][Kc]
@@ -43,10 +45,14 @@ struct DecodeState {
 int launch_decode_reset(const DecodeState& st, hipStream_t s);
 // slots[i] starts decoding window wins[i] at position 0 (device arrays of n entries)
 int launch_decode_admit(const DecodeState& st, const int* slots, const int* wins, int n, hipStream_t s);
+// page-table updates: kv_pt[pairs[2 i]] = pairs[2 i + 1] for i < n (device array of 2 n ints, written by the scheduler)
+int launch_kv_assign(int* kv_pt, const int* pairs, int n, hipStream_t s);
+// preemption: slots[i] stops decoding and produces no output (its window is re-queued by the scheduler)
+int launch_decode_abort(const DecodeState& st, const int* slots, int n, hipStream_t s);
 int launch_build_suppress_mask(unsigned char* mask, int V, const int* sup, int n_sup, const int* bsup, int n_bsup, hipStream_t s);
 // x[r][:] = tok_emb[tokens_in[r]][:] + pos_emb[pos[slot of r]][:]   (x: fp32 residual stream)
 int launch_embed(int dtype, const DecodeState& st, const void* tok_emb, const void* pos_emb, void* x, int d, hipStream_t s);
-// decoder self-attention over the KV cache [R][H][L][64] with per-position ancestry
+// decoder self-attention over the paged KV cache (pool of one layer: [units][nb][H][KV_PAGE][64], st.kv_pt) with per-position ancestry
 // qkv_part != nullptr: q/k/v of this step arrive as split-K partials [z][m_pad][3d] (+ qkv_bias); the kernel finishes the
 // reduction, appends k/v to the cache and uses them (saves the separate reduction launch).
 int launch_dec_self_attn(int dtype, const DecodeState& st, const void* q, void* kc, void* vc, void* out,

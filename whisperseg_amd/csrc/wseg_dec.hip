@@ -54,6 +54,16 @@ __global__ __launch_bounds__(256) void decode_admit_kernel(DecodeState st, const
   }
 }
 
+__global__ void kv_assign_kernel(int* __restrict__ kv_pt, const int* __restrict__ pairs, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) kv_pt[pairs[2 * i]] = pairs[2 * i + 1];
+}
+
+__global__ void decode_abort_kernel(DecodeState st, const int* __restrict__ slots, int n) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i < n) { const int w = slots[i]; st.done[w] = 1; st.win[w] = -1; st.unsat[w] = 0; }
+}
+
 __global__ void suppress_mask_kernel(unsigned char* mask, int V, const int* sup, int n_sup, const int* bsup, int n_bsup) {
   // single block: clear, then set bits
   for (int i = threadIdx.x; i < V; i += blockDim.x) mask[i] = 0;
@@ -161,14 +171,16 @@ __global__ __launch_bounds__(64, 8) void dec_self_attn_kernel(DecodeState st, co
   // path) the query.  A wave of this kernel is a chain of dependent loads at full occupancy (81 920 single-wave workgroups at
   // 1 024 slots, ten rounds of ~7 us): as separate steps the flag, the position and the ancestry were three links of it.
   const unsigned char* anc = st.anc + (size_t)r * L;
+  const int* pt = st.kv_pt + (size_t)w * st.npg;
   const int idle = st.done[w];
   const int pos = st.pos[w];
   int anc0 = anc[min(lane, L - 1)];
+  int pg0 = pt[min(lane, L - 1) / KV_PAGE];       // pool unit of position `lane` (same round trip: depends on nothing)
   float qv[8];
   qv[0] = 0.f;
   const bool fused = pi.part != nullptr;
   if (!fused) load8<T>(q + (size_t)r * d + h * 64 + sub * 8, qv);
-  asm volatile("" : "+v"(anc0), "+v"(qv[0]));     // keeps the loads above the branch (the compiler would sink them to their uses)
+  asm volatile("" : "+v"(anc0), "+v"(pg0), "+v"(qv[0]));     // keeps the loads above the branch (the compiler would sink them to their uses)
   if (idle) return;                               // idle slot: nothing to append
   WSEG_STAMP(1, 1);
   const int n = pos + 1;                          // keys 0 .. pos (the current token's K/V were just appended)
@@ -180,14 +192,21 @@ __global__ __launch_bounds__(64, 8) void dec_self_attn_kernel(DecodeState st, co
     const float k1 = El<T>::rnd(reduce1<T>(pi, r, d + h * 64 + lane, qkv_bias));
     const float v1 = El<T>::rnd(reduce1<T>(pi, r, 2 * d + h * 64 + lane, qkv_bias));
     sq[lane] = El<T>::rnd(q1 * scale);
-    const size_t at = (((size_t)r * H + h) * L + (n - 1)) * 64 + lane;
+    // this step's own page: lane n - 1 holds its unit when n <= 64 (no further round trip)
+    const int own_unit = n <= 64 ? __builtin_amdgcn_readlane(pg0, __builtin_amdgcn_readfirstlane(n - 1)) : pt[(n - 1) / KV_PAGE];
+    const size_t at = ((((size_t)own_unit * st.nb + (r - w * st.nb)) * H + h) * KV_PAGE + ((n - 1) % KV_PAGE)) * 64 + lane;
     El<T>::st(kc + at, k1);
     El<T>::st(vc + at, v1);
     snk[lane] = k1;
     snv[lane] = v1;
   }
   WSEG_STAMP(1, 2);                                     // q | k | v reduced (fused path), cache rows appended
-  for (int t = lane; t < n; t += 64) srow[t] = w * st.nb + (t == n - 1 ? (r - w * st.nb) : (t < 64 ? anc0 : (int)anc[t]));
+  // srow[t]: index of the 64-element cache row of position t = ((unit nb + beam) H + h) KV_PAGE + t % KV_PAGE
+  for (int t = lane; t < n; t += 64) {
+    const int beam = t == n - 1 ? (r - w * st.nb) : (t < 64 ? anc0 : (int)anc[t]);
+    const int unit = t < 64 ? pg0 : pt[t / KV_PAGE];
+    srow[t] = ((unit * st.nb + beam) * H + h) * KV_PAGE + (t % KV_PAGE);
+  }
   __syncthreads();
   WSEG_STAMP(1, 3);
   if (fused) {
@@ -202,7 +221,7 @@ __global__ __launch_bounds__(64, 8) void dec_self_attn_kernel(DecodeState st, co
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int tl = min(u * 8 + rowl, fused ? max(n - 2, 0) : n - 1);
-      vfirst[u].ld(vc + (((size_t)srow[tl] * H + h) * L + tl) * 64 + sub * 8);
+      vfirst[u].ld(vc + (size_t)srow[tl] * 64 + sub * 8);
     }
   }
   for (int t0 = 0; t0 < n; t0 += 32) {
@@ -211,7 +230,7 @@ __global__ __launch_bounds__(64, 8) void dec_self_attn_kernel(DecodeState st, co
     for (int u = 0; u < 4; ++u) {
       // unconditional clamped loads (see the cross-attention kernel); the fused step's own key is patched in after
       const int tl = min(t0 + u * 8 + rowl, fused ? max(n - 2, 0) : n - 1);
-      kr[u].ld(kc + (((size_t)srow[tl] * H + h) * L + tl) * 64 + sub * 8);
+      kr[u].ld(kc + (size_t)srow[tl] * 64 + sub * 8);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -245,7 +264,7 @@ __global__ __launch_bounds__(64, 8) void dec_self_attn_kernel(DecodeState st, co
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int tl = min(t0 + u * 8 + rowl, fused ? max(n - 2, 0) : n - 1);
-        vfirst[u].ld(vc + (((size_t)srow[tl] * H + h) * L + tl) * 64 + sub * 8);
+        vfirst[u].ld(vc + (size_t)srow[tl] * 64 + sub * 8);
       }
     }
 #pragma unroll
@@ -1126,6 +1145,18 @@ int launch_decode_admit(const DecodeState& st, const int* slots, const int* wins
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
+int launch_kv_assign(int* kv_pt, const int* pairs, int n, hipStream_t s) {
+  if (n <= 0) return WSEG_OK;
+  hipLaunchKernelGGL(kv_assign_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, kv_pt, pairs, n);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+int launch_decode_abort(const DecodeState& st, const int* slots, int n, hipStream_t s) {
+  if (n <= 0) return WSEG_OK;
+  hipLaunchKernelGGL(decode_abort_kernel, dim3(cdiv(n, 64)), dim3(64), 0, s, st, slots, n);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
 int launch_build_suppress_mask(unsigned char* mask, int V, const int* sup, int n_sup, const int* bsup, int n_bsup, hipStream_t s) {
   hipLaunchKernelGGL(suppress_mask_kernel, dim3(1), dim3(1024), 0, s, mask, V, sup, n_sup, bsup, n_bsup);
   WSEG_LAUNCH_CHECK();
@@ -1146,6 +1177,7 @@ int launch_embed(int dtype, const DecodeState& st, const void* tok_emb, const vo
 int launch_dec_self_attn(int dtype, const DecodeState& st, const void* q, void* kc, void* vc, void* out, int H, int d,
                          const PartialInfo* qkv_part, const void* qkv_bias, float scale, hipStream_t s) {
   if (st.L > 512) { set_error("self-attention: max_length %d > 512", st.L); return WSEG_ERR_INVALID; }
+  if (!st.kv_pt || st.npg * KV_PAGE < st.L) { set_error("self-attention: page table missing"); return WSEG_ERR_STATE; }
   const int R = st.W * st.nb;
   PartialInfo pi;
   if (qkv_part) pi = *qkv_part;

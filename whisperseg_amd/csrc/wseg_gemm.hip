@@ -95,6 +95,10 @@ __device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, fl
     typedef typename IO<T>::A AT;
     if (IO<T>::split && ep.qkv_mode == 1) put((float*)nullptr, 0, v);
     else {
+      if constexpr (IO<T>::split) {                // the encoder attention's Q / K / V^T are IEEE-half planes in BOTH split modes:
+#pragma unroll                                     // saturate like every other split operand (inf - inf = NaN in the lo plane otherwise)
+        for (int i = 0; i < 4; ++i) v[i] = H16<AT>::sat(v[i]);
+      }
       put((AT*)nullptr, 0, v);
       if (IO<T>::split && ep.qkv_mode == 2) {      // lo plane: x - rn(x)
         float lo[4];
@@ -128,8 +132,12 @@ __device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, fl
       for (int i = 0; i < 4; ++i) v[i] *= ep.scale;
       Vec4<PT>::st((PT*)ep.q + (size_t)m * d + nn, v);
     } else {
-      const int pos = ep.pos_ptr[m / ep.pos_div];
-      PT* dst = (PT*)(sec == 1 ? ep.k : ep.v) + (((size_t)m * ep.n_heads + h) * ep.t_pad + pos) * 64 + e;
+      const int slot = m / ep.pos_div, beam = m - slot * ep.pos_div;
+      if (ep.idle_ptr[slot]) return;
+      const int pos = ep.pos_ptr[slot];
+      const int unit = ep.kv_pt[(size_t)slot * ep.kv_npg + pos / KV_PAGE];
+      PT* dst = (PT*)(sec == 1 ? ep.k : ep.v) +
+                ((((size_t)unit * ep.pos_div + beam) * ep.n_heads + h) * KV_PAGE + (pos % KV_PAGE)) * 64 + e;
       Vec4<PT>::st(dst, v);
     }
   } else if constexpr (EPI == EPI_SCALE) {
@@ -207,6 +215,10 @@ __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, f
     typedef typename IO<T>::A AT;
     if (IO<T>::split && ep.qkv_mode == 1) put((float*)nullptr, 0, v);
     else {
+      if constexpr (IO<T>::split) {                // IEEE-half planes in both split modes: saturate (see epi_apply)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = H16<AT>::sat(v[i]);
+      }
       put((AT*)nullptr, 0, v);
       if (IO<T>::split && ep.qkv_mode == 2) {      // lo plane: x - rn(x)
         float lo[8];

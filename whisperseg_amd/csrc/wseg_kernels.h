@@ -4,6 +4,13 @@
 
 namespace wseg {
 
+// Decoder self-attention K / V live in PAGES of KV_PAGE positions, allocated on demand by wseg_generate's scheduler from a pool
+// sized for the EXPECTED, not the maximal, sequence length (the API default max_length = 448, reference model.py:406-409, would
+// otherwise cost 0.6-1.3 MiB per position per slot up front: 376 MiB per slot, against 10-60 tokens a real window emits).
+// A pool UNIT = one page of every beam row of a slot, in every layer, K and V:  pool[layer][unit][beam][head][KV_PAGE][64].
+// Page table: kv_pt[slot][position / KV_PAGE] -> unit (the beams of a slot advance together, so one entry serves them all).
+constexpr int KV_PAGE = 8;
+
 // ---------------------------------------------------------------------------------------------
 // GEMM:  C[m][n] = sum_k A[m][k] * W[n][k]   (A [M][lda], W [N][ldw]; both K-contiguous, i.e. W is a
 // torch.nn.Linear weight as stored).  Epilogues fuse bias / GELU / residual / layout scatter.
@@ -16,7 +23,7 @@ enum EpiKind {
   EPI_QKV_ENC,       // fused q|k|v: q*scale -> Q[b][h][t][64], k -> K[b][h][t][64], v -> Vt[b][h][64][Tp]
   EPI_KV_CROSS,      // fused k|v of one decoder layer: K[b][h][t][64], V[b][h][t][64]
   EPI_F32,           // out_f32[m][n] = acc (+ bias)
-  EPI_QKV_DEC,       // decoder step: q*scale -> q[m][n]; k,v -> self cache [m][h][pos][64]
+  EPI_QKV_DEC,       // decoder step: q*scale -> q[m][n]; k,v -> paged self cache [unit][beam][h][pos % KV_PAGE][64]
   EPI_SCALE,         // out = (acc + bias) * scale                                (cross-attention q)
   EPI_COUNT
 };
@@ -34,10 +41,14 @@ struct EpiParams {
   void* v = nullptr;
   int d_model = 0;
   int t_len = 1;               // rows per window (500)
-  int t_pad = 1;               // padded rows per (b,h) slab (512) / cache capacity for EPI_QKV_DEC
+  int t_pad = 1;               // padded rows per (b,h) slab (512)
   int n_heads = 1;
   const int* pos_ptr = nullptr;  // device [rows / pos_div]: current decode position of each window slot (EPI_QKV_DEC)
   int pos_div = 1;               // rows (beams) per slot
+  const int* kv_pt = nullptr;    // device [slots][kv_npg]: pool unit of each KV_PAGE positions of a slot (EPI_QKV_DEC)
+  int kv_npg = 0;
+  const int* idle_ptr = nullptr; // device [slots]: 1 = the slot is idle (EPI_QKV_DEC must not store its K / V: the page its stale
+                                 // table entry names may already belong to another slot)
   const int* slot_map = nullptr; // device [M / t_len]: destination window slot of each window of the batch (EPI_KV_CROSS); null = identity
   float* out_f32 = nullptr;
   int qkv_mode = 0;              // split-precision modes, EPI_QKV_ENC storage of Q / K / V^T (x3_enc_attention_mode): 0 = IEEE half,

@@ -5,6 +5,7 @@
 // greedy / beam-search decoding (HF generation/utils.py:3208-3510).  The host code below only enqueues
 // kernels on the caller's stream; all decoding state lives in the caller-provided workspace.
 #include <algorithm>
+#include <deque>
 #include <map>
 #include <string>
 #include <vector>
@@ -25,6 +26,10 @@ struct DecLayer {
 struct DecPlan {   // decoder-side buffers (W window slots)
   int W = 0;
   char *ck, *cv, *sk, *sv, *dx, *dy, *dq, *dattn, *dh, *logits, *first_logits, *splitk, *mask;
+  int kv_units = 0;                          // pool units of the paged self-attention K / V (wseg_kernels.h)
+  size_t kv_layer_stride = 0;                // bytes between the pools of consecutive layers (K and V alike)
+  int* kv_pt = nullptr;                      // page table [W][npg]
+  int* kv_pairs = nullptr;                   // scratch of the page-table update kernel [2 * W]
   char *tk_val, *tk_idx, *tk_stat;
   int *adm_slots, *adm_wins, *ret_slots;     // device lists written by the scheduler (admission / retirement)
   int* seed_dev;                             // sampling seed (2 words), rewritten per call: the step graph stays valid
@@ -79,7 +84,8 @@ struct wseg_model {
   // last wseg_generate call: whole-call event pair, geometry, scheduler statistics
   int ev_total[2] = {-1, -1};
   bool timing_valid = false;
-  int last_W = 0, last_nb = 0, last_L = 0;
+  int last_W = 0, last_nb = 0, last_L = 0, last_units = 0;
+  bool first_logits_valid = false;
   wseg_generate_stats stats = {};
 };
 
@@ -90,13 +96,30 @@ void add_slot(wseg_model* m, const std::string& name, const void** field, size_t
   m->slots[name] = Slot{field, elems * m->es, false};
 }
 
-// Lay out the workspace for W window slots (and encoder passes of up to W windows), nb beams, capacity L positions.
-// base may be null (size query).
-void make_plan(const wseg_model* m, int W, int nb, int L, char* base, Plan& p) {
+// The encoder (and the cross-K/V GEMMs behind it) runs over at most ENC_CHUNK windows at a time: its activations (FFN hidden:
+// 10 MB per window in the 16-bit modes, 20 MB in the split modes) then stop growing with the slot count, and a pass of 256
+// windows (128 000 rows: the r01 / r02 headline workload) already fills the chip for tens of rounds.
+constexpr int ENC_CHUNK = 256;
+// Default self-K/V pool of wseg_workspace_bytes: positions per slot, or max_length if that is smaller.
+constexpr int KV_DEFAULT_POSITIONS = 64;
+
+int kv_pages(int L) { return (L + KV_PAGE - 1) / KV_PAGE; }
+// pool units for W slots holding `per` positions each on average — never less than ONE slot's worth of max_length (the scheduler's
+// progress guarantee: a lone window can always finish)
+int kv_units_for(int W, int L, int per) { return std::max(W * kv_pages(per < L ? per : L), kv_pages(L)); }
+int kv_default_units(int W, int L) { return kv_units_for(W, L, KV_DEFAULT_POSITIONS); }
+size_t kv_unit_bytes(const wseg_model* m, int nb) {      // one unit: every layer, K and V
+  return (size_t)m->cfg.dec_layers * 2 * nb * m->cfg.n_heads * KV_PAGE * 64 * m->es;
+}
+
+// Lay out the workspace for W window slots (encoder passes of up to min(W, ENC_CHUNK) windows), nb beams, capacity L positions,
+// kv_units pool units of self-attention K / V.  base may be null (size query).
+void make_plan(const wseg_model* m, int W, int nb, int L, int kv_units, char* base, Plan& p) {
   const wseg_model_config& c = m->cfg;
   const size_t es = m->es;
   const size_t d = c.d_model, H = c.n_heads, ffn = c.ffn;
-  const size_t M1p = align_up((size_t)W * c.spec_cols, 256), Mp = align_up((size_t)W * c.enc_positions, 256);
+  const int We = W < ENC_CHUNK ? W : ENC_CHUNK;
+  const size_t M1p = align_up((size_t)We * c.spec_cols, 256), Mp = align_up((size_t)We * c.enc_positions, 256);
   char* cur = base;
   auto take = [&](size_t bytes) { char* q = cur; cur += align_up(bytes, 256); return q; };
   // encoder: a1 | h1 | a2 are dead once conv2 has run; hbuf reuses their space.
@@ -109,9 +132,9 @@ void make_plan(const wseg_model* m, int W, int nb, int L, char* base, Plan& p) {
   p.hbuf = u;
   p.x = take(Mp * d * 4);                          // the residual stream is fp32 in every mode
   p.y = take(Mp * d * es);
-  p.q = take((size_t)W * H * m->tp * 64 * es);
-  p.k = take((size_t)W * H * m->tp * 64 * es);
-  p.vt = take((size_t)W * H * m->tp * 64 * es);
+  p.q = take((size_t)We * H * m->tp * 64 * es);
+  p.k = take((size_t)We * H * m->tp * 64 * es);
+  p.vt = take((size_t)We * H * m->tp * 64 * es);
   p.enc_out = take(Mp * d * es);
   const size_t Ld = c.dec_layers, Tk = c.enc_positions;
   const size_t maxn = 3 * d > ffn ? 3 * d : ffn;
@@ -121,8 +144,12 @@ void make_plan(const wseg_model* m, int W, int nb, int L, char* base, Plan& p) {
   const size_t ces = (m->x3 && x3_cross_kv24() && nb <= 4) ? 3 : es;      // 24-bit cross K / V (wseg_dec.hip)
   q.ck = take(Ld * Wc * H * Tk * 64 * ces);
   q.cv = take(Ld * Wc * H * Tk * 64 * ces);
-  q.sk = take(Ld * R * H * (size_t)L * 64 * es);
-  q.sv = take(Ld * R * H * (size_t)L * 64 * es);
+  q.kv_units = kv_units;
+  q.kv_layer_stride = align_up((size_t)kv_units * nb * H * KV_PAGE * 64 * es, 256);
+  q.sk = take(Ld * q.kv_layer_stride);
+  q.sv = take(Ld * q.kv_layer_stride);
+  q.kv_pt = (int*)take(Wc * kv_pages(L) * 4);
+  q.kv_pairs = (int*)take(2 * Wc * 4);
   q.dx = take(Rp * d * 4);                         // decoder residual stream, fp32
   q.dy = take(Rp * d * es);
   q.dq = take(Rp * d * es);
@@ -142,6 +169,7 @@ void make_plan(const wseg_model* m, int W, int nb, int L, char* base, Plan& p) {
   q.seed_dev = (int*)take(8);
   DecodeState& st = q.st;
   st.W = (int)Wc; st.nb = nb; st.L = L; st.V = c.vocab; st.ldv = m->vp;
+  st.kv_pt = q.kv_pt; st.npg = kv_pages(L);
   st.pos = (int*)take(Wc * 4);
   st.done = (int*)take(Wc * 4);
   st.win = (int*)take(Wc * 4);
@@ -229,9 +257,8 @@ int run_decoder_step(wseg_model* m, DecPlan& p, bool want_logits, hipStream_t s)
   const int dt = c.dtype, d = c.d_model, H = c.n_heads, ffn = c.ffn, Tk = c.enc_positions;
   const DecodeState& st = p.st;
   const int R = st.W * st.nb;
-  const size_t es = m->es;
-  const size_t self_stride = (size_t)R * H * st.L * 64 * es;
-  const size_t cross_stride = (size_t)st.W * H * Tk * 64 * ((m->x3 && x3_cross_kv24() && st.nb <= 4) ? 3 : es);
+  const size_t self_stride = p.kv_layer_stride;
+  const size_t cross_stride = (size_t)st.W * H * Tk * 64 * ((m->x3 && x3_cross_kv24() && st.nb <= 4) ? 3 : m->es);
   WSEG_TRY(launch_embed(dt, st, m->dec_tok, m->dec_pos, p.dx, d, s));
   EpiParams e;
   auto gemm_resid_ln = [&](const void* A, int K, const void* Wt, const void* bias, const void* g_, const void* b_) -> int {
@@ -256,7 +283,7 @@ int run_decoder_step(wseg_model* m, DecPlan& p, bool want_logits, hipStream_t s)
       } else {
         e = EpiParams();
         e.bias = L.qkv_b; e.q = p.dq; e.k = p.sk + l * self_stride; e.v = p.sv + l * self_stride;
-        e.d_model = d; e.n_heads = H; e.t_pad = st.L; e.pos_ptr = st.pos; e.pos_div = st.nb; e.scale = 0.125f;
+        e.d_model = d; e.n_heads = H; e.pos_ptr = st.pos; e.pos_div = st.nb; e.kv_pt = st.kv_pt; e.kv_npg = st.npg; e.idle_ptr = st.done; e.scale = 0.125f;
         WSEG_TRY(gemm(m, EPI_QKV_DEC, p.dy, d, L.qkv_w, d, R, 3 * d, d, e, &p, s));
         WSEG_TRY(launch_dec_self_attn(dt, st, p.dq, p.sk + l * self_stride, p.sv + l * self_stride, p.dattn, H, d, nullptr, nullptr, 0.125f, s));
       }
@@ -386,11 +413,17 @@ extern "C" int wseg_model_ready(const wseg_model* m) {
   return WSEG_OK;
 }
 
-extern "C" size_t wseg_workspace_bytes(const wseg_model* m, int32_t max_windows, int32_t num_beams, int32_t max_length) {
-  if (!m || max_windows <= 0 || num_beams <= 0 || num_beams > MAX_BEAMS || max_length <= 0) return 0;
+extern "C" size_t wseg_workspace_bytes_kv(const wseg_model* m, int32_t max_windows, int32_t num_beams, int32_t max_length,
+                                          int32_t kv_positions_per_slot) {
+  if (!m || max_windows <= 0 || num_beams <= 0 || num_beams > MAX_BEAMS || max_length <= 0 || kv_positions_per_slot < 0) return 0;
   Plan p;
-  make_plan(m, max_windows, num_beams, max_length, nullptr, p);
+  make_plan(m, max_windows, num_beams, max_length,
+            kv_units_for(max_windows, max_length, kv_positions_per_slot == 0 ? KV_DEFAULT_POSITIONS : kv_positions_per_slot), nullptr, p);
   return p.total + 256;
+}
+
+extern "C" size_t wseg_workspace_bytes(const wseg_model* m, int32_t max_windows, int32_t num_beams, int32_t max_length) {
+  return wseg_workspace_bytes_kv(m, max_windows, num_beams, max_length, 0);
 }
 
 static char* aligned_base(void* ws) { return (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255); }
@@ -402,12 +435,16 @@ extern "C" int wseg_encode(wseg_model* m, const float* feats, int32_t n_windows,
   WSEG_TRY(wseg_model_ready(m));
   if (n_windows <= 0) return WSEG_OK;
   Plan p;
-  make_plan(m, n_windows, 1, 8, aligned_base(workspace), p);
+  make_plan(m, n_windows, 1, 8, kv_default_units(n_windows, 8), aligned_base(workspace), p);
   if (p.total + 256 > workspace_bytes) { set_error("workspace too small: need %zu, have %zu", p.total + 256, workspace_bytes); return WSEG_ERR_STATE; }
-  WSEG_TRY(run_encoder(m, feats, n_windows, p, p.enc_out, s));
-  const size_t rows = (size_t)n_windows * m->cfg.enc_positions;
-  if (m->x3) return launch_operand_to_f32(m->cfg.dtype, p.enc_out, (float*)enc_out, rows, m->cfg.d_model, s);
-  WSEG_HIP_CHECK(hipMemcpyAsync(enc_out, p.enc_out, rows * m->cfg.d_model * m->es, hipMemcpyDeviceToDevice, s));
+  const size_t feat_stride = (size_t)m->cfg.n_mels * m->cfg.spec_cols;
+  for (int w0 = 0; w0 < n_windows; w0 += ENC_CHUNK) {      // passes of at most ENC_CHUNK windows (the encoder buffers' size)
+    const int n = std::min(ENC_CHUNK, n_windows - w0);
+    WSEG_TRY(run_encoder(m, feats + (size_t)w0 * feat_stride, n, p, p.enc_out, s));
+    const size_t rows = (size_t)n * m->cfg.enc_positions, row0 = (size_t)w0 * m->cfg.enc_positions;
+    if (m->x3) WSEG_TRY(launch_operand_to_f32(m->cfg.dtype, p.enc_out, (float*)enc_out + row0 * m->cfg.d_model, rows, m->cfg.d_model, s));
+    else WSEG_HIP_CHECK(hipMemcpyAsync((char*)enc_out + row0 * m->cfg.d_model * m->es, p.enc_out, rows * m->cfg.d_model * m->es, hipMemcpyDeviceToDevice, s));
+  }
   return WSEG_OK;
 }
 
@@ -458,15 +495,22 @@ static int timing_event(Sched& ln, hipStream_t s, int* idx) {
 // The host runs at most `lookahead` steps ahead of the device: the per-step status mirror (done flag of every slot)
 // is read behind an event, which both bounds the wasted steps after the last window finishes and tells the scheduler
 // which slots to retire / refill.
+//
+// Self-attention K / V are PAGED (wseg_kernels.h): the host knows the position every occupied slot feeds at step t (t minus the
+// step it was admitted at), so it hands out a pool unit whenever a slot crosses a page boundary — before the step is launched,
+// through a small page-table update kernel — and takes the slot's units back when it retires.  The pool is sized for the
+// expected length; when it runs short the YOUNGEST slot is preempted (aborted on the device, its window re-queued and later
+// decoded again from scratch: the same tokens), so the oldest window always makes progress, and admissions keep a one-page
+// cushion per window in flight and pause after a preemption until a slot retires.
 static int generate_windows(wseg_model* m, const float* feats, int n_windows, const wseg_generate_params* gp, char* base, int S,
-                            int32_t* out_tokens, int32_t* out_lengths, hipStream_t s) {
+                            int kv_units, int32_t* out_tokens, int32_t* out_lengths, hipStream_t s) {
   Sched& ln = m->sched;
   const wseg_model_config& c = m->cfg;
   const int nb = gp->num_beams, P = gp->prompt_len, L = gp->max_length;
   const int G = gp->refill_min > 0 ? gp->refill_min : (S >= 16 ? S / 8 : 1);                // admit once this many slots are free
   const int K = gp->lookahead > 0 ? (gp->lookahead < PinnedRing::N - 2 ? gp->lookahead : PinnedRing::N - 2) : 1;
   Plan p;
-  make_plan(m, S, nb, L, base, p);
+  make_plan(m, S, nb, L, kv_units, base, p);
   DecPlan& q = p.dec;
   DecodeState& st = q.st;
   st.P = P; st.eos = gp->eos_token_id; st.pad = gp->pad_token_id; st.max_length = L; st.length_penalty = gp->length_penalty;
@@ -475,11 +519,11 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
   st.top_k = (nb == 1 && gp->top_k > 1) ? gp->top_k : 1;
   st.top_p = gp->top_p;
   st.seed = (const unsigned long long*)q.seed_dev;
-  WSEG_TRY(ring_prepare(ln.ring_h2d, S > 2 ? S : 2));
+  WSEG_TRY(ring_prepare(ln.ring_h2d, 2 * S > 2 ? 2 * S : 2));
   WSEG_TRY(ring_prepare(ln.ring_status, S));
   wseg_generate_stats& stats = m->stats;
   stats = wseg_generate_stats();
-  stats.n_windows = n_windows; stats.n_slots = S;
+  stats.n_windows = n_windows; stats.n_slots = S; stats.kv_units_total = kv_units;
   {   // the seed lives in device memory (read by the sampling kernel): per-call values do not invalidate the step graph
     const unsigned long long sd = gp->seed;
     int words[2];
@@ -494,42 +538,109 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
   const bool kv24 = m->x3 && x3_cross_kv24() && nb <= 4;
   const size_t cross_stride = (size_t)S * H * Tk * 64 * (kv24 ? 3 : m->es);
   const size_t feat_stride = (size_t)c.n_mels * c.spec_cols;
+  const int npg = st.npg;
 
   // host view of the slots
   std::vector<int> slot_win(S, -1), slot_from(S, 0);   // window in the slot (-1 = free), first step whose status counts for it
-  std::vector<int> free_slots, tmp_a, tmp_b;
+  std::vector<std::vector<int>> slot_units(S);         // pool units the slot holds, in page order
+  std::vector<int> free_slots, free_units, tmp_a, tmp_b;
   for (int i = S - 1; i >= 0; --i) free_slots.push_back(i);   // popped from the back: lowest slot first
-  int in_flight = 0, t = 0, next_window = 0;
+  for (int i = kv_units - 1; i >= 0; --i) free_units.push_back(i);
+  std::deque<int> queue;                               // windows waiting for a slot (preempted windows return to the front)
+  for (int i = 0; i < n_windows; ++i) queue.push_back(i);
+  int in_flight = 0, t = 0, units_in_use = 0;
+  bool hold_admission = false;                         // set by a preemption, cleared by the next retirement
+  bool first_admission = true;
+  m->first_logits_valid = false;
 
-  // encoder + cross-K/V of windows [w0, w0 + n) into n free slots; their decode state starts at position 0
-  auto admit = [&](int w0, int n) -> int {
+  // encoder + cross-K/V of the consecutive windows [w0, w0 + n) into the slots listed at q.adm_slots + off (device)
+  auto encode_run = [&](int w0, int n, int off) -> int {
+    for (int c0 = 0; c0 < n; c0 += ENC_CHUNK) {
+      const int nc = std::min(ENC_CHUNK, n - c0), wc = w0 + c0;
+      int e0, e1, e2;
+      WSEG_TRY(timing_event(ln, s, &e0));
+      const char* enc_rows = p.enc_out;
+      if (gp->encoder_output && m->x3)      // handed over as fp32: re-split into operand rows for the cross-K/V GEMMs
+        WSEG_TRY(launch_f32_to_operand(c.dtype, (const float*)gp->encoder_output + (size_t)wc * Tk * d, p.enc_out, (size_t)nc * Tk, d, s));
+      else if (gp->encoder_output) enc_rows = (const char*)gp->encoder_output + (size_t)wc * Tk * d * m->es;
+      else WSEG_TRY(run_encoder(m, feats + (size_t)wc * feat_stride, nc, p, p.enc_out, s));
+      WSEG_TRY(timing_event(ln, s, &e1));
+      for (int l = 0; l < c.dec_layers; ++l) {     // cross-attention K/V of every decoder layer, once per window (shared by its beams)
+        EpiParams e;
+        e.bias = m->dec[l].ckv_b; e.k = q.ck + l * cross_stride; e.v = q.cv + l * cross_stride;
+        e.d_model = d; e.t_len = Tk; e.n_heads = H; e.slot_map = q.adm_slots + off + c0; e.kv24 = kv24;
+        WSEG_TRY(gemm(m, EPI_KV_CROSS, enc_rows, d, m->dec[l].ckv_w, d, nc * Tk, 2 * d, d, e, nullptr, s));
+      }
+      WSEG_TRY(timing_event(ln, s, &e2));
+      ln.ev_enc.push_back(e0); ln.ev_enc.push_back(e1); ln.ev_ckv.push_back(e1); ln.ev_ckv.push_back(e2);
+    }
+    return WSEG_OK;
+  };
+  // the first n windows of the queue into n free slots; their decode state starts at position 0
+  auto admit = [&](int n) -> int {
     tmp_a.clear(); tmp_b.clear();
     for (int i = 0; i < n; ++i) {
       const int sl = free_slots.back(); free_slots.pop_back();
-      tmp_a.push_back(sl); tmp_b.push_back(w0 + i);
-      slot_win[sl] = w0 + i; slot_from[sl] = t;
+      const int w = queue.front(); queue.pop_front();
+      tmp_a.push_back(sl); tmp_b.push_back(w);
+      slot_win[sl] = w; slot_from[sl] = t;
     }
     WSEG_TRY(h2d_list(ln, tmp_a.data(), n, q.adm_slots, s));
     WSEG_TRY(h2d_list(ln, tmp_b.data(), n, q.adm_wins, s));
-    int e0, e1, e2;
-    WSEG_TRY(timing_event(ln, s, &e0));
-    const char* enc_rows = p.enc_out;
-    if (gp->encoder_output && m->x3)      // handed over as fp32: re-split into operand rows for the cross-K/V GEMMs
-      WSEG_TRY(launch_f32_to_operand(c.dtype, (const float*)gp->encoder_output + (size_t)w0 * Tk * d, p.enc_out, (size_t)n * Tk, d, s));
-    else if (gp->encoder_output) enc_rows = (const char*)gp->encoder_output + (size_t)w0 * Tk * d * m->es;
-    else WSEG_TRY(run_encoder(m, feats + (size_t)w0 * feat_stride, n, p, p.enc_out, s));
-    WSEG_TRY(timing_event(ln, s, &e1));
-    for (int l = 0; l < c.dec_layers; ++l) {     // cross-attention K/V of every decoder layer, once per window (shared by its beams)
-      EpiParams e;
-      e.bias = m->dec[l].ckv_b; e.k = q.ck + l * cross_stride; e.v = q.cv + l * cross_stride;
-      e.d_model = d; e.t_len = Tk; e.n_heads = H; e.slot_map = q.adm_slots; e.kv24 = kv24;
-      WSEG_TRY(gemm(m, EPI_KV_CROSS, enc_rows, d, m->dec[l].ckv_w, d, n * Tk, 2 * d, d, e, nullptr, s));
+    for (int i = 0; i < n;) {                      // runs of consecutive window indices (a re-queued window breaks a run)
+      int j = i + 1;
+      while (j < n && tmp_b[j] == tmp_b[j - 1] + 1) ++j;
+      WSEG_TRY(encode_run(tmp_b[i], j - i, i));
+      i = j;
     }
-    WSEG_TRY(timing_event(ln, s, &e2));
-    ln.ev_enc.push_back(e0); ln.ev_enc.push_back(e1); ln.ev_ckv.push_back(e1); ln.ev_ckv.push_back(e2);
     WSEG_TRY(launch_decode_admit(st, q.adm_slots, q.adm_wins, n, s));
     in_flight += n;
     stats.n_admissions += 1;
+    return WSEG_OK;
+  };
+  // take a slot out of flight without output (its window goes back to the head of the queue)
+  auto preempt = [&](int sl) -> int {
+    WSEG_TRY(h2d_list(ln, &sl, 1, q.ret_slots, s));
+    WSEG_TRY(launch_decode_abort(st, q.ret_slots, 1, s));
+    queue.push_front(slot_win[sl]);
+    slot_win[sl] = -1;
+    for (int u : slot_units[sl]) free_units.push_back(u);
+    units_in_use -= (int)slot_units[sl].size();
+    slot_units[sl].clear();
+    free_slots.push_back(sl);
+    std::sort(free_slots.begin(), free_slots.end(), [](int a, int b) { return a > b; });
+    --in_flight;
+    stats.n_preemptions += 1;
+    hold_admission = true;
+    return WSEG_OK;
+  };
+  // pool units for every occupied slot that enters a new page at step t (position t - slot_from: the host's upper bound — a slot
+  // that finished inside the look-ahead window is idle on the device and simply does not use the page)
+  auto assign_pages = [&]() -> int {
+    tmp_a.clear();
+    for (int sl = 0; sl < S; ++sl) {
+      if (slot_win[sl] < 0) continue;
+      const int pos = t - slot_from[sl];
+      if (pos >= L || pos % KV_PAGE) continue;
+      while (free_units.empty()) {
+        int victim = -1;                                // youngest slot that holds pages (never the requester)
+        for (int v = 0; v < S; ++v)
+          if (v != sl && slot_win[v] >= 0 && !slot_units[v].empty() && (victim < 0 || slot_from[v] >= slot_from[victim])) victim = v;
+        if (victim < 0) { set_error("self-attention K/V pool exhausted by one window (pool of %d units)", kv_units); return WSEG_ERR_STATE; }
+        // an assignment already queued for the victim in this pass is void: drop it
+        for (size_t i = 0; i + 1 < tmp_a.size();) { if (tmp_a[i] / npg == victim) tmp_a.erase(tmp_a.begin() + i, tmp_a.begin() + i + 2); else i += 2; }
+        WSEG_TRY(preempt(victim));
+      }
+      const int u = free_units.back(); free_units.pop_back();
+      slot_units[sl].push_back(u);
+      ++units_in_use;
+      tmp_a.push_back(sl * npg + pos / KV_PAGE); tmp_a.push_back(u);
+    }
+    if (units_in_use > stats.kv_units_peak) stats.kv_units_peak = units_in_use;
+    if (!tmp_a.empty()) {
+      WSEG_TRY(h2d_list(ln, tmp_a.data(), (int)tmp_a.size(), q.kv_pairs, s));
+      WSEG_TRY(launch_kv_assign(q.kv_pt, q.kv_pairs, (int)tmp_a.size() / 2, s));
+    }
     return WSEG_OK;
   };
 
@@ -543,22 +654,24 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
     else WSEG_TRY(launch_beam_step(st, qs));
     return WSEG_OK;
   };
-  // The step reads every step-dependent value (positions, tokens, ancestry, idle flags, the sampling seed) from device
-  // memory, so ONE captured graph serves all steps and later calls: replay costs ~1.6 us per kernel instead of ~5 us per
+  // The step reads every step-dependent value (positions, tokens, ancestry, idle flags, the page table, the sampling seed) from
+  // device memory, so ONE captured graph serves all steps and later calls: replay costs ~1.6 us per kernel instead of ~5 us per
   // eager launch.  The key holds what the captured kernels take BY VALUE; per-window length caps are applied by the
   // admission kernel (launched outside the graph) and the weight pointers invalidate the key in wseg_model_set_tensor.
   static const bool use_graph = getenv("WSEG_NO_GRAPH") == nullptr;
   std::vector<unsigned char> key;
   {
     auto put = [&](const void* ptr, size_t n) { const unsigned char* b = (const unsigned char*)ptr; key.insert(key.end(), b, b + n); };
-    put(&base, sizeof(base)); put(&S, 4); put(&nb, 4); put(&L, 4);
+    put(&base, sizeof(base)); put(&S, 4); put(&nb, 4); put(&L, 4); put(&kv_units, 4);
     put(&st.P, 4); put(&st.eos, 4); put(&st.pad, 4); put(&st.length_penalty, 4); put(st.prompt, sizeof(st.prompt));
     put(&st.top_k, 4); put(&st.top_p, 4);
   }
+  bool snap_ok = false;                          // did every window of the call start together (first-logits snapshot)?
   auto launch_step = [&]() -> int {
     // the first generated step of a call whose windows all start together is launched eagerly with the logits snapshot
     // (wseg_debug_first_logits); every other step replays the graph
-    const bool snap = t == P - 1 && n_windows <= S;
+    const bool snap = t == P - 1 && snap_ok && stats.n_preemptions == 0;
+    if (snap) m->first_logits_valid = true;
     if (snap || !use_graph) return enqueue_step(snap, s);
     if (!ln.step_graph || ln.step_graph_key != key) {
       if (ln.step_graph) { (void)hipGraphExecDestroy(ln.step_graph); ln.step_graph = nullptr; }
@@ -601,30 +714,45 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
       const int n = (int)tmp_a.size();
       WSEG_TRY(h2d_list(ln, tmp_a.data(), n, q.ret_slots, s));
       WSEG_TRY(launch_finalize(st, q.ret_slots, n, out_tokens, out_lengths, s));
-      for (int sl : tmp_a) free_slots.push_back(sl);
+      for (int sl : tmp_a) {
+        free_slots.push_back(sl);
+        for (int v : slot_units[sl]) free_units.push_back(v);
+        units_in_use -= (int)slot_units[sl].size();
+        slot_units[sl].clear();
+      }
       std::sort(free_slots.begin(), free_slots.end(), [](int a, int b) { return a > b; });
       in_flight -= n;
+      hold_admission = false;
     }
     return WSEG_OK;
   };
 
   int consumed = 0;                               // statuses of steps [0, consumed) have been processed
   while (true) {
-    const int rem = n_windows - next_window;
-    if (rem > 0) {      // refill rule: enough free slots, or the rest of the queue, or nothing else is running
-      const int n_adm = std::min(rem, (int)free_slots.size());
+    const int rem = (int)queue.size();
+    if (rem > 0 && !(hold_admission && in_flight > 0)) {
+      // refill rule: enough free slots, or the rest of the queue, or nothing else is running — and a pool unit for every
+      // admitted window on top of one spare unit per window in flight (16+ steps without a preemption)
+      int n_adm = std::min(rem, (int)free_slots.size());
+      const int spare = (int)free_units.size() - in_flight;
+      n_adm = std::min(n_adm, in_flight == 0 ? (int)free_units.size() : std::max(spare, 0));
       if (n_adm > 0 && (n_adm >= G || n_adm == rem || in_flight == 0)) {
-        WSEG_TRY(admit(next_window, n_adm));
-        next_window += n_adm;
+        if (first_admission) snap_ok = n_adm == n_windows;
+        first_admission = false;
+        WSEG_TRY(admit(n_adm));
       }
     }
-    const bool drained = next_window == n_windows;
-    if (in_flight == 0) break;
+    const bool drained = queue.empty();
+    if (in_flight == 0) {
+      if (!drained) { set_error("scheduler stalled with %d windows queued", (int)queue.size()); return WSEG_ERR_STATE; }
+      break;
+    }
     if (drained) {                // nothing left to admit later: stop launching once every window in flight must have ended
       bool may_run = false;       // (a window admitted before step f feeds its last position, L - 2, at step f + L - 2)
       for (int sl = 0; sl < S && !may_run; ++sl) may_run = slot_win[sl] >= 0 && t < slot_from[sl] + L - 1;
       if (!may_run) break;
     }
+    WSEG_TRY(assign_pages());
     WSEG_TRY(launch_step());
     {   // mirror the idle flags of this step
       int ri;
@@ -642,7 +770,7 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
     while (consumed < t - K) WSEG_TRY(consume_status(consumed++));
   }
   while (consumed < t) WSEG_TRY(consume_status(consumed++));
-  if (in_flight != 0) { set_error("scheduler ended with %d windows in flight", in_flight); return WSEG_ERR_STATE; }
+  if (in_flight != 0 || !queue.empty()) { set_error("scheduler ended with %d windows in flight, %d queued", in_flight, (int)queue.size()); return WSEG_ERR_STATE; }
   stats.n_steps = t;
   return WSEG_OK;
 }
@@ -667,16 +795,32 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
   if (gp->n_slots < 0 || gp->refill_min < 0 || gp->lookahead < 0) { set_error("bad scheduler parameters"); return WSEG_ERR_INVALID; }
   if (nb == 1 && gp->top_k > MAX_CAND) { set_error("top_k %d unsupported (sampling draws among at most %d candidates)", gp->top_k, MAX_CAND); return WSEG_ERR_INVALID; }
   const int S = gp->n_slots > 0 && gp->n_slots < n_windows ? gp->n_slots : n_windows;       // window slots
+  // self-attention K / V pool: every unit the workspace has room for behind the fixed buffers, at most a full set (every slot
+  // to max_length), at least one slot's worth (a lone window can always finish: the scheduler's progress guarantee)
+  const int npg = kv_pages(L), full = S * npg;
   Plan p;
-  make_plan(m, S, nb, L, nullptr, p);
-  if (p.total + 256 > workspace_bytes) { set_error("workspace too small: need %zu, have %zu", p.total + 256, workspace_bytes); return WSEG_ERR_STATE; }
+  make_plan(m, S, nb, L, 0, nullptr, p);
+  const size_t fixed = p.total + 256;
+  long units = workspace_bytes > fixed ? (long)((workspace_bytes - fixed) / kv_unit_bytes(m, nb)) : 0;
+  if (units > full) units = full;
+  while (units >= npg) {      // the per-layer pools are aligned: make sure the chosen count really fits
+    make_plan(m, S, nb, L, (int)units, nullptr, p);
+    if (p.total + 256 <= workspace_bytes) break;
+    --units;
+  }
+  if (units < npg) {
+    make_plan(m, S, nb, L, npg, nullptr, p);
+    set_error("workspace too small: need at least %zu bytes (wseg_workspace_bytes: %zu), have %zu", p.total + 256,
+              wseg_workspace_bytes(m, S, nb, L), workspace_bytes);
+    return WSEG_ERR_STATE;
+  }
   Sched& sc = m->sched;
   sc.ev_used = 0; sc.ev_enc.clear(); sc.ev_ckv.clear();
   m->timing_valid = false;
   WSEG_TRY(timing_event(sc, s, &m->ev_total[0]));
-  WSEG_TRY(generate_windows(m, feats, n_windows, gp, aligned_base(workspace), S, out_tokens, out_lengths, s));
+  WSEG_TRY(generate_windows(m, feats, n_windows, gp, aligned_base(workspace), S, (int)units, out_tokens, out_lengths, s));
   WSEG_TRY(timing_event(sc, s, &m->ev_total[1]));
-  m->last_W = S; m->last_nb = nb; m->last_L = L;
+  m->last_W = S; m->last_nb = nb; m->last_L = L; m->last_units = (int)units;
   m->timing_valid = true;
   return WSEG_OK;
 }
@@ -684,11 +828,11 @@ extern "C" int wseg_generate(wseg_model* m, const float* feats, int32_t n_window
 extern "C" int wseg_debug_first_logits(wseg_model* m, void* workspace, float* out, int32_t n_rows, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   if (!m || !workspace || !out || n_rows <= 0) { set_error("wseg_debug_first_logits: bad argument"); return WSEG_ERR_INVALID; }
-  if (m->last_W <= 0 || n_rows > m->last_W * m->last_nb || m->stats.n_windows > m->stats.n_slots) {
+  if (m->last_W <= 0 || n_rows > m->last_W * m->last_nb || !m->first_logits_valid) {
     set_error("no matching wseg_generate call (all windows must have started together)"); return WSEG_ERR_STATE;
   }
   Plan p;
-  make_plan(m, m->last_W, m->last_nb, m->last_L, aligned_base(workspace), p);
+  make_plan(m, m->last_W, m->last_nb, m->last_L, m->last_units, aligned_base(workspace), p);
   WSEG_HIP_CHECK(hipMemcpy2DAsync(out, (size_t)m->cfg.vocab * 4, p.dec.first_logits, (size_t)m->vp * 4,
                                   (size_t)m->cfg.vocab * 4, (size_t)n_rows, hipMemcpyDeviceToDevice, s));
   return WSEG_OK;

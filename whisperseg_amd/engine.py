@@ -68,10 +68,14 @@ DEFAULT_SUPPRESS_TOKENS = [
 DEFAULT_BEGIN_SUPPRESS_TOKENS = [220, 50257]
 # Window slots decoded concurrently (in-flight batching; include/wseg.h).  Throughput grows with the concurrency until
 # ~1024 windows (whisperseg-large, 4 beams: 14.2 / 15.9 / 17.0 k audio-sec/s at 256 / 512 / 1024 slots — more GEMM rows per
-# weight pass, less launch tail in the attention streams); the workspace is 118 MiB per slot at 35
-# decode positions and 376 MiB at max_length 448 (self-attention cache for the longest allowed sequence), so pick_slots ends at
-# 1024 slots for short decodes and 512 for segment()'s default max_length on a 288 GB part.
+# weight pass, less launch tail in the attention streams).  Since ABI 5 the self-attention K/V are paged: the workspace holds
+# min(max_length, 64) positions per slot on average whatever max_length is, so segment()'s default max_length = 448 keeps the
+# same 1024 slots as a 35-position decode (whisperseg-large, 4 beams, split-precision mode: ~123 MiB of cross K/V + 1.3 MiB per
+# pooled position per slot).
 DEFAULT_SLOTS = 1024
+# consecutive small calls before a much larger workspace is given back (a folder loop over files of very different lengths, or
+# encode() between generate() calls, must not free and re-allocate tens of GB — and re-capture the step graph — on every flip)
+SHRINK_AFTER_CALLS = 4
 
 
 def _round_up(v, a):
@@ -231,7 +235,7 @@ class Engine:
             _lib.check(self.lib.wseg_model_set_tensor(handle, name.encode(), t.data_ptr(), t.numel() * t.element_size()))
         _lib.check(self.lib.wseg_model_ready(handle))
         self._ws = None
-        self._ws_key = None
+        self._small_calls = 0
 
     @classmethod
     def from_state_dict(cls, sd, hf_config, device="cuda:0", dtype="bf16"):
@@ -280,39 +284,54 @@ class Engine:
         except Exception:
             pass
 
-    def _workspace(self, n_slots, num_beams, max_length):
-        need = self.lib.wseg_workspace_bytes(self.handle, n_slots, num_beams, max_length)
+    def _workspace(self, n_slots, num_beams, max_length, kv_positions=0, may_shrink=True):
+        need = self.lib.wseg_workspace_bytes_kv(self.handle, n_slots, num_beams, max_length, int(kv_positions or 0))
         if need == 0:
             raise _lib.WsegError("wseg_workspace_bytes rejected the request")
-        # grow when too small; give a much larger one back (a single long file must not pin ~100 GB for every later short call)
-        if self._ws is None or self._ws.numel() < need or (self._ws.numel() > 4 * need and self._ws.numel() > (2 << 30)):
-            old = 0 if self._ws is None else self._ws.numel()
+        held = 0 if self._ws is None else self._ws.numel()
+        # grow when too small.  Give a much larger one back only after SHRINK_AFTER_CALLS consecutive generate() calls that needed
+        # less than a quarter of it (a single long file must not pin ~100 GB for every later short call, but alternating large
+        # and small requests must not thrash either); encode() never shrinks the decode workspace (may_shrink=False).
+        small = held > 4 * need and held > (2 << 30)
+        if may_shrink:
+            self._small_calls = self._small_calls + 1 if small else 0
+        if held < need or (small and may_shrink and self._small_calls >= SHRINK_AFTER_CALLS):
             self._ws = None
-            if old >= (1 << 30):
-                # hand the old block back to the driver first: kept in torch's cache it could neither be reused for the larger
-                # request nor be seen by pick_slots' free-memory query (a 118-GiB block beside a 140-GiB one does not fit)
+            self._small_calls = 0
+            if held >= (1 << 30):
+                # hand the old block back to the driver first: kept in torch's cache it could not be reused for the larger request
                 torch.cuda.empty_cache()
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            try:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            except torch.OutOfMemoryError as exc:
+                raise _lib.WsegError(
+                    f"cannot allocate the {need / 2 ** 30:.1f}-GiB decode workspace for {n_slots} window slots on {self.device} (the slot "
+                    "count is derived from the device's TOTAL memory so that results never depend on what else is resident; "
+                    "lower it with segmenter.max_slots / $WSEG_SLOTS when the GPU is shared)") from exc
         return self._ws
 
     def release_workspace(self):
         """Free the decode workspace (it is re-allocated by the next call)."""
         self._ws = None
+        self._small_calls = 0
 
-    def pick_slots(self, n_windows, num_beams, max_length, n_slots=None):
+    def weight_bytes(self):
+        return sum(t.numel() * t.element_size() for t in self.weights.values())
+
+    def pick_slots(self, n_windows, num_beams, max_length, n_slots=None, kv_positions=0):
         """Window slots for a generate call: min(n_windows, cap) where cap is `n_slots`, else $WSEG_SLOTS, else DEFAULT_SLOTS,
-        halved until the workspace (whisperseg-large, 4 beams, 16-bit modes: 82 MiB of cross-K/V + 0.58 MiB of self-K/V per
-        position + 16 MiB of activations per slot; twice that in the f32 / split-precision modes) fits in 80 % of the free
-        device memory (plus what this engine's current workspace already holds).  The reference bounds memory with
-        `batch_size`; here that role is played by `n_slots` / $WSEG_SLOTS (SegmenterBase.max_slots)."""
+        halved until the workspace fits in 80 % of the device's TOTAL memory minus this engine's weights.  Deliberately NOT a
+        function of the memory that happens to be free: in the 16-bit modes the GEMM plans (and with them the last bits of the
+        logits) follow the row count = slots x beams, so the slot count must be a pure function of (geometry, mode, call
+        parameters, device) for a recording to decode the same way run after run; the count used is
+        reported by last_stats()["n_slots"].  When the GPU is shared and the allocation fails, _workspace raises with the
+        remedy.  The reference bounds memory with `batch_size`; here that role is played by `n_slots` / $WSEG_SLOTS
+        (SegmenterBase.max_slots)."""
         cap = int(n_slots or os.environ.get("WSEG_SLOTS", 0) or DEFAULT_SLOTS)
         s = max(1, min(int(n_windows), cap))
-        free, _ = torch.cuda.mem_get_info(self.device)
-        # blocks torch's allocator has cached but not handed out are as good as free (empty_cache returns them)
-        free += max(0, torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device))
-        own = self._ws.numel() if self._ws is not None else 0
-        budget = max(own, 0.8 * (free + own))          # what this engine already holds is always available to it
-        while s > 1 and self.lib.wseg_workspace_bytes(self.handle, s, num_beams, max_length) > budget:
+        total = torch.cuda.get_device_properties(self.device).total_memory
+        budget = 0.8 * total - self.weight_bytes()
+        while s > 1 and self.lib.wseg_workspace_bytes_kv(self.handle, s, num_beams, max_length, int(kv_positions or 0)) > budget:
             s = (s + 1) // 2
         return s
 
@@ -320,7 +339,7 @@ class Engine:
         """feats float32 device tensor [W, 80, 1000] -> [W, 500, d] in the model dtype (float32 in the split-precision modes)."""
         feats = feats.to(device=self.device, dtype=torch.float32).contiguous()
         W = feats.shape[0]
-        ws = self._workspace(W, 1, 8)
+        ws = self._workspace(W, 1, 8, may_shrink=False)
         out = torch.empty((W, self.geo["enc_positions"], self.geo["d_model"]), dtype=self.torch_dtype, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.wseg_encode(self.handle, feats.data_ptr(), W, ws.data_ptr(), ws.numel(), out.data_ptr(),
@@ -329,18 +348,21 @@ class Engine:
 
     def generate(self, feats, prompt, eos_token_id, pad_token_id, max_length=448, num_beams=4, length_penalty=1.0,
                  suppress_tokens=(), begin_suppress_tokens=(), return_first_logits=False, n_slots=None, refill_min=0,
-                 lookahead=0, window_max_length=None, encoder_output=None, top_k=1, top_p=1.0, seed=0):
+                 lookahead=0, window_max_length=None, encoder_output=None, top_k=1, top_p=1.0, seed=0, kv_positions=0):
         """Greedy / beam-search decode of ALL windows of `feats` [N, 80, 1000] through `n_slots` window slots with
         in-flight refill (a finished window's slot goes to the next queued window; wseg_generate; see pick_slots for the
         default slot count).  `top_k` in 2..16 with
         num_beams == 1 samples (top-k, then nucleus `top_p`) with a counter-based generator keyed by `seed`.
+        `kv_positions`: average self-attention K/V positions per slot to provision in the paged pool (0: min(max_length, 64);
+        >= max_length: every slot can reach max_length at once); when the pool runs short the engine preempts and re-decodes
+        the youngest window (last_stats()["n_preemptions"]).
         Returns (tokens int32 [N, max_length] on device, lengths int32 [N])."""
         feats = feats.to(device=self.device, dtype=torch.float32).contiguous()
         W = feats.shape[0]
         max_length = int(min(max_length, self.geo["dec_positions"]))
         with torch.cuda.device(self.device):
-            slots = self.pick_slots(W, num_beams, max_length, n_slots)
-            ws = self._workspace(slots, num_beams, max_length)
+            slots = self.pick_slots(W, num_beams, max_length, n_slots, kv_positions)
+            ws = self._workspace(slots, num_beams, max_length, kv_positions)
         sup = torch.tensor(list(suppress_tokens) or [0], dtype=torch.int32, device=self.device)
         bsup = torch.tensor(list(begin_suppress_tokens) or [0], dtype=torch.int32, device=self.device)
         gp = _lib.GenerateParams()
@@ -381,7 +403,9 @@ class Engine:
 
     def last_stats(self):
         """Scheduler statistics of the last generate call: dict(n_windows, n_slots, n_steps, n_admissions,
-        slot_steps_active, slot_steps_total, occupancy, steady_occupancy = occupancy while windows were still queued)."""
+        slot_steps_active, slot_steps_total, occupancy, steady_occupancy = occupancy while windows were still queued,
+        kv_units_total / kv_units_peak = pool units of the paged self-attention K/V (one unit = an 8-position page of every beam
+        of a slot), n_preemptions)."""
         st = _lib.GenerateStats()
         _lib.check(self.lib.wseg_last_stats(self.handle, C.byref(st)))
         out = {k: int(getattr(st, k)) for k, _ in st._fields_ if not k.endswith("_")}

@@ -29,7 +29,8 @@ PROMPT_TOKENS = ["<|startoftranscript|>", "<|en|>", "<|notimestamps|>"]   # refe
 # reference computes in fp32 (model.py:655-666), and this is the fastest mode that meets the north-star tolerance (clusters
 # exact, boundaries within +-1 mel frame) on every recording of the 200-recording parity sweep (profiles/README.md): GEMM operands
 # as hi + lo IEEE-half pairs multiplied with three MFMAs per product, fp32 everywhere else; first-step logits within 4e-4 of the
-# exact mode at 32 + 32 layers.  "bf16x3" is the same with bfloat16 halves (no fp16 range limit, 16 instead of 22 operand bits);
+# exact mode at 32 + 32 layers.  "bf16x3" is the same with bfloat16 halves (16 instead of 22 operand bits; no fp16 range limit on the GEMM operands — the
+# encoder attention's Q / K / V^T are IEEE-half pairs in both split modes and saturate at +-65 504);
 # "f16" / "bf16" are the plain 16-bit modes (2.2x faster, 95 % / 86 % of the sweep inside the tolerance); "f32" is the
 # exact-parity mode.
 DEFAULT_DTYPE = "f16x3"
