@@ -48,7 +48,12 @@ typedef enum {
    * are attached pre-split: rows of 2K 16-bit words, every 32 logical columns as [32 hi | 32 lo]
    * (whisperseg_amd/engine.py::split_operand); every other tensor is float32. */
   WSEG_BF16X3 = 3,
-  WSEG_F16X3 = 4
+  WSEG_F16X3 = 4,
+  /* Mixed split-precision mode: WSEG_F16X3 everywhere outside the GEMMs; a GEMM takes hi*hi on the IEEE-half matrix cores and the
+   * two cross terms hi*lo + lo*hi on the block-scaled MX matrix cores (fp6 e2m3 operands with per-32-element e8m0 scales, 4x the
+   * 16-bit rate): 3.25 instead of 6 matrix-core issue units per 64 logical columns at a bf16x3-class operand error.  Weight
+   * matrices are attached as "M6 rows" produced by wseg_convert_operand from the WSEG_F16X3 rows. */
+  WSEG_F16M6 = 5
 } wseg_dtype;
 
 int wseg_abi_version(void);
@@ -213,6 +218,12 @@ typedef struct {
 } wseg_generate_stats;
 int wseg_last_stats(const wseg_model* m, wseg_generate_stats* out);
 
+/* WSEG_F16M6: GEMM operand rows of the mixed split-precision mode from WSEG_F16X3 operand rows (whisperseg_amd/engine.py::
+ * split_operand with IEEE-half pairs).  src: device, rows of 2 K 16-bit words; dst: device, rows of 4 K bytes (must not alias
+ * src); K % 64 == 0.  weight_order != 0 for the W operand of a GEMM (weight matrices: what wseg_model_set_tensor expects in
+ * WSEG_F16M6 mode), 0 for an activation operand (only the library's own GEMM wrappers and wseg_debug_gemm need that). */
+int wseg_convert_operand(const void* src_x3_rows, void* dst_m6_rows, int64_t n_rows, int32_t K, int32_t weight_order, void* stream);
+
 /* Debug/parity taps (used by tests): first-step logits fp32 [n_windows*num_beams][vocab] of the last
  * wseg_generate call are kept in the workspace; this copies them out (device to device). */
 int wseg_debug_first_logits(wseg_model* m, void* workspace, float* out, int32_t n_rows, void* stream);
@@ -228,6 +239,10 @@ int wseg_last_timing(const wseg_model* m, float out[4]);
  * K % 64 == 0.  Used by tests/test_gemm_gpu.py (parity vs torch) and tools/gemm_bench.py. */
 int wseg_debug_gemm(int32_t dtype, int32_t epi, int32_t M, int32_t N, int32_t K, const void* A, const void* W,
                     const void* bias, const void* resid, void* out, void* splitk_ws, size_t splitk_ws_bytes, void* stream);
+
+/* WSEG_F16M6: 1 when wseg_debug_gemm with epi 0 / 1 writes its output as M6 rows (the LDS-staged epilogues of the large-tile
+ * kernels), 0 when it writes hi | lo IEEE-half rows (skinny family); always 0 for the other dtypes. */
+int wseg_debug_gemm_out_is_mx(int32_t dtype, int32_t M, int32_t N, int32_t K);
 
 /* Test / tuning tap of the decoder's fused step x += A W^T + bias; y = LayerNorm(x) * gamma + beta (x: fp32 residual stream [M][N],
  * in place; y: GEMM operand rows of the dtype; bias / gamma / beta: parameter type of the dtype).  Same operand rules as

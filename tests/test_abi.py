@@ -85,7 +85,7 @@ def test_workspace_sizing_is_host_arithmetic_and_fits_the_default_api_call():
     from whisperseg_amd import _lib
     lib = _lib.load()
     out = {}
-    for name, dtype in (("bf16", 1), ("f16x3", 4)):
+    for name, dtype in (("bf16", 1), ("f16x3", 4), ("f16m6", 5)):
         cfg = _lib.ModelConfig(d_model=1280, n_heads=20, enc_layers=32, dec_layers=32, ffn=5120, vocab=51865, n_mels=80,
                                spec_cols=1000, enc_positions=500, dec_positions=448, dtype=dtype)
         h = C.c_void_p()
@@ -101,6 +101,7 @@ def test_workspace_sizing_is_host_arithmetic_and_fits_the_default_api_call():
         finally:
             lib.wseg_model_destroy(h)
     weights_x3 = 6.2e9
-    assert out["f16x3"][0] + weights_x3 <= 0.8 * 288e9, out          # the API default call keeps 1 024 slots in the default mode
+    assert out["f16x3"][0] + weights_x3 <= 0.8 * 288e9, out          # the API default call keeps 1 024 slots in the split modes
+    assert out["f16m6"][0] + weights_x3 + 0.3e9 <= 0.8 * 288e9, out  # ... incl. the default mode (M6 operand scratch, fp32 embedding copy)
     assert out["f16x3"][1] > 288e9                                    # ... which a fully provisioned cache could never do
     assert out["bf16"][0] < 0.5 * 288e9

@@ -91,6 +91,76 @@ def test_split_precision_gemm_matches_fp64(gpu_lib, M, N, K, epi, dtype):
     assert worst <= tol * scale, (worst, scale)
 
 
+M6_SHAPES = [sh for sh in X3_SHAPES if sh[2] % 64 == 0] + [(128000, 1280, 1280), (25000, 2560, 5120), (4096, 1280, 5120), (4096, 5120, 1280)]
+
+
+@pytest.mark.parametrize("M,N,K", M6_SHAPES)
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_mixed_precision_gemm_matches_fp64(gpu_lib, M, N, K, epi):
+    """WSEG_F16M6: hi*hi on the IEEE-half matrix cores + both cross terms on the block-scaled MX matrix cores (fp6 e2m3 codes with a
+    power-of-two scale per 32 columns, v_mfma_scale_f32_16x16x128_f8f6f4), operands converted on the device by
+    wseg_convert_operand (activation order / weight order), against an fp64 product of the same fp32 operands.  Error budget: the
+    cross terms are 2^-11 of a product and carry 3 mantissa bits (2^-4 relative, block-scaled): ~2^-15.5 per product, random in
+    sign — a few 1e-5 of the output scale (bf16x3 class, tools/precision_study.py "gemm=f16m6").  Every kernel family: skinny
+    split-K (whole (hi, MX) tile pairs per split), 128x128 persistent, 256x256 ping-pong and its split-K form; run twice for
+    bit-stability."""
+    from whisperseg_amd import _lib
+    from whisperseg_amd.engine import split_operand, unsplit_m6, unsplit_operand
+    base = torch.float16
+    g = torch.Generator(device="cuda").manual_seed(M * 31 + N * 7 + K + epi)
+    Mp = (M + 255) // 256 * 256
+    A = torch.rand(Mp, K, device="cuda", generator=g) * 2 - 1
+    A[:, : K // 2] *= 0.02                                  # blocks of very different magnitude inside a row: the block scales matter
+    A[::7, 5] = 37.5                                       # an outlier inside a block of small values
+    W = (torch.rand(N, K, device="cuda", generator=g) * 2 - 1) * K ** -0.5
+    bias = torch.rand(N, device="cuda", generator=g) - 0.5
+    res = torch.rand(Mp, N, device="cuda", generator=g) - 0.5
+    As, Ws = split_operand(A, base), split_operand(W, base)
+    Am, Wm = torch.empty_like(As), torch.empty_like(Ws)
+    _lib.check(gpu_lib.wseg_convert_operand(As.data_ptr(), Am.data_ptr(), Mp, K, 0, _lib.stream_ptr()))
+    _lib.check(gpu_lib.wseg_convert_operand(Ws.data_ptr(), Wm.data_ptr(), N, K, 1, _lib.stream_ptr()))
+    # the hi halves travel unchanged: 64 hi words of every 128-word block
+    assert torch.equal(Am.view(Mp, K // 64, 128)[:, :, :64].reshape(Mp, K // 32, 32), As.view(Mp, K // 32, 2, 32)[:, :, 0])
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    outs = []
+    for rep in range(2):
+        if epi == 2:
+            out = torch.full((Mp, N), float("nan"), device="cuda")
+        else:
+            out = torch.full((Mp, 2 * N), -1, device="cuda", dtype=torch.int16)
+        _lib.check(gpu_lib.wseg_debug_gemm(5, epi, M, N, K, Am.data_ptr(), Wm.data_ptr(), bias.data_ptr(), res.data_ptr(),
+                                           out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0][:M].view(torch.int32), outs[1][:M].view(torch.int32))
+    # the conversion itself: hi + fp6(lo) of the M6 rows reproduces the operand to ~2^-15 of each 32-column block's maximum
+    blockmax = A.abs().view(Mp, K // 32, 32).amax(-1, keepdim=True).expand(-1, -1, 32).reshape(Mp, K)
+    assert ((unsplit_m6(Am) - A).abs() <= 2.0 ** -14 * blockmax + 1e-30).all()
+    # EPI_STORE / EPI_GELU outputs are the next GEMM's operand: M6 rows from the LDS-staged epilogues of the large-tile kernels
+    # (N % 64 == 0 there), hi | lo IEEE-half rows from the skinny family
+    if epi == 2:
+        got_all = outs[0]
+    elif gpu_lib.wseg_debug_gemm_out_is_mx(5, M, N, K):
+        got_all = torch.full((Mp, N), float("nan"), device="cuda")
+        got_all[:M] = unsplit_m6(outs[0][:M])
+    else:
+        got_all = unsplit_operand(outs[0], base)
+    assert torch.isnan(got_all[M:]).all() or M == Mp
+    worst, scale = 0.0, 1.0
+    for lo in range(0, M, 8192):
+        hi = min(M, lo + 8192)
+        ref = A[lo:hi].double() @ W.double().T + bias.double()
+        if epi == 1:
+            ref = torch.nn.functional.gelu(ref)
+        if epi == 2:
+            ref = ref + res[lo:hi].double()
+        got = got_all[lo:hi].double()
+        assert torch.isfinite(got).all()
+        worst = max(worst, (got - ref).abs().max().item())
+        scale = max(scale, ref.abs().max().item())
+    assert worst <= 1e-4 * scale, (worst, scale)
+
+
 # Shapes that reach the 256x256 ping-pong kernel (N % 256 == 0, >= 192 tiles): fewer tiles than workgroups x 2,
 # several tiles per workgroup (the K-tile stream crosses output tiles and holds the prefetch back over the epilogue),
 # the minimum K (2 K tiles), an odd number of K tiles, M not a tile multiple, and the bench's own row count.

@@ -38,7 +38,7 @@ def two_layer():
     cfg = large_cfg(2)
     rc = R.RefConfig.from_hf_dict(cfg)
     sd = {k: v.to(torch.bfloat16).float() for k, v in R.random_state_dict(rc, seed=31, fast=True).items()}
-    engines = {dt: Engine.from_state_dict(sd, cfg, "cuda:0", dt) for dt in ("f32", "bf16", "f16", "f16x3", "bf16x3")}
+    engines = {dt: Engine.from_state_dict(sd, cfg, "cuda:0", dt) for dt in ("f32", "bf16", "f16", "f16x3", "bf16x3", "f16m6")}
     return cfg, rc, sd, engines
 
 
@@ -94,7 +94,7 @@ def test_two_layer_8_windows_vs_oracle(gpu_lib, two_layer):
             if nb == 4:
                 assert torch.equal(got16[0::4], got16[1::4]) and torch.equal(got16[0::4], got16[3::4])
         # split-precision modes (8 slots x 20 heads: the few-slot cross-attention, 4 workgroups per (slot, head) over 24-bit K / V)
-        for dt, rel in (("f16x3", 1e-4), ("bf16x3", 1e-3)):
+        for dt, rel in (("f16x3", 1e-4), ("bf16x3", 1e-3), ("f16m6", 1e-3)):
             t3, l3, got3 = gen(engines[dt], x, nb, 10, return_first_logits=True)
             assert (got3.cpu() - want_logits).abs().max().item() <= rel * max(1.0, want_logits.abs().max().item()), dt
             assert all(int(t3[i, 3]) == int(want_tok[i][3]) for i in range(8)), (dt, nb)
@@ -141,7 +141,7 @@ def test_two_layer_256_windows_1024_rows_vs_oracle(gpu_lib, two_layer):
     # split-precision modes (the product default and the bench headline) at the same row counts: logits of ALL 1024 rows within
     # 1e-3 of the logit scale of the f32 mode (measured ~1e-5 / ~1e-4) and of the oracle on its subset, every first token equal
     scale = max(1.0, want_logits.abs().max().item())
-    for dt, rel in (("f16x3", 1e-4), ("bf16x3", 1e-3)):
+    for dt, rel in (("f16x3", 1e-4), ("bf16x3", 1e-3), ("f16m6", 1e-3)):
         t3, l3, g3 = gen(engines[dt], x, 4, 8, return_first_logits=True)
         g3, t3 = g3.cpu(), t3.cpu()
         assert (g3 - g32).abs().max().item() <= rel * scale, dt
@@ -184,7 +184,7 @@ def test_two_layer_1024_windows_4096_rows(gpu_lib, two_layer):
     # cross-K/V kernel at 1024 slots — logits of all 4096 rows within 1e-3 of the scale of the f32 mode, first tokens equal,
     # and identical to the same engine at 256 slots wherever the GEMM plan family is row-count independent (reported otherwise)
     scale = max(1.0, g32.abs().max().item())
-    for dt, rel in (("f16x3", 1e-4), ("bf16x3", 1e-3)):
+    for dt, rel in (("f16x3", 1e-4), ("bf16x3", 1e-3), ("f16m6", 1e-3)):
         t, l, g = gen(engines[dt], x, 4, 8, return_first_logits=True, n_slots=1024)
         assert engines[dt].last_stats()["n_slots"] == 1024
         g, t = g.cpu(), t.cpu()
@@ -224,7 +224,7 @@ def test_full_large_properties(gpu_lib, full_large, n):
     assert torch.equal(tp, toks[perm]) and torch.equal(lp, lens[perm])
 
 
-@pytest.mark.parametrize("dt,rel", [("f16x3", 1e-4), ("bf16x3", 5e-4)])
+@pytest.mark.parametrize("dt,rel", [("f16x3", 1e-4), ("bf16x3", 5e-4), ("f16m6", 5e-4)])
 def test_full_large_split_precision_vs_f32_mode(gpu_lib, full_large, dt, rel):
     """32 + 32 layers: the split-precision modes (product default f16x3, bench headline bf16x3) against the exact-parity f32
     mode on the same fp32 weights: encoder output and first-step logits within rel x scale (measured 2.8e-5 / 1.1e-4 of the

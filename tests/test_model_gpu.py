@@ -38,7 +38,7 @@ def feats(n, seed=0):
     return torch.randn(n, 80, 1000, generator=g) * 0.5
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 5e-4), ("bf16", 6e-2), ("f16", 1e-2), ("bf16x3", 5e-4), ("f16x3", 5e-4)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 5e-4), ("bf16", 6e-2), ("f16", 1e-2), ("bf16x3", 5e-4), ("f16x3", 5e-4), ("f16m6", 5e-4)])
 @pytest.mark.parametrize("n", [1, 3])
 def test_encoder_matches_oracle(gpu_lib, dtype, tol, n):
     cfg = hf_cfg()
@@ -51,7 +51,7 @@ def test_encoder_matches_oracle(gpu_lib, dtype, tol, n):
     assert err <= tol * max(1.0, want.abs().max().item()), err
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 5e-4), ("bf16", 8e-2), ("f16", 1.5e-2), ("bf16x3", 5e-4), ("f16x3", 5e-4)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 5e-4), ("bf16", 8e-2), ("f16", 1.5e-2), ("bf16x3", 5e-4), ("f16x3", 5e-4), ("f16m6", 5e-4)])
 def test_encoder_wider_geometry(gpu_lib, dtype, tol):
     """d=256 / 4 heads / ffn 1024: exercises multi-tile N and more than two heads."""
     cfg = hf_cfg(d=256, heads=4, layers=2, ffn=1024)
@@ -68,7 +68,7 @@ def gen_params(nb, ml):
                        suppress_tokens=[5, 6, 7, 200], begin_suppress_tokens=[220, EOS])
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16x3", "f16x3"])      # the split-precision modes meet the exact mode's bound
+@pytest.mark.parametrize("dtype", ["f32", "bf16x3", "f16x3", "f16m6"])      # the split-precision modes meet the exact mode's bound
 @pytest.mark.parametrize("nb", [1, 4])
 def test_first_logits_f32(gpu_lib, nb, dtype):
     cfg = hf_cfg()
@@ -82,7 +82,7 @@ def test_first_logits_f32(gpu_lib, nb, dtype):
     assert err <= 1e-3, err
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16x3", "f16x3"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16x3", "f16x3", "f16m6"])
 @pytest.mark.parametrize("nb,ml", [(1, 12), (1, 40), (4, 12), (4, 40), (2, 20)])
 def test_generate_tokens_f32_random_weights(gpu_lib, nb, ml, dtype):
     cfg = hf_cfg()

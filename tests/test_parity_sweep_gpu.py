@@ -32,10 +32,10 @@ def test_f32_mode_reproduces_every_row(gpu_lib, sweep):
     assert res["exact_runs"] == len(sweep), (res["structure_mismatch_runs"][:3], res["beyond_one_frame_runs"][:3])
 
 
-@pytest.mark.parametrize("dtype", ["bf16x3", "f16x3"])
+@pytest.mark.parametrize("dtype", ["bf16x3", "f16x3", "f16m6"])
 def test_split_precision_modes_meet_the_north_star_tolerance(gpu_lib, sweep, dtype):
-    """The fast parity mode (and the segmenter's default): GEMM operands as hi + lo 16-bit pairs, three MFMAs per product,
-    fp32 everywhere else.  North star: clusters exact, boundaries within +-1 mel frame — on EVERY recording of the sweep."""
+    """The fast parity modes: GEMM operands as hi + lo 16-bit pairs, three MFMAs per product (f16x3 / bf16x3) or hi*hi on the
+    half matrix cores + both cross terms on the fp6 MX matrix cores (f16m6), fp32 everywhere else.  North star: clusters exact, boundaries within +-1 mel frame — on EVERY recording of the sweep."""
     from tools.parity_sweep import score
     from whisperseg_amd.model import WhisperSegmenter
     res = score(WhisperSegmenter(MODEL_DIR, device="cuda", device_ids=[0], dtype=dtype), sweep)

@@ -50,7 +50,7 @@ def gen(eng, x, nb=4, ml=448, **kw):
     return t.cpu(), l.cpu()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f16x3", "bf16x3", "bf16", "f16"])
+@pytest.mark.parametrize("dtype", ["f32", "f16x3", "bf16x3", "f16m6", "bf16", "f16"])
 @pytest.mark.parametrize("nb", [1, 4])
 def test_slot_refill_gives_the_same_tokens(gpu_lib, dtype, nb):
     eng = tiny_engine(dtype)
@@ -62,7 +62,7 @@ def test_slot_refill_gives_the_same_tokens(gpu_lib, dtype, nb):
         st = eng.last_stats()
         assert st["n_windows"] == 23 and st["n_slots"] == slots and st["n_admissions"] >= -(-23 // slots)
         assert 0 < st["occupancy"] <= 1.0
-        if dtype in ("f32", "f16x3", "bf16x3"):
+        if dtype in ("f32", "f16x3", "bf16x3", "f16m6"):
             # f32: every dot product is one k-ordered chain whatever the plan -> bit-identical.  Split-precision modes (the
             # product default): split-K plans follow the row count, which moves logits by fp32 summation-order noise (~1e-7 of
             # their scale) — four orders of magnitude below the smallest top-1 / top-2 margin of the parity sweep (1e-5,

@@ -53,6 +53,7 @@ SYMBOLS = {
     "wseg_model_ready": (C.c_int, [C.c_void_p]),
     "wseg_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "wseg_workspace_bytes_kv": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "wseg_convert_operand": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "wseg_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "wseg_generate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(GenerateParams), C.c_void_p, C.c_size_t,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -61,6 +62,7 @@ SYMBOLS = {
     "wseg_last_stats": (C.c_int, [C.c_void_p, C.POINTER(GenerateStats)]),
     "wseg_debug_gemm": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "wseg_debug_gemm_out_is_mx": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "wseg_debug_gemm_resid_ln": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "wseg_debug_lane_xor": (C.c_int, [C.c_void_p, C.c_void_p]),

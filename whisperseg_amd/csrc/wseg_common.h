@@ -129,6 +129,32 @@ struct f16_t;
 template <typename T> struct IO { typedef T P; typedef T H; typedef T A; static constexpr bool split = false; };
 template <typename HT> struct IO<X3<HT>> { typedef float P; typedef HT H; typedef f16_t A; static constexpr bool split = true; };
 
+// ------------------------------------------------------------------------------------------------------------------
+// Mixed split-precision mode WSEG_F16M6 (tag M6): everything OUTSIDE the GEMMs is the f16x3 code (fp32 arithmetic, producers write
+// hi | lo IEEE-half operand rows); a GEMM multiplies  hi*hi  on the IEEE-half matrix cores and the two cross terms
+// hi*lo + lo*hi  on the block-scaled MX matrix cores (v_mfma_scale_f32_16x16x128_f8f6f4, fp6 e2m3 operands: ~10 PFLOP/s dense, 4x
+// the 16-bit rate) — the cross terms are 2^-11 of the product, so 3 mantissa bits + a per-32-element power-of-two scale keep the
+// total operand error at ~2^-15.5 (bf16x3 class; tools/precision_study.py "gemm=f16m6": 200 / 200 sweep recordings identical).
+// Per 64 logical columns: 2 half MFMAs (16 cycles each) + 1 MX MFMA (~20 cycles) instead of the six half MFMAs of f16x3.
+// GEMM operands are "M6 rows" built from the hi | lo rows by x3_to_m6 (wseg_enc.hip): per 64 logical columns 256 bytes =
+//   [64 hi halves (128 B)] [MX block (128 B)]      MX block = four 32-byte chunks, one per lane group g of the MX MFMA:
+//   [24 bytes = 32 e2m3 codes][e8m0 scale byte][7 bytes padding].  ACTIVATION order: g = 0, 1 hold lo6 of logical columns 0..31 /
+//   32..63 of the group, g = 2, 3 hold hi6 of the same columns; WEIGHT order: hi6 chunks first, then lo6 chunks.  Lane (row, g)
+//   of the MX MFMA reads its chunk with two 16-byte LDS reads — the codes land in registers 0..5 of the operand, the scale byte
+//   in register 6, which is passed as the instruction's scale operand — from BOTH operands: that pairs activation lo with weight
+//   hi (g = 0, 1) and activation hi with weight lo (g = 2, 3): one instruction = both cross terms of 64 logical columns.
+// A 64-word K tile of the GEMM kernels is alternately a hi tile (plain half MFMAs) and an MX tile.
+// ------------------------------------------------------------------------------------------------------------------
+struct M6 {};
+template <> struct IO<M6> { typedef float P; typedef f16_t H; typedef f16_t A; static constexpr bool split = true; };
+template <typename T> struct IsMx { static constexpr bool v = false; };
+template <> struct IsMx<M6> { static constexpr bool v = true; };
+typedef int mx_i32x8 __attribute__((ext_vector_type(8)));
+struct MxFrag { mx_i32x8 v; };      // a 32-byte chunk: v[0..5] = 32 e2m3 codes, low byte of v[6] = e8m0 scale (the MFMA reads 6 registers)
+__device__ __forceinline__ f32x4 mfma_mx6(const MxFrag& a, const MxFrag& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a.v, b.v, c, 2, 2, 0, a.v[6], 0, b.v[6]);
+}
+
 __host__ __device__ __forceinline__ int x3_col(int c) { return ((c >> 5) << 6) | (c & 31); }
 
 // 8 consecutive logical columns (c % 8 == 0) <-> the two 16-byte pieces of a split row
@@ -161,8 +187,71 @@ template <typename HT> struct Op<X3<HT>> {
     return H16<HT>::one(__builtin_bit_cast(HT, p[0])) + H16<HT>::one(__builtin_bit_cast(HT, p[32]));
   }
 };
+// ---- M6 rows written directly by a producer (activation order; layout above) ------------------------------------------------
+// 32 IEEE halves held by ONE lane (16 registers of packed pairs) -> 24 bytes of e2m3 codes + the e8m0 scale byte of the block:
+// the smallest power of two that brings the block's maximum inside e2m3's +-7.5 (nothing saturates), codes rounded to nearest even
+// by v_cvt_scalef32_pk32_fp6_f16 (tools/probes/fp6_cvt_probe.hip pins its semantics and its agreement with the MX MFMA).
+typedef _Float16 mx_h32 __attribute__((ext_vector_type(32)));
+typedef unsigned mx_u6 __attribute__((ext_vector_type(6)));
+__device__ __forceinline__ int mx_scale_byte(float amax) {      // smallest E with amax <= 7.5 * 2^E, as the e8m0 byte E + 127
+  const float t = amax * (1.0f / 7.5f);
+  int e = (int)((__float_as_uint(t) + 0x7fffffu) >> 23) - 127;      // ceil(log2 t) for normal t
+  e = max(-120, min(e, 120));
+  return e + 127;
+}
+// one 32-byte chunk of an MX block: [24 bytes codes][scale byte][7 bytes 0], as two 16-byte values
+__device__ __forceinline__ void mx_chunk(const uint32_t (&w)[16], float amax, uint4& c0, uint4& c1) {
+  union { uint32_t u[16]; mx_h32 h; } x;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x.u[i] = w[i];
+  const int sb = mx_scale_byte(amax);
+  const mx_u6 c = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(x.h, __uint_as_float((unsigned)sb << 23));
+  c0 = make_uint4(c[0], c[1], c[2], c[3]);
+  c1 = make_uint4(c[4], c[5], (unsigned)sb, 0u);
+}
+// Cooperative store of 8 consecutive logical columns per lane: the FOUR lanes of an aligned quad (lane & 3 = 0..3) must call this
+// together with c = c0, c0 + 8, c0 + 16, c0 + 24 (c0 % 32 == 0) of the SAME row — which is how every 8-column producer of the
+// library is laid out (LayerNorm, the LDS-staged GEMM epilogues, the fused split-K reduction, the decoder attention outputs).
+// Each lane writes its 8 hi halves; the quad shares its 16 + 16 packed words by DPP quad broadcasts, every lane converts the
+// block (identical results), and lane k of the quad writes piece k of {lo chunk first / second half, hi chunk first / second half}.
+__device__ __forceinline__ void op_st8_m6(void* base, size_t row, int ld, int c, const float v[8]) {
+  uint4 hi, lo;
+  split8<f16_t>(v, hi, lo);
+  unsigned char* blk = (unsigned char*)base + row * (size_t)(4 * ld) + (size_t)(c >> 6) * 256;      // the 256-byte block of 64 logical columns
+  *(uint4*)(blk + (c & 63) * 2) = hi;
+  float h8[8], l8[8];
+  unpack8<f16_t>(hi, h8);
+  unpack8<f16_t>(lo, l8);
+  float ah = 0.f, al = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { ah = fmaxf(ah, fabsf(h8[e])); al = fmaxf(al, fabsf(l8[e])); }
+  auto quad_max = [](float a) {      // maximum over the quad: quad_perm [1,0,3,2], then [2,3,0,1]
+    a = fmaxf(a, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true)));
+    return fmaxf(a, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x4E, 0xF, 0xF, true)));
+  };
+  ah = quad_max(ah);
+  al = quad_max(al);
+  const uint32_t hw[4] = {hi.x, hi.y, hi.z, hi.w}, lw[4] = {lo.x, lo.y, lo.z, lo.w};
+  uint32_t gh[16], gl[16];
+#define WSEG_QUAD_BCAST(K)                                                                                               \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                        \
+    gh[4 * (K) + i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hw[i], (K) * 0x55, 0xF, 0xF, true); /* quad_perm [K,K,K,K] */ \
+    gl[4 * (K) + i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lw[i], (K) * 0x55, 0xF, 0xF, true);                  \
+  }
+  WSEG_QUAD_BCAST(0) WSEG_QUAD_BCAST(1) WSEG_QUAD_BCAST(2) WSEG_QUAD_BCAST(3)
+#undef WSEG_QUAD_BCAST
+  uint4 l0, l1, h0, h1;
+  mx_chunk(gl, al, l0, l1);
+  mx_chunk(gh, ah, h0, h1);
+  const int chunk = (c >> 5) & 1, piece = (c >> 3) & 3;      // piece == lane & 3
+  const uint4 mine = piece == 0 ? l0 : (piece == 1 ? l1 : (piece == 2 ? h0 : h1));
+  *(uint4*)(blk + 128 + 32 * ((piece >> 1) * 2 + chunk) + 16 * (piece & 1)) = mine;
+}
+
 template <typename T> __device__ __forceinline__ void op_st8(void* base, size_t row, int ld, int c, const float v[8]) {
-  if constexpr (IO<T>::split) {
+  if constexpr (IsMx<T>::v) {
+    op_st8_m6(base, row, ld, c, v);
+  } else if constexpr (IO<T>::split) {
     typedef typename IO<T>::H HT;
     uint16_t* p = (uint16_t*)base + row * (size_t)(2 * ld) + x3_col(c);
     uint4 hi, lo;

@@ -779,10 +779,12 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_k24_kernel(DecodeState 
       if (rowl == 0) red[wave][j][sub * 8 + e] = a;
     }
   __syncthreads();
-  for (int i = tid; i < nb * 64; i += 256) {
-    const int j = i >> 6, e = i & 63;
-    const float o = ((red[0][j][e] + red[1][j][e]) + red[2][j][e]) + red[3][j][e];
-    Op<TO>::st1(out, (size_t)(w * nb + j), d, h * 64 + e, o * sinv[j]);
+  if (tid < NB * 8) {      // thread (j, e8): 8 consecutive columns of beam j — whole quads of threads share a 32-column block (M6 rows)
+    const int j = tid >> 3, e0 = (tid & 7) * 8;
+    float o8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] = (((red[0][j][e0 + e] + red[1][j][e0 + e]) + red[2][j][e0 + e]) + red[3][j][e0 + e]) * sinv[min(j, nb - 1)];
+    if (j < nb) op_st8<TO>(out, (size_t)(w * nb + j), d, h * 64 + e0, o8);
   }
   WSEG_STAMP(3, 7);
 }
@@ -1186,6 +1188,7 @@ int launch_dec_self_attn(int dtype, const DecodeState& st, const void* q, void* 
   else if (dtype == WSEG_F16) WSEG_SA(f16_t, f16_t);
   else if (dtype == WSEG_BF16X3) WSEG_SA(float, X3<bf16_t>);
   else if (dtype == WSEG_F16X3) WSEG_SA(float, X3<f16_t>);
+  else if (dtype == WSEG_F16M6) WSEG_SA(float, M6);      // the o-proj GEMM's operand as M6 rows
   else WSEG_SA(float, float);
 #undef WSEG_SA
   WSEG_LAUNCH_CHECK();
@@ -1212,10 +1215,13 @@ int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const
   if (Tk > 512) { set_error("cross-attention: %d encoder positions > 512", Tk); return WSEG_ERR_INVALID; }
   PartialInfo pi;
   if (q_part) pi = *q_part;
-  if ((dtype == WSEG_BF16X3 || dtype == WSEG_F16X3) && x3_cross_kv24() && st.nb <= 4) {
+  const bool m6 = dtype == WSEG_F16M6;      // cross-attention output (the co-proj GEMM's operand) as M6 rows: 24-bit K / V kernel only
+  if (m6 && !(x3_cross_kv24() && st.nb <= 4)) { set_error("f16m6: cross-attention needs the 24-bit K/V kernel (beams <= 4)"); return WSEG_ERR_INVALID; }
+  if ((dtype == WSEG_BF16X3 || dtype == WSEG_F16X3 || m6) && x3_cross_kv24() && st.nb <= 4) {
     dim3 grid(st.W * H), block(256);
 #define WSEG_K24(TO_, NB_) hipLaunchKernelGGL((dec_cross_attn_k24_kernel<TO_, NB_>), grid, block, 0, s, st, (const float*)q, (const unsigned char*)ck, (const unsigned char*)cv, out, H, Tk, d, pi, (const float*)q_bias, scale)
     if (dtype == WSEG_BF16X3) { if (st.nb <= 1) WSEG_K24(X3<bf16_t>, 1); else if (st.nb <= 2) WSEG_K24(X3<bf16_t>, 2); else WSEG_K24(X3<bf16_t>, 4); }
+    else if (m6) { if (st.nb <= 1) WSEG_K24(M6, 1); else if (st.nb <= 2) WSEG_K24(M6, 2); else WSEG_K24(M6, 4); }
     else { if (st.nb <= 1) WSEG_K24(X3<f16_t>, 1); else if (st.nb <= 2) WSEG_K24(X3<f16_t>, 2); else WSEG_K24(X3<f16_t>, 4); }
 #undef WSEG_K24
     WSEG_LAUNCH_CHECK();

@@ -299,7 +299,59 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
     }
   }
   const int q = q0 + qi;
-  if (q < T) {
+  if constexpr (IsMx<TO>::v) {
+    // M6 rows (wseg_common.h): lane (qi, g2) holds, of query q and column half ht, the 16 columns 8 rg + 4 g2 + {0..3}; its partner
+    // lane ^ 32 holds the other 16.  Lane g2 = 0 builds the 32-column block ht = 0 and lane g2 = 1 the block ht = 1: each splits
+    // its 32 values into halves, hands the partner the 16 packed words (hi and lo) of the block the PARTNER builds
+    // (v_permlane32_swap), and writes 64 bytes of hi halves + the lo6 and hi6 chunks of its block.
+    const float inv = 1.0f / l_run;
+    uint32_t hw[2][8], lw[2][8];                       // [ht][rg * 2 + pair]: packed halves of this lane's 16 columns of half ht
+    float amax_h[2] = {0.f, 0.f}, amax_l[2] = {0.f, 0.f};
+#pragma unroll
+    for (int ht = 0; ht < 2; ++ht) {
+      const f32x16& o = ht == 0 ? o0 : o1;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const float a0 = H16<f16_t>::sat(o[2 * p] * inv), a1 = H16<f16_t>::sat(o[2 * p + 1] * inv);
+        const uint32_t hh = H16<f16_t>::pack(a0, a1);
+        const float r0 = a0 - H16<f16_t>::lo(hh), r1 = a1 - H16<f16_t>::hi(hh);
+        const uint32_t ll = H16<f16_t>::pack(r0, r1);
+        hw[ht][p] = hh; lw[ht][p] = ll;
+        amax_h[ht] = fmaxf(amax_h[ht], fmaxf(fabsf(H16<f16_t>::lo(hh)), fabsf(H16<f16_t>::hi(hh))));
+        amax_l[ht] = fmaxf(amax_l[ht], fmaxf(fabsf(H16<f16_t>::lo(ll)), fabsf(H16<f16_t>::hi(ll))));
+      }
+    }
+    // my block = ht == g2; the partner needs my words of block 1 - g2
+    uint32_t gh[16], gl[16];
+    float ah = g2 ? amax_h[1] : amax_h[0], al = g2 ? amax_l[1] : amax_l[0];
+    ah = fmaxf(ah, lane_xor<32>(g2 ? amax_h[0] : amax_h[1]));
+    al = fmaxf(al, lane_xor<32>(g2 ? amax_l[0] : amax_l[1]));
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const uint32_t mine_h = g2 ? hw[1][p] : hw[0][p], give_h = g2 ? hw[0][p] : hw[1][p];
+      const uint32_t mine_l = g2 ? lw[1][p] : lw[0][p], give_l = g2 ? lw[0][p] : lw[1][p];
+      const uint32_t got_h = lane_xor_u<32>(give_h), got_l = lane_xor_u<32>(give_l);
+      // columns of the block: 8 rg + 4 g2' + e; p = 2 rg + pair: the g2' = 0 lane's pair lands at word 4 rg + pair, the g2' = 1 lane's at 4 rg + 2 + pair
+      const int rg = p >> 1, pr = p & 1;
+      gh[4 * rg + pr] = g2 ? got_h : mine_h;
+      gh[4 * rg + 2 + pr] = g2 ? mine_h : got_h;
+      gl[4 * rg + pr] = g2 ? got_l : mine_l;
+      gl[4 * rg + 2 + pr] = g2 ? mine_l : got_l;
+    }
+    if (q < T) {
+      const size_t row = (size_t)b * T + q;
+      const int c = h * 64 + g2 * 32;                  // first logical column of my block
+      unsigned char* blk = (unsigned char*)out + row * (size_t)(4 * d) + (size_t)(c >> 6) * 256;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *(uint4*)(blk + (c & 63) * 2 + 16 * i) = make_uint4(gh[4 * i], gh[4 * i + 1], gh[4 * i + 2], gh[4 * i + 3]);
+      uint4 c0, c1;
+      const int chunk = (c >> 5) & 1;
+      mx_chunk(gl, al, c0, c1);
+      *(uint4*)(blk + 128 + 32 * chunk) = c0; *(uint4*)(blk + 128 + 32 * chunk + 16) = c1;
+      mx_chunk(gh, ah, c0, c1);
+      *(uint4*)(blk + 128 + 32 * (2 + chunk)) = c0; *(uint4*)(blk + 128 + 32 * (2 + chunk) + 16) = c1;
+    }
+  } else if (q < T) {
     const float inv = 1.0f / l_run;
 #pragma unroll
     for (int ht = 0; ht < 2; ++ht) {
@@ -496,6 +548,74 @@ __global__ __launch_bounds__(256) void f32_to_operand_kernel(const float* __rest
     op_st8<X3<HT>>(op, row, d, c, v);
   }
 }
+// ------------------------------------------------------------------------------------------------
+// WSEG_F16M6: hi | lo IEEE-half operand rows -> M6 rows (layout: wseg_common.h).  One lane per 32 logical columns (one 128-byte
+// [32 hi | 32 lo] group of the source row): the block maxima of |hi| and |lo| give the two e8m0 scales (the smallest power of two
+// that brings the block inside e2m3's +-7.5: nothing saturates), v_cvt_scalef32_pk32_fp6_f16 quantises the 32 halves of a lane to
+// 24 bytes of e2m3 codes (round to nearest even; tools/probes/fp6_cvt_probe.hip pins its semantics and its agreement with the MX
+// MFMA), the hi halves are copied.  The wave's 8 KB of source rows arrive by fully coalesced 16-byte loads through a padded LDS
+// image (144-byte pitch: conflict-free 16-byte reads at a 128-byte lane stride).
+// ------------------------------------------------------------------------------------------------
+template <bool WORDER>
+__global__ __launch_bounds__(256) void x3_to_m6_kernel(const uint16_t* __restrict__ src, unsigned char* __restrict__ dst, size_t n_groups, int K) {
+  __shared__ __attribute__((aligned(16))) unsigned char stage[4][64 * 144];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gpr = K >> 5;                                   // 32-column groups per row
+  for (size_t g0 = ((size_t)blockIdx.x * 4 + wave) * 64; g0 < n_groups; g0 += (size_t)gridDim.x * 256) {
+    // groups g0 .. g0 + 63 are 8 KB of contiguous source bytes (a row is gpr groups of 128 bytes, rows are contiguous)
+    const unsigned char* sp = (const unsigned char*)src + g0 * 128;
+    const size_t n_here = n_groups - g0 < 64 ? n_groups - g0 : 64;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int piece = q * 64 + lane;                        // 16-byte piece of the 8 KB
+      const int grp = piece >> 3;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if ((size_t)grp < n_here) v = *(const uint4*)(sp + (size_t)piece * 16);
+      *(uint4*)(stage[wave] + grp * 144 + (piece & 7) * 16) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    union { uint4 q[4]; mx_h32 h; } hi, lo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { hi.q[q] = *(const uint4*)(stage[wave] + lane * 144 + q * 16); lo.q[q] = *(const uint4*)(stage[wave] + lane * 144 + 64 + q * 16); }
+    __builtin_amdgcn_wave_barrier();                          // every lane has read its group before the image is overwritten
+    if ((size_t)lane < n_here) {
+      float ah = 0.f, al = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) { ah = fmaxf(ah, fabsf((float)hi.h[i])); al = fmaxf(al, fabsf((float)lo.h[i])); }
+      const int sbh = mx_scale_byte(ah), sbl = mx_scale_byte(al);
+      const mx_u6 ch = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(hi.h, __uint_as_float((unsigned)sbh << 23));
+      const mx_u6 cl = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(lo.h, __uint_as_float((unsigned)sbl << 23));
+      const size_t g = g0 + lane, row = g / gpr;
+      const int gi = (int)(g - row * gpr), chunk = gi & 1;
+      unsigned char* d64 = dst + row * (size_t)(4 * K) + (size_t)(gi >> 1) * 256;      // the 256-byte block of 64 logical columns
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *(uint4*)(d64 + chunk * 64 + q * 16) = hi.q[q];
+      // chunk g of the MX block: activation order lo chunks 0, 1 then hi chunks 0, 1; weight order hi first
+      unsigned char* mx = d64 + 128;
+      unsigned char* plo = mx + 32 * ((WORDER ? 2 : 0) + chunk);
+      unsigned char* phi = mx + 32 * ((WORDER ? 0 : 2) + chunk);
+      *(uint4*)plo = make_uint4(cl[0], cl[1], cl[2], cl[3]);
+      *(uint4*)(plo + 16) = make_uint4(cl[4], cl[5], (unsigned)sbl, 0u);
+      *(uint4*)phi = make_uint4(ch[0], ch[1], ch[2], ch[3]);
+      *(uint4*)(phi + 16) = make_uint4(ch[4], ch[5], (unsigned)sbh, 0u);
+    }
+  }
+}
+
+int launch_x3_to_m6(const void* x3_rows, void* m6_rows, size_t M, int K, bool weight_order, hipStream_t s) {
+  if (K <= 0 || K % 64) { set_error("x3_to_m6: K %d must be a multiple of 64", K); return WSEG_ERR_INVALID; }
+  const size_t n_groups = M * (size_t)(K >> 5);
+  if (n_groups == 0) return WSEG_OK;
+  const size_t want = (n_groups + 255) / 256;
+  const int blocks = (int)(want < 16384 ? want : 16384);
+  if (weight_order) hipLaunchKernelGGL(x3_to_m6_kernel<true>, dim3(blocks), dim3(256), 0, s, (const uint16_t*)x3_rows, (unsigned char*)m6_rows, n_groups, K);
+  else hipLaunchKernelGGL(x3_to_m6_kernel<false>, dim3(blocks), dim3(256), 0, s, (const uint16_t*)x3_rows, (unsigned char*)m6_rows, n_groups, K);
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+
 int launch_operand_to_f32(int dtype, const void* op, float* out, size_t M, int d, hipStream_t s) {
   if (!is_x3(dtype) || d % 32) { set_error("operand_to_f32: dtype %d / d %d unsupported", dtype, d); return WSEG_ERR_INVALID; }
   const size_t n8 = M * (size_t)(d >> 3);
@@ -554,6 +674,7 @@ int launch_layernorm(int dtype, const float* x, const void* g, const void* b, vo
   else if (dtype == WSEG_F16) WSEG_LN3(f16_t);
   else if (dtype == WSEG_BF16X3) WSEG_LN3(X3<bf16_t>);
   else if (dtype == WSEG_F16X3) WSEG_LN3(X3<f16_t>);
+  else if (dtype == WSEG_F16M6) WSEG_LN3(M6);      // M6 rows written directly (the four lanes of a quad share a 32-column block)
   else WSEG_LN3(float);
 #undef WSEG_LN3
 #undef WSEG_LN
@@ -573,8 +694,19 @@ static void launch_enc_attention_f32(const void* q, const void* k, const void* v
   }
 }
 
+bool enc_attention_writes_mx(int dtype) { return dtype == WSEG_F16M6 && x3_enc_attention_mode() == 2; }
+
 int launch_enc_attention(int dtype, const void* q, const void* k, const void* vt, void* out,
                          int B, int H, int T, int Tp, int d, hipStream_t s) {
+  if (dtype == WSEG_F16M6 && x3_enc_attention_mode() == 2) {      // split-precision attention writing M6 rows directly
+    if (Tp % 128) { set_error("enc_attention: Tp %d %% 128", Tp); return WSEG_ERR_INVALID; }
+    dim3 grid(cdiv(T, 128), B * H);
+    hipLaunchKernelGGL((enc_attention_h16_kernel<f16_t, M6, true>), grid, dim3(256), 0, s, (const f16_t*)q, (const f16_t*)k, (const f16_t*)vt, out, H, T, Tp, d,
+                       (size_t)B * H * Tp * 64);
+    WSEG_LAUNCH_CHECK();
+    return WSEG_OK;
+  }
+  dtype = storage_dtype(dtype);
   const bool x3 = is_x3(dtype);
   const int mode = x3 ? x3_enc_attention_mode() : 0;
   if (dtype == WSEG_BF16 || dtype == WSEG_F16 || (x3 && mode != 1)) {
@@ -595,3 +727,9 @@ int launch_enc_attention(int dtype, const void* q, const void* k, const void* vt
 }
 
 }  // namespace wseg
+
+extern "C" int wseg_convert_operand(const void* src_x3_rows, void* dst_m6_rows, int64_t n_rows, int32_t K, int32_t weight_order, void* stream) {
+  using namespace wseg;
+  if (!src_x3_rows || !dst_m6_rows || n_rows < 0 || src_x3_rows == dst_m6_rows) { set_error("wseg_convert_operand: bad argument"); return WSEG_ERR_INVALID; }
+  return launch_x3_to_m6(src_x3_rows, dst_m6_rows, (size_t)n_rows, K, weight_order != 0, (hipStream_t)stream);
+}

@@ -281,6 +281,51 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // epilogue in a co-resident workgroup) they lost about once per 10^4 K tiles (tools/concurrency_stress.py).
 __device__ __forceinline__ void lds_reads_done_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// MX fragment reads (M6 rows, wseg_common.h).  A lane (fr = lane & 15, fg = lane >> 4) reads, from row fr of a 16-row block of a
+// [rows][64 words] operand tile (128-byte rows, 16-byte slots XOR-swizzled with row & 7 like every operand tile), its 32-byte
+// chunk fg = logical slots 2 fg and 2 fg + 1: two ds_read_b128.  The two byte offsets depend on the lane only (MxOff, computed
+// once per kernel); a 16-row block is 2048 bytes further on.
+struct MxOff { int p0, p1; };
+__device__ __forceinline__ MxOff mx_offsets(int fr, int fg) {
+  const int sw = fr & 7, base = fr * 128;
+  MxOff m;
+  m.p0 = base + (((2 * fg) ^ sw) << 4);
+  m.p1 = base + (((2 * fg + 1) ^ sw) << 4);
+  return m;
+}
+__device__ __forceinline__ MxFrag ld_mx_frag(const void* block16, const MxOff& m) {
+  const unsigned char* b = (const unsigned char*)block16;
+  const uint4 p0 = *(const uint4*)(b + m.p0), p1 = *(const uint4*)(b + m.p1);
+  MxFrag f;
+  f.v = (mx_i32x8){(int)p0.x, (int)p0.y, (int)p0.z, (int)p0.w, (int)p1.x, (int)p1.y, (int)p1.z, (int)p1.w};
+  return f;
+}
+// The same for the ping-pong kernel, which runs at the 256-register cap: the second read as ds_read_b96 (codes 4, 5 + scale: the
+// chunk's padding dword never takes a register), 7 registers per fragment.  Opaque to the compiler's waitcnt bookkeeping: the
+// caller retires the reads with its own s_waitcnt lgkmcnt(0) (the L part of a phase ends with one anyway).
+// The ping-pong kernel runs at the 256-register cap, and the MFMA builtin wants 8-register operands (two of them dead for fp6):
+// there the fragment is exactly what the instruction reads — a 6-register tuple of codes + one scale register (b128 + b96 LDS
+// reads: the chunk's padding dword never takes a register) — and the instruction is issued through inline assembly.  Its
+// accumulator is written by builtin MFMAs and asm MFMAs alternately, always with a barrier and a round of LDS reads in between.
+typedef unsigned mx_u3 __attribute__((ext_vector_type(3)));
+typedef unsigned mx_u4 __attribute__((ext_vector_type(4)));
+struct MxFrag7 { mx_u6 v; unsigned s; };
+template <int OFF>
+__device__ __forceinline__ MxFrag7 ld_mx_frag7(unsigned lds_block16, const MxOff& m) {
+  typedef const mx_u4 __attribute__((address_space(3))) * lds_u4;
+  typedef const mx_u3 __attribute__((address_space(3))) * lds_u3;
+  const mx_u4 p0 = *(lds_u4)(uintptr_t)(lds_block16 + (unsigned)m.p0 + OFF);
+  const mx_u3 p1 = *(lds_u3)(uintptr_t)(lds_block16 + (unsigned)m.p1 + OFF);      // 16-byte aligned 12-byte read: ds_read_b96
+  MxFrag7 f;
+  f.v = (mx_u6){p0[0], p0[1], p0[2], p0[3], p1[0], p1[1]};
+  f.s = p1[2];
+  return f;
+}
+__device__ __forceinline__ void mfma_mx6_asm(f32x4& c, const MxFrag7& a, const MxFrag7& b) {
+  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2"
+               : "+v"(c) : "v"(a.v), "v"(b.v), "v"(a.s), "v"(b.s));
+}
+
 // SPLIT: write fp32 partials [z][m_pad][n] (epilogue applied later by splitk_reduce_kernel).
 // T = X3<HT> (split-precision modes): A / W rows are hi | lo pairs (wseg_common.h), lda / ldw / k_len count 16-bit words
 // (twice the logical K), and a K tile is multiplied as (W hi, A hi) + (W hi, A lo) + (W lo, A hi).
@@ -290,7 +335,8 @@ __global__ __launch_bounds__(WM * WN * 64, (BM <= 128 && BN <= 64 && WM * WN == 
                                                         int M, int N, int k_len, EpiParams ep,
                                                         float* __restrict__ part, int m_pad, int ntm) {
   typedef typename IO<T>::H HT;
-  constexpr bool X3M = IO<T>::split;
+  constexpr bool MXM = IsMx<T>::v;               // M6 rows: K tiles alternate hi (plain half MFMAs) / MX (one scaled MFMA per 16x16 tile)
+  constexpr bool X3M = IO<T>::split && !MXM;
   constexpr int BK = 64;
   constexpr int TM = BM / WM, TN = BN / WN;      // wave tile
   constexpr int MI = TM / 16, NI = TN / 16;      // 16x16 MFMA tiles per wave
@@ -399,6 +445,25 @@ __global__ __launch_bounds__(WM * WN * 64, (BM <= 128 && BN <= 64 && WM * WN == 
       wcur = wnxt;
     }
   };
+  // M6 rows, MX tile: both cross terms of 64 logical columns in one scaled MFMA per 16x16 tile
+  auto compute_mx = [&](int buf) {
+    const HT* cA = sA + buf * BM * BK + (wm * TM) * BK;
+    const HT* cW = sW + buf * BN * BK + (wn * TN) * BK;
+    const MxOff mo = mx_offsets(fr, fg);
+    MxFrag am[MI];
+#pragma unroll
+    for (int j = 0; j < MI; ++j) am[j] = ld_mx_frag(cA + j * 16 * BK, mo);
+    MxFrag wcur = ld_mx_frag(cW, mo);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      MxFrag wnxt = wcur;
+      if (i + 1 < NI) wnxt = ld_mx_frag(cW + (i + 1) * 16 * BK, mo);
+      if (i == NI - 1) lds_reads_done_barrier();      // every fragment of the tile has been read: the stage may be refilled
+#pragma unroll
+      for (int j = 0; j < MI; ++j) acc[i][j] = mfma_mx6(wcur, am[j], acc[i][j]);
+      wcur = wnxt;
+    }
+  };
   // NST-deep LDS ring.  NST == 2: prefetch one tile ahead.  NST > 2 (decoder weight streams, few K tiles per
   // workgroup): NST-1 tiles are kept in flight; past the end the last tile is re-issued so the counted vmcnt
   // stays a compile-time constant.
@@ -423,7 +488,8 @@ __global__ __launch_bounds__(WM * WN * 64, (BM <= 128 && BN <= 64 && WM * WN == 
       wait_vmcnt<NLD*(NST - 1)>();
     }
     __builtin_amdgcn_s_barrier();
-    compute(buf);                                   // ends with lds_reads_done_barrier(): the stage may be refilled
+    if (MXM && ((kbeg / BK + kt) & 1)) compute_mx(buf);
+    else compute(buf);                              // ends with lds_reads_done_barrier(): the stage may be refilled
   }
 
   // epilogue: lane holds n = nb + i*16 + fg*4 + {0..3}, m = mb + j*16 + fr
@@ -560,11 +626,12 @@ __device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NI][MI], floa
 // 8-row-group tile order; its workgroups interleave over that run, so tiles in flight on one L2 are neighbours.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_h16_persist_kernel(const typename IO<T>::H* __restrict__ A, int lda,
+__global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 2 : 1) void gemm_h16_persist_kernel(const typename IO<T>::H* __restrict__ A, int lda,
                                                                          const typename IO<T>::H* __restrict__ W, int ldw, int M, int N,
                                                                          int K, EpiParams ep, int ntm, int GM) {
   typedef typename IO<T>::H HT;
-  constexpr bool X3M = IO<T>::split;
+  constexpr bool MXM = IsMx<T>::v;
+  constexpr bool X3M = IO<T>::split && !MXM;
   constexpr int BK = 64;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 16, NI = TN / 16;
@@ -629,7 +696,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h16_persist_kernel(const ty
     const bool has_next = nidx < count;
     int nm0 = 0, nn0 = 0;
     if (has_next) tile_coords(start + nidx, nm0, nn0);
-    for (int kt = 0; kt < nk; ++kt) {
+    // tile bodies as lambdas: the M6 instantiation runs a (hi tile, MX tile) pair per iteration as straight-line code (register
+    // allocation: see gemm_h16_pp_kernel)
+    auto tile_head = [&](int kt, const HT*& cA, const HT*& cW) {
       const int buf = (g + kt) & 1;
       if (kt + 1 < nk) {
         issue(kt + 1, buf ^ 1);
@@ -642,8 +711,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h16_persist_kernel(const ty
         wait_vmcnt<0>();
       }
       __builtin_amdgcn_s_barrier();
-      const HT* cA = smem + buf * STAGE + (wm * TM) * BK;
-      const HT* cW = smem + buf * STAGE + BM * BK + (wn * TN) * BK;
+      cA = smem + buf * STAGE + (wm * TM) * BK;
+      cW = smem + buf * STAGE + BM * BK + (wn * TN) * BK;
+    };
+    auto hi_tile = [&](int kt) {
+      const HT *cA, *cW;
+      tile_head(kt, cA, cW);
       auto lda_f = [&](int kk, int j) {
         const int rw = j * 16 + fr;
         return *(const bf16x8*)(cA + rw * BK + (((kk * 4 + fg) ^ (rw & 7)) << 3));
@@ -684,6 +757,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_h16_persist_kernel(const ty
         for (int j = 0; j < MI; ++j) acc[i][j] = H16<HT>::mfma16(wcur, X3M ? af0[j] : af1[j], acc[i][j]);
         wcur = wnxt;
       }
+    };
+    [[maybe_unused]] auto mx_tile = [&](int kt) {
+      const HT *cA, *cW;
+      tile_head(kt, cA, cW);
+                        // M6 rows, MX tile (K / 64 is even: the parity of kt is the tile kind)
+        const MxOff mo = mx_offsets(fr, fg);
+        MxFrag am[MI];
+#pragma unroll
+        for (int j = 0; j < MI; ++j) am[j] = ld_mx_frag(cA + j * 16 * BK, mo);
+        MxFrag wcur = ld_mx_frag(cW, mo);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          MxFrag wnxt = wcur;
+          if (i + 1 < NI) wnxt = ld_mx_frag(cW + (i + 1) * 16 * BK, mo);
+          if (i == NI - 1) lds_reads_done_barrier();
+#pragma unroll
+          for (int j = 0; j < MI; ++j) acc[i][j] = mfma_mx6(wcur, am[j], acc[i][j]);
+          wcur = wnxt;
+        }
+    };
+    if constexpr (MXM) {
+      for (int kt = 0; kt < nk; kt += 2) { hi_tile(kt); mx_tile(kt + 1); }
+    } else {
+      for (int kt = 0; kt < nk; ++kt) hi_tile(kt);
     }
     g += nk;
     // LDS-staged epilogue in the stage consumed last ((g-1)&1); the other stage is receiving the next tile
@@ -731,7 +828,8 @@ template <typename T, int EPI, bool STAGED_RESID = false, bool SPLITK = false>
 __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::H* __restrict__ A, int lda, const typename IO<T>::H* __restrict__ W,
                                                           int ldw, int M, int N, int K, EpiParams ep, int ntm, int GM, int S) {
   typedef typename IO<T>::H HT;
-  constexpr bool X3M = IO<T>::split;      // hi | lo K tiles: 24 instead of 16 MFMAs per phase, (W hi, A hi) (W hi, A lo) (W lo, A hi)
+  constexpr bool MXM = IsMx<T>::v;        // M6 rows: odd K tiles are MX tiles (16 scaled MFMAs per phase instead of 32 plain ones)
+  constexpr bool X3M = IO<T>::split && !MXM;      // hi | lo K tiles: 24 instead of 16 MFMAs per phase, (W hi, A hi) (W hi, A lo) (W lo, A hi)
   // Residual epilogue without LDS and without barriers (EPI_RESID, opt-in: WSEG_PP_DIRECT_RESID=1; the LDS-staged one is the
   // default): the accumulators of a tile START as its fp32 residual rows (loaded in the MFMA accumulator layout: a lane owns 4
   // consecutive columns of a row, 16 bytes), the MFMAs add A W^T on top, and the epilogue is bias + 32 direct 16-byte stores
@@ -762,7 +860,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   if (loc >= count) return;
   // split-K: copy z of the tile grid owns K tiles [k_first(z), k_first(z + 1))
   auto tile_z = [&](int swz) { return SPLITK ? swz / ntmn : 0; };
-  auto k_first = [&](int z) { return SPLITK ? z * nk / S : 0; };
+  auto k_first = [&](int z) { return SPLITK ? (MXM ? 2 * (z * (nk / 2) / S) : z * nk / S) : 0; };      // M6 rows: whole (hi, MX) tile pairs
   int KT = ((count - loc + bpx - 1) / bpx) * nk;            // K tiles this workgroup consumes
   if constexpr (SPLITK) {
     KT = 0;
@@ -780,7 +878,22 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   // thread's piece of a half-tile: LDS 16-B slot p = it*512 + tid (it = 0, 1) holds row p >> 3, logical slot
   // (p & 7) ^ (row & 7) (swizzle on the source side); piece 1 is 64 rows below piece 0, same slot.
   const int prow = tid >> 3, pslot = (tid & 7) ^ (prow & 7);
-  const int a_lane = prow * lda + pslot * 8, w_lane = prow * ldw + pslot * 8;      // element offsets (< 2^31)
+  // per-lane BYTE offsets, unsigned 32-bit (rows of a tile span < 2^31 bytes): with a wave-uniform 64-bit base they select the
+  // SGPR-base + 32-bit-VGPR-offset form of global_load_lds — no 64-bit address arithmetic (and no 64-bit lane offsets to spill:
+  // a spilled pair was reloaded behind an s_waitcnt vmcnt(0) in every phase, draining the prefetch stream)
+  const unsigned a_lane = (unsigned)(prow * lda + pslot * 8) * (unsigned)sizeof(HT), w_lane = (unsigned)(prow * ldw + pslot * 8) * (unsigned)sizeof(HT);
+  // M6 instantiation (at the 256-register cap): the lane offset is RECOMPUTED from the thread index at every issue (a few VALU
+  // operations in an L part that has room for them) behind an opaque copy of tid, so that no 64-bit lane offset is kept alive
+  // across the loop — and spilled, and reloaded behind a vmcnt(0).  Other modes keep the precomputed value.
+  auto lane_off = [&](int ld, unsigned kept) -> unsigned {
+    if constexpr (!MXM) return kept;
+    else {
+      unsigned t = (unsigned)tid;
+      asm volatile("" : "+v"(t));
+      const unsigned pr = t >> 3, ps = (t & 7) ^ (pr & 7);
+      return (pr * (unsigned)ld + ps * 8) * (unsigned)sizeof(HT);
+    }
+  };
   int ca_idx = loc, ca_kt = 0, ca_g = 0, cb_idx = loc, cb_kt = 0, cb_g = 0;
   int tm, tn;
   tile_coords(start + loc, tm, tn);
@@ -788,9 +901,10 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   int ca_k0 = k_first(tile_z(start + loc)), ca_nk = SPLITK ? k_first(tile_z(start + loc) + 1) - ca_k0 : nk, cb_k0 = ca_k0, cb_nk = ca_nk;
   auto issue_a = [&](int half) {                       // half-tile A<half> of K tile ca_g; the cursor advances after A1
     HT* dst = smem + (ca_g & 1) * BUF + half * HTILE + wave * 512;
-    const HT* src = A + (ca_row + (size_t)(half * 128) * lda + ((SPLITK ? ca_k0 : 0) + ca_kt) * BK) + a_lane;
-    WSEG_GLDS16(src, dst);
-    WSEG_GLDS16(src + (size_t)64 * lda, dst + 4096);
+    const char* sbase = (const char*)(A + (ca_row + (size_t)(half * 128) * lda + ((SPLITK ? ca_k0 : 0) + ca_kt) * BK));      // uniform
+    const unsigned al = lane_off(lda, a_lane);
+    WSEG_GLDS16(sbase + (size_t)al, dst);
+    WSEG_GLDS16(sbase + (size_t)64 * lda * sizeof(HT) + (size_t)al, dst + 4096);
     if (half == 1) {
       ++ca_g;
       if (++ca_kt == (SPLITK ? ca_nk : nk)) {
@@ -806,9 +920,10 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   };
   auto issue_b = [&](int half) {
     HT* dst = smem + (cb_g & 1) * BUF + (2 + half) * HTILE + wave * 512;
-    const HT* src = W + (cb_row + (size_t)(half * 128) * ldw + ((SPLITK ? cb_k0 : 0) + cb_kt) * BK) + w_lane;
-    WSEG_GLDS16(src, dst);
-    WSEG_GLDS16(src + (size_t)64 * ldw, dst + 4096);
+    const char* sbase = (const char*)(W + (cb_row + (size_t)(half * 128) * ldw + ((SPLITK ? cb_k0 : 0) + cb_kt) * BK));      // uniform
+    const unsigned wl = lane_off(ldw, w_lane);
+    WSEG_GLDS16(sbase + (size_t)wl, dst);
+    WSEG_GLDS16(sbase + (size_t)64 * ldw * sizeof(HT) + (size_t)wl, dst + 4096);
     if (half == 1) {
       ++cb_g;
       if (++cb_kt == (SPLITK ? cb_nk : nk)) {
@@ -834,6 +949,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   const int frag0 = fr * BK + ((fg ^ (fr & 7)) << 3);
   const int fa0 = wr * HTILE + frag0, fa1 = fa0 ^ 32;
   const int fb0 = (2 + (wc >> 1)) * HTILE + (wc & 1) * 64 * BK + frag0, fb1 = fb0 ^ 32;
+  [[maybe_unused]] const MxOff mxo = mx_offsets(fr, fg);
 
 #define WSEG_PP_QUADRANT(JA, IB)                                                                                      \
   _Pragma("unroll") for (int kk = 0; kk < (X3M ? 3 : 2); ++kk)                                                        \
@@ -888,8 +1004,10 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
 #pragma unroll
       for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-#pragma nounroll
-  for (int kt = 0; kt < nkt; ++kt, ++g) {
+  // One K tile = two phases.  The tile bodies are lambdas so that the M6 instantiation can run a (hi tile, MX tile) PAIR per loop
+  // iteration as straight-line code: with both bodies behind a branch inside one loop the register allocator spilled ~60 VGPRs into
+  // the loop, and every scratch reload waits (vmcnt is in order) for the whole LDS-DMA prefetch stream: 4x slower than f16x3.
+  auto hi_tile = [&](int kt) {
     // direct epilogue: the K-tile stream never pauses at an output-tile boundary (no staging buffer to protect)
     const bool first = !(DIRECT && direct) && kt == 0 && g > 0, final = !(DIRECT && direct) && kt == nkt - 1;
     const HT* cur = smem + (g & 1) * BUF;
@@ -927,6 +1045,54 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
     __builtin_amdgcn_sched_barrier(0);
     WSEG_PP_MFMA(1, 1, 0);
     if (!final) __builtin_amdgcn_s_barrier();
+  };
+  [[maybe_unused]] auto mx_tile = [&](int kt) {
+    // direct epilogue: the K-tile stream never pauses at an output-tile boundary (no staging buffer to protect)
+    const bool first = !(DIRECT && direct) && kt == 0 && g > 0, final = !(DIRECT && direct) && kt == nkt - 1;
+    const HT* cur = smem + (g & 1) * BUF;
+      // ---- MX tile (M6 rows): the same two phases, hand-overs and prefetch stream as below; the fragments are 24-byte e2m3
+      // groups + a scale byte (ld_mx_frag), a quadrant pair is 16 scaled MFMAs ----
+      const unsigned aT = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)(cur + wr * HTILE);      // this row group's 128-row A half-tile
+      const unsigned bT = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)(cur + (2 + (wc >> 1)) * HTILE + (wc & 1) * 64 * BK);   // this wave's 64 W rows
+      MxFrag7 bm[NI], am[4];
+      bm[0] = ld_mx_frag7<0>(bT, mxo); bm[1] = ld_mx_frag7<2048>(bT, mxo); bm[2] = ld_mx_frag7<4096>(bT, mxo); bm[3] = ld_mx_frag7<6144>(bT, mxo);
+      am[0] = ld_mx_frag7<0>(aT, mxo); am[1] = ld_mx_frag7<2048>(aT, mxo); am[2] = ld_mx_frag7<4096>(aT, mxo); am[3] = ld_mx_frag7<6144>(aT, mxo);
+      if (first && g + 1 < KT) { issue_b(0); issue_b(1); }
+      if (g + 1 < KT) { issue_a(0); issue_a(1); }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mfma_mx6_asm(acc[i][j], bm[i], am[j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      am[0] = ld_mx_frag7<8192>(aT, mxo); am[1] = ld_mx_frag7<10240>(aT, mxo); am[2] = ld_mx_frag7<12288>(aT, mxo); am[3] = ld_mx_frag7<14336>(aT, mxo);
+      if (!final && g + 2 < KT) { issue_b(0); issue_b(1); wait_vmcnt<4>(); }
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mfma_mx6_asm(acc[i][4 + j], bm[i], am[j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!final) __builtin_amdgcn_s_barrier();
+  };
+  if constexpr (MXM) {
+#pragma nounroll
+    for (int kt = 0; kt < nkt; kt += 2) { hi_tile(kt); ++g; mx_tile(kt + 1); ++g; }      // K ranges are whole tile pairs starting at a hi tile
+  } else {
+#pragma nounroll
+    for (int kt = 0; kt < nkt; ++kt, ++g) hi_tile(kt);
   }
   // Epilogue: group 0 gives up its one-barrier lead (it idles while group 1 finishes its last 16 MFMAs), both groups run
   // their epilogues in the SAME interval — back to back they cost two epilogue times with the matrix pipe idle, side by
@@ -1253,7 +1419,7 @@ static int device_cu_count() {
 // applies the epilogue (or the fused residual + LayerNorm).
 struct SkinnyPlan { int bm, bn, mt, m_pad, splits, k_len; };
 
-static SkinnyPlan plan_skinny(const GemmArgs& g) {
+static SkinnyPlan plan_skinny(const GemmArgs& g, bool pairs = false) {      // pairs: M6 rows — a K range is whole (hi, MX) tile pairs
   SkinnyPlan sp;
   // largest row tile that still yields >= 160 workgroups without splitting K; otherwise 128 rows + split-K
   sp.bm = g.M <= 32 ? 32 : (g.M <= 64 ? 64 : 128);
@@ -1273,7 +1439,7 @@ static SkinnyPlan plan_skinny(const GemmArgs& g) {
     const int nk = g.K / 64;
     static const int target = getenv("WSEG_SKINNY_TARGET") ? atoi(getenv("WSEG_SKINNY_TARGET")) : 256;   // tuning knob
     for (int cand = 2; cand <= 16 && blocks * sp.splits < target; ++cand) {
-      if (nk % cand || nk / cand < 2) continue;
+      if (nk % cand || nk / cand < 2 || (pairs && (nk / cand) % 2)) continue;
       if ((size_t)cand * sp.m_pad * g.N * sizeof(float) > g.splitk_ws_bytes) break;
       sp.splits = cand;
     }
@@ -1391,7 +1557,7 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
   const GemmArgs g = kernel_view<T>(g0);
   const HT* A = (const HT*)g.A;
   const HT* W = (const HT*)g.W;
-  if (g.K % 64 || g.N % 64) { set_error("gemm h16: K %d / N %d not tile multiples", g.K, g.N); return WSEG_ERR_INVALID; }
+  if (g.K % 64 || g.N % 64 || (IsMx<T>::v && g.K % 128)) { set_error("gemm h16: K %d / N %d not tile multiples", g.K, g.N); return WSEG_ERR_INVALID; }
   if (big_tile_path(g)) {
     static const bool no_swz = getenv("WSEG_NO_XCD_SWIZZLE") != nullptr;
     static const bool big256 = getenv("WSEG_GEMM_128") == nullptr;   // 256x256 tiles by default where they fill the chip
@@ -1460,7 +1626,7 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
     WSEG_LAUNCH_CHECK();
     return WSEG_OK;
   }
-  SkinnyPlan sp = plan_skinny(g);
+  SkinnyPlan sp = plan_skinny(g, IsMx<T>::v);
   if (sp.splits == 1) {
     dim3 grid(g.N / 64, sp.mt, 1);
 #define WSEG_SKINNY(BM_, WM_, WN_)                                                                                      \
@@ -1519,6 +1685,7 @@ static int launch_any(int dtype, const GemmArgs& g, hipStream_t s) {
   if (dtype == WSEG_F16) return launch_h16<EPI, f16_t>(g, s);
   if (dtype == WSEG_BF16X3) return launch_h16<EPI, X3<bf16_t>>(g, s);
   if (dtype == WSEG_F16X3) return launch_h16<EPI, X3<f16_t>>(g, s);
+  if (dtype == WSEG_F16M6) return launch_h16<EPI, M6>(g, s);
   return launch_f32<EPI>(g, s);
 }
 
@@ -1526,7 +1693,7 @@ template <typename T>
 static int gemm_partial_t(const GemmArgs& g0, PartialInfo* info, bool* ok, hipStream_t s) {
   const GemmArgs g = kernel_view<T>(g0);
   if (big_tile_path(g) || !g.splitk_ws || g.K % 64 || g.N % 64) return WSEG_OK;
-  SkinnyPlan sp = plan_skinny(g);
+  SkinnyPlan sp = plan_skinny(g, IsMx<T>::v);
   if ((size_t)sp.splits * sp.m_pad * g.N * sizeof(float) > g.splitk_ws_bytes) return WSEG_OK;
   WSEG_TRY_(launch_skinny_partial<T>(g, sp, s));
   info->part = g.splitk_ws; info->splits = sp.splits; info->m_pad = sp.m_pad; info->n = g.N;
@@ -1541,6 +1708,7 @@ int launch_gemm_partial(int dtype, const GemmArgs& g, PartialInfo* info, bool* o
     case WSEG_F16: return gemm_partial_t<f16_t>(g, info, ok, s);
     case WSEG_BF16X3: return gemm_partial_t<X3<bf16_t>>(g, info, ok, s);
     case WSEG_F16X3: return gemm_partial_t<X3<f16_t>>(g, info, ok, s);
+    case WSEG_F16M6: return gemm_partial_t<M6>(g, info, ok, s);
     default: return WSEG_OK;      // exact-parity mode: no split-K (one k-ordered chain per output)
   }
 }
@@ -1593,7 +1761,7 @@ static int gemm_resid_ln_t(const GemmArgs& g0, const void* gamma, const void* be
   if (big_tile_path(g) || !g.splitk_ws || d % 8 || d > 2048 || !g.ep.bias || g.ep.resid != g.ep.out || g.ep.ldc != d || g.K % 64 ||
       g.N % 64)
     return WSEG_OK;
-  SkinnyPlan sp = plan_skinny(g);
+  SkinnyPlan sp = plan_skinny(g, IsMx<T>::v);
   static const bool fuse_unsplit = getenv("WSEG_RESID_LN_ALWAYS_PARTIAL") == nullptr;   // tuning knob
   // K not split (enough row tiles to fill the chip, 2048+ rows): the fp32 partial round trip buys nothing; the GEMM adds
   // the residual in its own epilogue and a LayerNorm launch follows (2048 rows: 21.6 + ~6 us against 26.7 + 8.9 us)
@@ -1613,11 +1781,21 @@ int launch_gemm_resid_ln(int dtype, const GemmArgs& g, const void* gamma, const 
     case WSEG_F16: WSEG_TRY_(gemm_resid_ln_t<f16_t>(g, gamma, beta, y, &done, s)); break;
     case WSEG_BF16X3: WSEG_TRY_(gemm_resid_ln_t<X3<bf16_t>>(g, gamma, beta, y, &done, s)); break;
     case WSEG_F16X3: WSEG_TRY_(gemm_resid_ln_t<X3<f16_t>>(g, gamma, beta, y, &done, s)); break;
+    case WSEG_F16M6: WSEG_TRY_(gemm_resid_ln_t<M6>(g, gamma, beta, y, &done, s)); break;
     default: break;
   }
   if (done) return WSEG_OK;
   WSEG_TRY_(launch_gemm(dtype, EPI_RESID, g, s));
-  return launch_layernorm(dtype, (const float*)g.ep.out, gamma, beta, y, g.M, g.N, s);
+  return launch_layernorm(dtype, (const float*)g.ep.out, gamma, beta, y, g.M, g.N, s);      // (WSEG_F16M6: y as M6 rows, like the fused kernel)
+}
+
+// WSEG_F16M6: are the operand rows an EPI_STORE / EPI_GELU launch of this shape writes M6 rows (LDS-staged 8-column epilogues of the
+// large-tile kernels: cooperative op_st8) or hi | lo rows (4-column epilogues of the skinny family and its split-K reduction)?
+bool gemm_out_is_mx(int dtype, int M, int N, int K) {
+  if (dtype != WSEG_F16M6) return false;
+  GemmArgs g;
+  g.M = M; g.N = N; g.K = 2 * K;
+  return big_tile_path(g);
 }
 
 int launch_gemm(int dtype, EpiKind epi, const GemmArgs& g, hipStream_t s) {
@@ -1650,6 +1828,8 @@ extern "C" int wseg_debug_gemm(int32_t dtype, int32_t epi, int32_t M, int32_t N,
   g.splitk_ws = (float*)splitk_ws; g.splitk_ws_bytes = splitk_ws_bytes;
   return launch_gemm(dtype, epi == 0 ? EPI_STORE : (epi == 1 ? EPI_GELU : EPI_RESID), g, (hipStream_t)stream);
 }
+
+extern "C" int wseg_debug_gemm_out_is_mx(int32_t dtype, int32_t M, int32_t N, int32_t K) { return wseg::gemm_out_is_mx(dtype, M, N, K) ? 1 : 0; }
 
 extern "C" int wseg_debug_gemm_resid_ln(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, const void* W, const void* bias,
                                         void* x, const void* gamma, const void* beta, void* y, void* splitk_ws, size_t splitk_ws_bytes,

@@ -72,6 +72,8 @@ struct GemmArgs {
 // M may be any value as long as A has round_up(M,256) readable rows; N % 128 == 0 rows of W readable; K % 64 == 0
 // (K % 32 == 0 in the split-precision modes).
 int launch_gemm(int dtype, EpiKind epi, const GemmArgs& g, hipStream_t s);
+// WSEG_F16M6: does an EPI_STORE / EPI_GELU launch of this (logical) shape write M6 rows (true) or hi | lo rows (false)?
+bool gemm_out_is_mx(int dtype, int M, int N, int K);
 // Split-K partial sums only (bf16 decoder rows): part[z][m_pad][N] fp32 in g.splitk_ws, no epilogue.  The consumer
 // kernel (decoder self-/cross-attention) finishes the reduction itself.  Returns false in *ok when the shape is not
 // served by the skinny family (caller falls back to launch_gemm).
@@ -90,6 +92,8 @@ int launch_im2col_conv2(int dtype, const void* h1, void* a2, int B, int cols, in
 // y[m][:] = LayerNorm(x[m][:]) * g + b, eps 1e-5; x is the fp32 residual stream, y / g / b have the model dtype.
 int launch_layernorm(int dtype, const float* x, const void* g, const void* b, void* y, int M, int d, hipStream_t s);
 // Encoder self-attention over Q,K [B][H][Tp][64], Vt [B][H][64][Tp] (q pre-scaled) -> out [B*T][d].
+// WSEG_F16M6: *out_is_mx (may be null) reports whether out was written as M6 rows (split-precision attention) or as hi | lo rows.
+bool enc_attention_writes_mx(int dtype);
 int launch_enc_attention(int dtype, const void* q, const void* k, const void* vt, void* out,
                          int B, int H, int T, int Tp, int d, hipStream_t s);
 
@@ -100,6 +104,10 @@ int x3_enc_attention_mode();
 // bits — the ">= 16 bits" the precision study asks of the cross K; 3 instead of 4 bytes per element of an HBM-bound stream).
 // Default on; WSEG_X3_CKV=f32 keeps fp32.
 bool x3_cross_kv24();
+// WSEG_F16M6: hi | lo IEEE-half operand rows [M][2K words] -> M6 rows [M][4K bytes] (wseg_common.h), K % 64 == 0
+int launch_x3_to_m6(const void* x3_rows, void* m6_rows, size_t M, int K, bool weight_order, hipStream_t s);
+// the dtype every NON-GEMM kernel runs in: WSEG_F16M6 is WSEG_F16X3 outside the GEMMs
+static inline int storage_dtype(int dtype) { return dtype == WSEG_F16M6 ? WSEG_F16X3 : dtype; }
 // Split-precision modes only: operand rows (hi | lo pairs, wseg_common.h) [M][2d words] <-> fp32 [M][d], d % 32 == 0.
 int launch_operand_to_f32(int dtype, const void* op, float* out, size_t M, int d, hipStream_t s);
 int launch_f32_to_operand(int dtype, const float* in, void* op, size_t M, int d, hipStream_t s);

@@ -40,6 +40,7 @@ struct DecPlan {   // decoder-side buffers (W window slots)
 struct Plan {   // workspace carve-up (all offsets 256-byte aligned)
   size_t total = 0;
   char *a1, *h1, *a2, *x, *y, *q, *k, *vt, *hbuf, *enc_out;
+  char *mxa = nullptr, *mxe = nullptr;      // WSEG_F16M6: M6 rows of the current GEMM's activation operand / of the encoder output
   DecPlan dec;
 };
 
@@ -73,6 +74,9 @@ struct wseg_model {
   wseg_model_config cfg;
   size_t es;                 // element size of the model dtype
   bool x3 = false;           // split-precision mode (GEMM operands are hi | lo rows, everything else fp32)
+  bool mx = false;           // WSEG_F16M6: GEMM operands are M6 rows (weights attached converted; activations converted before each GEMM)
+  int sdt = 0;               // dtype of every non-GEMM kernel (WSEG_F16M6 -> WSEG_F16X3)
+  const void* dec_tok_f32 = nullptr;      // WSEG_F16M6: fp32 copy of the token embedding for the embedding lookup
   size_t ckv_es = 0;         // bytes per cross-attention K / V element: es, or 3 (24-bit planes) in the split modes with <= 4 beams
   int kp1, vp, tp;           // conv1 K padded, vocab padded, encoder positions padded
   std::map<std::string, Slot> slots;
@@ -137,6 +141,24 @@ void make_plan(const wseg_model* m, int W, int nb, int L, int kv_units, char* ba
   p.vt = take((size_t)We * H * m->tp * 64 * es);
   p.enc_out = take(Mp * d * es);
   const size_t Ld = c.dec_layers, Tk = c.enc_positions;
+  if (m->mx) {
+    // scratch for the activation operands that still arrive as hi | lo rows and are converted in front of their GEMM: the conv1
+    // im2col always; conv2's operand, the attention output and the FFN hidden only when their producer is not one that writes
+    // M6 rows directly (4-column epilogues of the skinny GEMM family on small problems; WSEG_X3_ENC_ATTN != split)
+    const int dtp = c.dtype, Me = We * c.enc_positions, M1e = We * c.spec_cols, R0 = W * nb;
+    const size_t Rp0 = align_up((size_t)R0, 256);
+    size_t big = M1p * (size_t)m->kp1;
+    if (!enc_attention_writes_mx(dtp)) big = std::max(big, Mp * d);
+    for (int n = 1; n <= We; ++n) {      // an encoder pass runs over 1 .. We windows (refills admit a few at a time)
+      const size_t mp = align_up((size_t)n * c.enc_positions, 256);
+      if (!gemm_out_is_mx(dtp, n * c.spec_cols, (int)d, m->kp1)) big = std::max(big, mp * 3 * d);
+      if (!gemm_out_is_mx(dtp, n * c.enc_positions, (int)ffn, (int)d)) big = std::max(big, mp * ffn);
+    }
+    (void)Me; (void)M1e;
+    if (!gemm_out_is_mx(dtp, R0, (int)ffn, (int)d)) big = std::max(big, Rp0 * ffn);
+    p.mxa = take(big * 4);
+    p.mxe = take(Mp * d * 4);
+  }
   const size_t maxn = 3 * d > ffn ? 3 * d : ffn;
   DecPlan& q = p.dec;
   q.W = W;
@@ -196,15 +218,26 @@ int check_geometry(const wseg_model_config& c) {
   if (c.spec_cols != 2 * c.enc_positions || c.enc_positions > 512 || c.enc_positions < 128) { set_error("spec_cols %d / enc_positions %d unsupported", c.spec_cols, c.enc_positions); return WSEG_ERR_INVALID; }
   if (c.n_mels <= 0 || c.n_mels > 96) { set_error("n_mels %d unsupported", c.n_mels); return WSEG_ERR_INVALID; }
   if (c.dec_positions <= 0 || c.dec_positions > 512) { set_error("dec_positions %d unsupported", c.dec_positions); return WSEG_ERR_INVALID; }
-  if (c.dtype < WSEG_F32 || c.dtype > WSEG_F16X3) { set_error("dtype %d unsupported", c.dtype); return WSEG_ERR_INVALID; }
+  if (c.dtype < WSEG_F32 || c.dtype > WSEG_F16M6) { set_error("dtype %d unsupported", c.dtype); return WSEG_ERR_INVALID; }
   if (c.enc_layers <= 0 || c.dec_layers <= 0 || c.vocab <= 0) { set_error("bad layer/vocab counts"); return WSEG_ERR_INVALID; }
   return WSEG_OK;
 }
 
 #define WSEG_TRY(expr) do { int _s = (expr); if (_s != WSEG_OK) return _s; } while (0)
 
+// WSEG_F16M6: the activation operand of a GEMM (hi | lo rows, row length lda == K logical columns) as M6 rows in `scratch`
+int to_mx(const wseg_model* m, const void*& A, int M, int K, char* scratch, hipStream_t s) {
+  if (!m->mx) return WSEG_OK;
+  if (!scratch) { set_error("M6 operand scratch missing"); return WSEG_ERR_STATE; }
+  const int st = launch_x3_to_m6(A, scratch, (size_t)M, K, false, s);
+  A = scratch;
+  return st;
+}
+
+// mxa: scratch for the M6 image of A (WSEG_F16M6; null when A already is M6 rows)
 int gemm(const wseg_model* m, EpiKind epi, const void* A, int lda, const void* Wt, int ldw, int M, int N, int K,
-         const EpiParams& ep, const DecPlan* p, hipStream_t s) {
+         const EpiParams& ep, const DecPlan* p, hipStream_t s, char* mxa = nullptr) {
+  if (m->mx && mxa) { const int st = to_mx(m, A, M, K, mxa, s); if (st != WSEG_OK) return st; }
   GemmArgs g;
   g.A = A; g.lda = lda; g.W = Wt; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.ep = ep;
   if (p) { g.splitk_ws = (float*)p->splitk; g.splitk_ws_bytes = p->splitk_bytes; }
@@ -213,7 +246,9 @@ int gemm(const wseg_model* m, EpiKind epi, const void* A, int lda, const void* W
 
 int run_encoder(wseg_model* m, const float* feats, int W, Plan& p, void* enc_out, hipStream_t s) {
   const wseg_model_config& c = m->cfg;
-  const int dt = c.dtype, d = c.d_model, H = c.n_heads, ffn = c.ffn, T = c.enc_positions, Tp = m->tp;
+  // dt: dtype of the non-GEMM kernels whose output is NOT a GEMM operand in M6 form; gdt: the model's dtype (WSEG_F16M6: LayerNorm,
+  // the attention and the large-tile GEMM epilogues write M6 rows directly; what still arrives as hi | lo rows is converted, mxa)
+  const int dt = m->sdt, gdt = c.dtype, d = c.d_model, H = c.n_heads, ffn = c.ffn, T = c.enc_positions, Tp = m->tp;
   const int M1 = W * c.spec_cols, M = W * T;
   const size_t qkv_bytes = (size_t)W * H * Tp * 64 * m->es;
   // pad rows of Q/K and pad columns of V^T must be finite (they are multiplied by exact zeros)
@@ -223,94 +258,103 @@ int run_encoder(wseg_model* m, const float* feats, int W, Plan& p, void* enc_out
   WSEG_TRY(launch_im2col_conv1(dt, feats, p.a1, W, c.n_mels, c.spec_cols, m->kp1, s));
   EpiParams e;
   e.bias = m->conv1_b; e.out = p.h1; e.ldc = d;
-  WSEG_TRY(gemm(m, EPI_GELU, p.a1, m->kp1, m->conv1_w, m->kp1, M1, d, m->kp1, e, nullptr, s));
+  WSEG_TRY(gemm(m, EPI_GELU, p.a1, m->kp1, m->conv1_w, m->kp1, M1, d, m->kp1, e, nullptr, s, p.mxa));
+  const bool h1_mx = gemm_out_is_mx(gdt, M1, d, m->kp1);       // the im2col of conv2 is a 16-byte copy: a2 inherits h1's row format
   WSEG_TRY(launch_im2col_conv2(dt, p.h1, p.a2, W, c.spec_cols, d, s));
   e = EpiParams();
   e.bias = m->conv2_b; e.out = p.x; e.ldc = d; e.pos = m->enc_pos; e.pos_rows = T;
-  WSEG_TRY(gemm(m, EPI_GELU_POS, p.a2, 3 * d, m->conv2_w, 3 * d, M, d, 3 * d, e, nullptr, s));
+  WSEG_TRY(gemm(m, EPI_GELU_POS, p.a2, 3 * d, m->conv2_w, 3 * d, M, d, 3 * d, e, nullptr, s, h1_mx ? nullptr : p.mxa));
+  const bool attn_mx = enc_attention_writes_mx(gdt), ffn_mx = gemm_out_is_mx(gdt, M, ffn, d);
   for (int l = 0; l < c.enc_layers; ++l) {
     const EncLayer& L = m->enc[l];
-    WSEG_TRY(launch_layernorm(dt, (const float*)p.x, L.ln1_g, L.ln1_b, p.y, M, d, s));
+    WSEG_TRY(launch_layernorm(gdt, (const float*)p.x, L.ln1_g, L.ln1_b, p.y, M, d, s));
     e = EpiParams();
     e.bias = L.qkv_b; e.q = p.q; e.k = p.k; e.v = p.vt; e.d_model = d; e.t_len = T; e.t_pad = Tp; e.n_heads = H; e.scale = 0.125f;
     if (m->x3) { e.qkv_mode = x3_enc_attention_mode(); e.qkv_plane = (size_t)W * H * Tp * 64; }
     WSEG_TRY(gemm(m, EPI_QKV_ENC, p.y, d, L.qkv_w, d, M, 3 * d, d, e, nullptr, s));
-    WSEG_TRY(launch_enc_attention(dt, p.q, p.k, p.vt, p.y, W, H, T, Tp, d, s));
+    WSEG_TRY(launch_enc_attention(gdt, p.q, p.k, p.vt, p.y, W, H, T, Tp, d, s));
     e = EpiParams();
     e.bias = L.o_b; e.out = p.x; e.resid = p.x; e.ldc = d;
-    WSEG_TRY(gemm(m, EPI_RESID, p.y, d, L.o_w, d, M, d, d, e, nullptr, s));
-    WSEG_TRY(launch_layernorm(dt, (const float*)p.x, L.ln2_g, L.ln2_b, p.y, M, d, s));
+    WSEG_TRY(gemm(m, EPI_RESID, p.y, d, L.o_w, d, M, d, d, e, nullptr, s, attn_mx ? nullptr : p.mxa));
+    WSEG_TRY(launch_layernorm(gdt, (const float*)p.x, L.ln2_g, L.ln2_b, p.y, M, d, s));
     e = EpiParams();
     e.bias = L.fc1_b; e.out = p.hbuf; e.ldc = ffn;
     WSEG_TRY(gemm(m, EPI_GELU, p.y, d, L.fc1_w, d, M, ffn, d, e, nullptr, s));
     e = EpiParams();
     e.bias = L.fc2_b; e.out = p.x; e.resid = p.x; e.ldc = d;
-    WSEG_TRY(gemm(m, EPI_RESID, p.hbuf, ffn, L.fc2_w, ffn, M, d, ffn, e, nullptr, s));
+    WSEG_TRY(gemm(m, EPI_RESID, p.hbuf, ffn, L.fc2_w, ffn, M, d, ffn, e, nullptr, s, ffn_mx ? nullptr : p.mxa));
   }
+  // the encoder output stays hi | lo rows (wseg_encode hands it out as fp32); the cross-K/V GEMMs convert it once (mxe)
   WSEG_TRY(launch_layernorm(dt, (const float*)p.x, m->enc_ln_g, m->enc_ln_b, enc_out, M, d, s));
   return WSEG_OK;
 }
 
 // One decoder step for all R rows at position *st.pos.  want_logits: run final LN + LM head.
-int run_decoder_step(wseg_model* m, DecPlan& p, bool want_logits, hipStream_t s) {
+int run_decoder_step(wseg_model* m, DecPlan& p, char* mxa, bool want_logits, hipStream_t s) {
   const wseg_model_config& c = m->cfg;
-  const int dt = c.dtype, d = c.d_model, H = c.n_heads, ffn = c.ffn, Tk = c.enc_positions;
+  const int dt = m->sdt, gdt = c.dtype, d = c.d_model, H = c.n_heads, ffn = c.ffn, Tk = c.enc_positions;
   const DecodeState& st = p.st;
   const int R = st.W * st.nb;
   const size_t self_stride = p.kv_layer_stride;
   const size_t cross_stride = (size_t)st.W * H * Tk * 64 * ((m->x3 && x3_cross_kv24() && st.nb <= 4) ? 3 : m->es);
-  WSEG_TRY(launch_embed(dt, st, m->dec_tok, m->dec_pos, p.dx, d, s));
+  WSEG_TRY(launch_embed(m->mx ? WSEG_F32 : dt, st, m->mx ? m->dec_tok_f32 : m->dec_tok, m->dec_pos, p.dx, d, s));
   EpiParams e;
-  auto gemm_resid_ln = [&](const void* A, int K, const void* Wt, const void* bias, const void* g_, const void* b_) -> int {
+  // WSEG_F16M6: LayerNorm outputs (dy) and attention outputs (dattn) are M6 rows already; the FFN hidden (dh) is when its GEMM
+  // ran on a large-tile kernel (a_mx: the operand needs no conversion)
+  const bool dh_mx = gemm_out_is_mx(gdt, R, ffn, d);
+  auto gemm_resid_ln = [&](const void* A, int K, const void* Wt, const void* bias, const void* g_, const void* b_, bool a_mx) -> int {
+    if (!a_mx) WSEG_TRY(to_mx(m, A, R, K, mxa, s));
     GemmArgs g;
     g.A = A; g.lda = K; g.W = Wt; g.ldw = K; g.M = R; g.N = d; g.K = K;
     g.ep.bias = bias; g.ep.out = p.dx; g.ep.resid = p.dx; g.ep.ldc = d;
     g.splitk_ws = (float*)p.splitk; g.splitk_ws_bytes = p.splitk_bytes;
-    return launch_gemm_resid_ln(dt, g, g_, b_, p.dy, s);
+    return launch_gemm_resid_ln(gdt, g, g_, b_, p.dy, s);
   };
   // y = LN1(x) of layer 0; every later LayerNorm is fused into the reduction of the GEMM that precedes it
-  WSEG_TRY(launch_layernorm(dt, (const float*)p.dx, m->dec[0].ln1_g, m->dec[0].ln1_b, p.dy, R, d, s));
+  WSEG_TRY(launch_layernorm(gdt, (const float*)p.dx, m->dec[0].ln1_g, m->dec[0].ln1_b, p.dy, R, d, s));
   for (int l = 0; l < c.dec_layers; ++l) {
     const DecLayer& L = m->dec[l];
     {   // q|k|v projection: partial sums only when possible; the attention kernel finishes the reduction
+      const void* a_op = p.dy;
       GemmArgs g;
-      g.A = p.dy; g.lda = d; g.W = L.qkv_w; g.ldw = d; g.M = R; g.N = 3 * d; g.K = d;
+      g.A = a_op; g.lda = d; g.W = L.qkv_w; g.ldw = d; g.M = R; g.N = 3 * d; g.K = d;
       g.splitk_ws = (float*)p.splitk; g.splitk_ws_bytes = p.splitk_bytes;
       PartialInfo pi; bool ok = false;
-      WSEG_TRY(launch_gemm_partial(dt, g, &pi, &ok, s));
+      WSEG_TRY(launch_gemm_partial(gdt, g, &pi, &ok, s));
       if (ok) {
-        WSEG_TRY(launch_dec_self_attn(dt, st, nullptr, p.sk + l * self_stride, p.sv + l * self_stride, p.dattn, H, d, &pi, L.qkv_b, 0.125f, s));
+        WSEG_TRY(launch_dec_self_attn(gdt, st, nullptr, p.sk + l * self_stride, p.sv + l * self_stride, p.dattn, H, d, &pi, L.qkv_b, 0.125f, s));
       } else {
         e = EpiParams();
         e.bias = L.qkv_b; e.q = p.dq; e.k = p.sk + l * self_stride; e.v = p.sv + l * self_stride;
         e.d_model = d; e.n_heads = H; e.pos_ptr = st.pos; e.pos_div = st.nb; e.kv_pt = st.kv_pt; e.kv_npg = st.npg; e.idle_ptr = st.done; e.scale = 0.125f;
-        WSEG_TRY(gemm(m, EPI_QKV_DEC, p.dy, d, L.qkv_w, d, R, 3 * d, d, e, &p, s));
-        WSEG_TRY(launch_dec_self_attn(dt, st, p.dq, p.sk + l * self_stride, p.sv + l * self_stride, p.dattn, H, d, nullptr, nullptr, 0.125f, s));
+        WSEG_TRY(gemm(m, EPI_QKV_DEC, a_op, d, L.qkv_w, d, R, 3 * d, d, e, &p, s));
+        WSEG_TRY(launch_dec_self_attn(gdt, st, p.dq, p.sk + l * self_stride, p.sv + l * self_stride, p.dattn, H, d, nullptr, nullptr, 0.125f, s));
       }
     }
-    WSEG_TRY(gemm_resid_ln(p.dattn, d, L.o_w, L.o_b, L.ln2_g, L.ln2_b));                    // x += attn Wo ; y = LN2(x)
+    WSEG_TRY(gemm_resid_ln(p.dattn, d, L.o_w, L.o_b, L.ln2_g, L.ln2_b, m->mx));                    // x += attn Wo ; y = LN2(x)
     {   // cross-attention query: same scheme
+      const void* a_op = p.dy;
       GemmArgs g;
-      g.A = p.dy; g.lda = d; g.W = L.cq_w; g.ldw = d; g.M = R; g.N = d; g.K = d;
+      g.A = a_op; g.lda = d; g.W = L.cq_w; g.ldw = d; g.M = R; g.N = d; g.K = d;
       g.splitk_ws = (float*)p.splitk; g.splitk_ws_bytes = p.splitk_bytes;
       PartialInfo pi; bool ok = false;
-      WSEG_TRY(launch_gemm_partial(dt, g, &pi, &ok, s));
+      WSEG_TRY(launch_gemm_partial(gdt, g, &pi, &ok, s));
       if (ok) {
-        WSEG_TRY(launch_dec_cross_attn(dt, st, nullptr, p.ck + l * cross_stride, p.cv + l * cross_stride, p.dattn, H, Tk, d, &pi, L.cq_b, 0.125f, s));
+        WSEG_TRY(launch_dec_cross_attn(gdt, st, nullptr, p.ck + l * cross_stride, p.cv + l * cross_stride, p.dattn, H, Tk, d, &pi, L.cq_b, 0.125f, s));
       } else {
         e = EpiParams();
         e.bias = L.cq_b; e.out = p.dq; e.ldc = d; e.scale = 0.125f;
-        WSEG_TRY(gemm(m, EPI_SCALE, p.dy, d, L.cq_w, d, R, d, d, e, &p, s));
-        WSEG_TRY(launch_dec_cross_attn(dt, st, p.dq, p.ck + l * cross_stride, p.cv + l * cross_stride, p.dattn, H, Tk, d, nullptr, nullptr, 0.125f, s));
+        WSEG_TRY(gemm(m, EPI_SCALE, a_op, d, L.cq_w, d, R, d, d, e, &p, s));
+        WSEG_TRY(launch_dec_cross_attn(gdt, st, p.dq, p.ck + l * cross_stride, p.cv + l * cross_stride, p.dattn, H, Tk, d, nullptr, nullptr, 0.125f, s));
       }
     }
-    WSEG_TRY(gemm_resid_ln(p.dattn, d, L.co_w, L.co_b, L.ln3_g, L.ln3_b));                  // x += cross Wo ; y = LN3(x)
+    WSEG_TRY(gemm_resid_ln(p.dattn, d, L.co_w, L.co_b, L.ln3_g, L.ln3_b, m->mx));                  // x += cross Wo ; y = LN3(x)
     e = EpiParams();
     e.bias = L.fc1_b; e.out = p.dh; e.ldc = ffn;
     WSEG_TRY(gemm(m, EPI_GELU, p.dy, d, L.fc1_w, d, R, ffn, d, e, &p, s));
     const bool last = l + 1 == c.dec_layers;                                                 // x += fc2 ; y = next LN1 / final LN
     WSEG_TRY(gemm_resid_ln(p.dh, ffn, L.fc2_w, L.fc2_b, last ? m->dec_ln_g : m->dec[l + 1].ln1_g,
-                           last ? m->dec_ln_b : m->dec[l + 1].ln1_b));
+                           last ? m->dec_ln_b : m->dec[l + 1].ln1_b, dh_mx));
   }
   if (want_logits) {
     e = EpiParams();
@@ -330,7 +374,9 @@ extern "C" int wseg_model_create(const wseg_model_config* cfg, wseg_model** out)
   // bytes per element of weights, parameters and activations: 2 in the 16-bit modes; 4 in f32 AND in the split-precision
   // modes, whose tensors are either fp32 or hi | lo pairs of 16-bit words
   m->es = (cfg->dtype == WSEG_BF16 || cfg->dtype == WSEG_F16) ? 2 : 4;
-  m->x3 = cfg->dtype == WSEG_BF16X3 || cfg->dtype == WSEG_F16X3;
+  m->x3 = cfg->dtype == WSEG_BF16X3 || cfg->dtype == WSEG_F16X3 || cfg->dtype == WSEG_F16M6;
+  m->mx = cfg->dtype == WSEG_F16M6;
+  m->sdt = storage_dtype(cfg->dtype);
   m->ckv_es = m->es;
   m->kp1 = (int)align_up((size_t)3 * cfg->n_mels, 64);
   m->vp = (int)align_up((size_t)cfg->vocab, 128);
@@ -344,6 +390,7 @@ extern "C" int wseg_model_create(const wseg_model_config* cfg, wseg_model** out)
   add_slot(m, "enc.ln.g", &m->enc_ln_g, d);
   add_slot(m, "enc.ln.b", &m->enc_ln_b, d);
   add_slot(m, "dec.tok", &m->dec_tok, (size_t)m->vp * d);
+  if (m->mx) add_slot(m, "dec.tok.f32", &m->dec_tok_f32, (size_t)m->vp * d);
   add_slot(m, "dec.pos", &m->dec_pos, (size_t)cfg->dec_positions * d);
   add_slot(m, "dec.ln.g", &m->dec_ln_g, d);
   add_slot(m, "dec.ln.b", &m->dec_ln_b, d);
@@ -442,7 +489,7 @@ extern "C" int wseg_encode(wseg_model* m, const float* feats, int32_t n_windows,
     const int n = std::min(ENC_CHUNK, n_windows - w0);
     WSEG_TRY(run_encoder(m, feats + (size_t)w0 * feat_stride, n, p, p.enc_out, s));
     const size_t rows = (size_t)n * m->cfg.enc_positions, row0 = (size_t)w0 * m->cfg.enc_positions;
-    if (m->x3) WSEG_TRY(launch_operand_to_f32(m->cfg.dtype, p.enc_out, (float*)enc_out + row0 * m->cfg.d_model, rows, m->cfg.d_model, s));
+    if (m->x3) WSEG_TRY(launch_operand_to_f32(m->sdt, p.enc_out, (float*)enc_out + row0 * m->cfg.d_model, rows, m->cfg.d_model, s));
     else WSEG_HIP_CHECK(hipMemcpyAsync((char*)enc_out + row0 * m->cfg.d_model * m->es, p.enc_out, rows * m->cfg.d_model * m->es, hipMemcpyDeviceToDevice, s));
   }
   return WSEG_OK;
@@ -561,10 +608,15 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
       WSEG_TRY(timing_event(ln, s, &e0));
       const char* enc_rows = p.enc_out;
       if (gp->encoder_output && m->x3)      // handed over as fp32: re-split into operand rows for the cross-K/V GEMMs
-        WSEG_TRY(launch_f32_to_operand(c.dtype, (const float*)gp->encoder_output + (size_t)wc * Tk * d, p.enc_out, (size_t)nc * Tk, d, s));
+        WSEG_TRY(launch_f32_to_operand(m->sdt, (const float*)gp->encoder_output + (size_t)wc * Tk * d, p.enc_out, (size_t)nc * Tk, d, s));
       else if (gp->encoder_output) enc_rows = (const char*)gp->encoder_output + (size_t)wc * Tk * d * m->es;
       else WSEG_TRY(run_encoder(m, feats + (size_t)wc * feat_stride, nc, p, p.enc_out, s));
       WSEG_TRY(timing_event(ln, s, &e1));
+      if (m->mx) {      // M6 rows of the encoder output ONCE for the cross-K/V GEMMs of all decoder layers
+        const void* er = enc_rows;
+        WSEG_TRY(to_mx(m, er, nc * Tk, d, p.mxe, s));
+        enc_rows = (const char*)er;
+      }
       for (int l = 0; l < c.dec_layers; ++l) {     // cross-attention K/V of every decoder layer, once per window (shared by its beams)
         EpiParams e;
         e.bias = m->dec[l].ckv_b; e.k = q.ck + l * cross_stride; e.v = q.cv + l * cross_stride;
@@ -646,7 +698,7 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
 
   // One decode step of every active slot: decoder layers, LM head, candidates, bookkeeping (which also advances the slot).
   auto enqueue_step = [&](bool snapshot_logits, hipStream_t qs) -> int {
-    WSEG_TRY(run_decoder_step(m, q, true, qs));
+    WSEG_TRY(run_decoder_step(m, q, p.mxa, true, qs));
     if (snapshot_logits)
       WSEG_HIP_CHECK(hipMemcpyAsync(q.first_logits, q.logits, (size_t)S * nb * m->vp * 4, hipMemcpyDeviceToDevice, qs));
     WSEG_TRY(launch_row_topk(st, (const float*)q.logits, (float*)q.tk_val, (int*)q.tk_idx, (float*)q.tk_stat, qs));

@@ -17,9 +17,14 @@ from . import _lib
 # name -> (wseg_dtype, torch dtype of parameters and activations).  "bf16x3" / "f16x3" are the split-precision modes
 # (include/wseg.h): fp32 everywhere except that GEMM operands travel as hi + lo 16-bit pairs and are multiplied with three
 # MFMAs per product; their weight MATRICES are attached pre-split (split_operand), everything else is float32.
+# "f16m6" is the MIXED split-precision mode: f16x3 everywhere outside the GEMMs; a GEMM takes hi*hi on the IEEE-half matrix cores and the
+# two cross terms on the block-scaled MX matrix cores (fp6 operands, 4x the 16-bit rate): its weight matrices are built as f16x3
+# operand rows and then converted ON THE DEVICE to "M6 rows" (wseg_convert_operand; same byte size), the token embedding is
+# attached a second time as plain fp32 ("dec.tok.f32") for the embedding lookup.
 DTYPES = {"f32": (0, torch.float32), "bf16": (1, torch.bfloat16), "f16": (2, torch.float16),
-          "bf16x3": (3, torch.float32), "f16x3": (4, torch.float32)}
-SPLIT_BASE = {"bf16x3": torch.bfloat16, "f16x3": torch.float16}
+          "bf16x3": (3, torch.float32), "f16x3": (4, torch.float32), "f16m6": (5, torch.float32)}
+SPLIT_BASE = {"bf16x3": torch.bfloat16, "f16x3": torch.float16, "f16m6": torch.float16}
+MX_MODES = ("f16m6",)
 
 
 def is_gemm_weight(name):
@@ -47,6 +52,29 @@ def unsplit_operand(t, base):
     n, k2 = t.shape
     v = t.view(base).view(n, k2 // 64, 2, 32).float()
     return (v[:, :, 0] + v[:, :, 1]).reshape(n, k2 // 2)
+
+
+def unsplit_m6(t, weight_order=False):
+    """M6 rows (csrc/wseg_common.h; int16 [N, 2K] as produced by wseg_convert_operand or written by a kernel) -> fp32 [N, K]:
+    hi half + the fp6 (e2m3, block-scaled) image of the lo half — what a GEMM of the mixed mode sees of the operand, to ~2^-15
+    relative.  Test helper."""
+    n, k2 = t.shape
+    k = k2 // 2
+    raw = t.contiguous().view(torch.uint8).view(n, k // 64, 256)
+    hi = raw[:, :, :128].contiguous().view(torch.float16).float()                      # [n, k/64, 64]
+    mx = raw[:, :, 128:].to(torch.int64)                                                # [n, k/64, 128] bytes
+    lo = torch.zeros(n, k // 64, 64, device=t.device)
+    for chunk in range(2):
+        g = (2 if weight_order else 0) + chunk
+        cb = mx[:, :, 32 * g:32 * g + 24]                                               # 24 code bytes = 32 codes, little-endian 6-bit
+        word = sum(cb[:, :, i::3] << (8 * i) for i in range(3))                          # 8 x 24-bit words holding 4 codes each
+        codes = torch.stack([(word >> (6 * j)) & 63 for j in range(4)], dim=-1).reshape(n, k // 64, 32)
+        sign = 1.0 - 2.0 * ((codes >> 5) & 1).float()
+        e, mnt = (codes >> 3) & 3, (codes & 7).float()
+        val = torch.where(e == 0, mnt / 8.0, (1.0 + mnt / 8.0) * torch.exp2((e - 1).float()))
+        scale = torch.exp2(mx[:, :, 32 * g + 24].float() - 127.0).unsqueeze(-1)
+        lo[:, :, 32 * chunk:32 * chunk + 32] = sign * val * scale
+    return (hi + lo).reshape(n, k)
 
 
 def to_engine_layout(weights, dtype):
@@ -226,16 +254,43 @@ class Engine:
         handle = C.c_void_p()
         _lib.check(self.lib.wseg_model_create(C.byref(cfg), C.byref(handle)))
         self.handle = handle
-        self.weights = weights          # keep the device tensors alive
         self.split_base = SPLIT_BASE.get(dtype)
+        self.mx = dtype in MX_MODES
+        self._x3_host = None
+        if self.mx:
+            weights = self._to_m6(weights)
+        self.weights = weights          # keep the device tensors alive
         for name, t in weights.items():
             want = torch.int16 if (self.split_base is not None and is_gemm_weight(name)) else self.torch_dtype
+            if name == "dec.tok.f32":
+                want = torch.float32
             if t.device != self.device or t.dtype != want or not t.is_contiguous():
                 raise ValueError(f"weight {name}: wrong device/dtype/layout")
             _lib.check(self.lib.wseg_model_set_tensor(handle, name.encode(), t.data_ptr(), t.numel() * t.element_size()))
         _lib.check(self.lib.wseg_model_ready(handle))
         self._ws = None
         self._small_calls = 0
+
+    def _to_m6(self, weights):
+        """f16x3 operand rows of the GEMM weight matrices -> M6 rows (device-side conversion, weight order); the hi | lo rows move
+        to host memory (weights_f32 / sibling rebuild the exact values from them); + the fp32 embedding table."""
+        out, self._x3_host = {}, {}
+        with torch.cuda.device(self.device):
+            for name, t in weights.items():
+                if not is_gemm_weight(name):
+                    out[name] = t
+                    continue
+                if t.dtype != torch.int16 or t.device != self.device or not t.is_contiguous():
+                    raise ValueError(f"weight {name}: wrong device/dtype/layout")
+                n, k2 = t.shape
+                dst = torch.empty_like(t)
+                _lib.check(self.lib.wseg_convert_operand(t.data_ptr(), dst.data_ptr(), n, k2 // 2, 1, _lib.stream_ptr()))
+                out[name] = dst
+                if name == "dec.tok":
+                    out["dec.tok.f32"] = unsplit_operand(t, self.split_base).contiguous()
+                self._x3_host[name] = t.cpu()
+            torch.cuda.synchronize(self.device)
+        return out
 
     @classmethod
     def from_state_dict(cls, sd, hf_config, device="cuda:0", dtype="bf16"):
@@ -265,6 +320,10 @@ class Engine:
         split-precision modes are read back as hi + lo)."""
         out = {}
         for k, v in self.weights.items():
+            if k == "dec.tok.f32":
+                continue
+            if self._x3_host is not None and k in self._x3_host:      # M6 rows are lossy in the lo part: the hi | lo rows are kept on the host
+                v = self._x3_host[k].to(self.device)
             out[k] = unsplit_operand(v, self.split_base) if v.dtype == torch.int16 else v.float()
         return out
 

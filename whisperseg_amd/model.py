@@ -25,15 +25,16 @@ from .utils import RATIO_DECODING_TIME_STEP_TO_SPEC_TIME_STEP
 from .windows import shard_bounds, window_table
 
 PROMPT_TOKENS = ["<|startoftranscript|>", "<|en|>", "<|notimestamps|>"]   # reference model.py:656
-# Engine mode when neither the constructor nor $WHISPERSEG_AMD_DTYPE names one: "f16x3", the split-precision mode — the
+# Engine mode when neither the constructor nor $WHISPERSEG_AMD_DTYPE names one: "f16m6", the MIXED split-precision mode — the
 # reference computes in fp32 (model.py:655-666), and this is the fastest mode that meets the north-star tolerance (clusters
 # exact, boundaries within +-1 mel frame) on every recording of the 200-recording parity sweep (profiles/README.md): GEMM operands
-# as hi + lo IEEE-half pairs multiplied with three MFMAs per product, fp32 everywhere else; first-step logits within 4e-4 of the
-# exact mode at 32 + 32 layers.  "bf16x3" is the same with bfloat16 halves (16 instead of 22 operand bits; no fp16 range limit on the GEMM operands — the
-# encoder attention's Q / K / V^T are IEEE-half pairs in both split modes and saturate at +-65 504);
-# "f16" / "bf16" are the plain 16-bit modes (2.2x faster, 95 % / 86 % of the sweep inside the tolerance); "f32" is the
-# exact-parity mode.
-DEFAULT_DTYPE = "f16x3"
+# as hi + lo IEEE-half pairs, hi*hi on the half matrix cores and both cross terms on the block-scaled fp6 MX matrix cores, fp32
+# everywhere else; first-step logits within 3.7e-5 of the logit scale of the exact mode at 32 + 32 layers.  "f16x3" takes all
+# three products on the half matrix cores (3.3e-6 of the scale, ~10 % slower), "bf16x3" the same with bfloat16 halves (1.3e-5; no
+# fp16 range limit on the GEMM operands — the encoder attention's Q / K / V^T are IEEE-half pairs in every split mode and saturate
+# at +-65 504); "f16" / "bf16" are the plain 16-bit modes (2x faster, 96 % / 85 % of the sweep inside the tolerance); "f32" is
+# the exact-parity mode.
+DEFAULT_DTYPE = "f16m6"
 POOL_WINDOWS = 8192      # windows per engine call / per pooled group of files (2.6 GB of log-mel features)
 
 
@@ -386,7 +387,7 @@ class WhisperSegmenter(SegmenterBase):
 class WhisperSegmenterFast(WhisperSegmenter):
     """reference model.py:678-746 is the CTranslate2 backend (float16 on a GPU, model.py:691), which the reference's CLI and
     evaluation try first (scripts/segment.py:34-37, evaluate.py:62-65).  Here it is the same MI355X engine as WhisperSegmenter and
-    — because those call sites make it the DEFAULT path of the CLI — it defaults to the same split-precision mode ("f16x3": rows
+    — because those call sites make it the DEFAULT path of the CLI — it defaults to the same split-precision mode ("f16m6": rows
     identical to the fp32 reference on the whole parity sweep).  `dtype="f16"` (or $WHISPERSEG_AMD_DTYPE=f16) selects what CT2
     computes in: plain IEEE half, 1.9x faster, 96 % of the sweep recordings within +-1 mel frame.  A CTranslate2-converted
     directory (binary `model.bin` + `hf_model/` without HF weights) cannot be read and raises, which makes the try-Fast-then-
