@@ -212,8 +212,8 @@ __device__ __forceinline__ void mx_chunk(const uint32_t (&w)[16], float amax, ui
 // Cooperative store of 8 consecutive logical columns per lane: the FOUR lanes of an aligned quad (lane & 3 = 0..3) must call this
 // together with c = c0, c0 + 8, c0 + 16, c0 + 24 (c0 % 32 == 0) of the SAME row — which is how every 8-column producer of the
 // library is laid out (LayerNorm, the LDS-staged GEMM epilogues, the fused split-K reduction, the decoder attention outputs).
-// Each lane writes its 8 hi halves; the quad shares its 16 + 16 packed words by DPP quad broadcasts, every lane converts the
-// block (identical results), and lane k of the quad writes piece k of {lo chunk first / second half, hi chunk first / second half}.
+// Each lane writes its 8 hi halves; the quad shares its 16 + 16 packed words by DPP quad broadcasts, and lane k of the quad converts
+// and writes piece k of {lo chunk first / second half, hi chunk first / second half}.
 __device__ __forceinline__ void op_st8_m6(void* base, size_t row, int ld, int c, const float v[8]) {
   uint4 hi, lo;
   split8<f16_t>(v, hi, lo);
@@ -231,21 +231,25 @@ __device__ __forceinline__ void op_st8_m6(void* base, size_t row, int ld, int c,
   };
   ah = quad_max(ah);
   al = quad_max(al);
+  // lanes 0, 1 of the quad store the two halves of the lo chunk, lanes 2, 3 those of the hi6 chunk: every lane gathers the 16 packed
+  // words of ITS kind (quad broadcast k delivers lane k's word to all four lanes; a lane keeps the lo or the hi copy) and runs ONE
+  // conversion
   const uint32_t hw[4] = {hi.x, hi.y, hi.z, hi.w}, lw[4] = {lo.x, lo.y, lo.z, lo.w};
-  uint32_t gh[16], gl[16];
+  const int piece = (c >> 3) & 3;      // == lane & 3
+  const bool want_hi = piece >= 2;
+  uint32_t gw[16];
 #define WSEG_QUAD_BCAST(K)                                                                                               \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                        \
-    gh[4 * (K) + i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hw[i], (K) * 0x55, 0xF, 0xF, true); /* quad_perm [K,K,K,K] */ \
-    gl[4 * (K) + i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lw[i], (K) * 0x55, 0xF, 0xF, true);                  \
+    const uint32_t bh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hw[i], (K) * 0x55, 0xF, 0xF, true); /* quad_perm [K,K,K,K] */ \
+    const uint32_t bl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lw[i], (K) * 0x55, 0xF, 0xF, true);                \
+    gw[4 * (K) + i] = want_hi ? bh : bl;                                                                                 \
   }
   WSEG_QUAD_BCAST(0) WSEG_QUAD_BCAST(1) WSEG_QUAD_BCAST(2) WSEG_QUAD_BCAST(3)
 #undef WSEG_QUAD_BCAST
-  uint4 l0, l1, h0, h1;
-  mx_chunk(gl, al, l0, l1);
-  mx_chunk(gh, ah, h0, h1);
-  const int chunk = (c >> 5) & 1, piece = (c >> 3) & 3;      // piece == lane & 3
-  const uint4 mine = piece == 0 ? l0 : (piece == 1 ? l1 : (piece == 2 ? h0 : h1));
-  *(uint4*)(blk + 128 + 32 * ((piece >> 1) * 2 + chunk) + 16 * (piece & 1)) = mine;
+  uint4 c0, c1;
+  mx_chunk(gw, want_hi ? ah : al, c0, c1);      // ONE conversion per lane: the chunk this lane stores half of
+  const int chunk = (c >> 5) & 1;
+  *(uint4*)(blk + 128 + 32 * ((piece >> 1) * 2 + chunk) + 16 * (piece & 1)) = (piece & 1) ? c1 : c0;
 }
 
 template <typename T> __device__ __forceinline__ void op_st8(void* base, size_t row, int ld, int c, const float v[8]) {

@@ -1587,6 +1587,8 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
     if (big256 && g.N % 256 == 0 && nt256 >= 192 && !ragged256) {
       const int ntm = cdiv(g.M, 256), ntiles = ntm * (g.N / 256);
       static const bool pingpong = getenv("WSEG_GEMM_NO_PP") == nullptr;   // ping-pong kernel by default (tuning knob)
+      // (Measured and dropped, r04: the generic kernel as 4 waves x 128x128 wave tiles, one wave per SIMD — a third fewer fragment
+      // reads per MFMA, but with nothing to hide its per-K-tile barriers behind: 640 against 1 080 TFLOP/s on the encoder shapes.)
       if (pingpong && g.K >= 128) {
         int grid = ntiles < n_cu ? ntiles : n_cu;
         grid &= ~7;
