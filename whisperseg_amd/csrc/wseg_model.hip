@@ -103,7 +103,7 @@ void add_slot(wseg_model* m, const std::string& name, const void** field, size_t
 // The encoder (and the cross-K/V GEMMs behind it) runs over at most ENC_CHUNK windows at a time: its activations (FFN hidden:
 // 10 MB per window in the 16-bit modes, 20 MB in the split modes) then stop growing with the slot count, and a pass of 256
 // windows (128 000 rows: the r01 / r02 headline workload) already fills the chip for tens of rounds.
-constexpr int ENC_CHUNK = 256;
+static const int ENC_CHUNK = getenv("WSEG_ENC_CHUNK") ? std::max(1, atoi(getenv("WSEG_ENC_CHUNK"))) : 256;      // (env: measurement knob)
 // Default self-K/V pool of wseg_workspace_bytes: positions per slot, or max_length if that is smaller.
 constexpr int KV_DEFAULT_POSITIONS = 64;
 
