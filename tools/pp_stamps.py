@@ -10,26 +10,40 @@ from whisperseg_amd import _lib
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="128000,1280,1280,2")
+ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16x3", "bf16x3", "f16m6"], help="f16m6: K tiles alternate hi (even) / MX (odd)")
 ap.add_argument("--iters", type=int, default=40, help="launches before the stamps are read (the clock settles within a few ms of load)")
 a = ap.parse_args()
 m, n, k, epi = (int(v) for v in a.shape.split(","))
 lib = _lib.load(require_device=True)
 raw = ctypes.CDLL(_lib.LIB_PATH)
-A = (torch.rand(m, k, device="cuda") * 2 - 1).to(torch.bfloat16)
-W = (torch.rand(n, k, device="cuda") * 2 - 1).to(torch.bfloat16)
-bias = torch.rand(n, device="cuda").to(torch.bfloat16)
-od = torch.float32 if epi == 2 else torch.bfloat16
+from whisperseg_amd.engine import DTYPES, SPLIT_BASE, split_operand
+DT = DTYPES[a.dtype][0]
+if a.dtype == "bf16":
+    A = (torch.rand(m, k, device="cuda") * 2 - 1).to(torch.bfloat16)
+    W = (torch.rand(n, k, device="cuda") * 2 - 1).to(torch.bfloat16)
+    pd = torch.bfloat16
+else:
+    A = split_operand(torch.rand(m, k, device="cuda") * 2 - 1, SPLIT_BASE[a.dtype])
+    W = split_operand((torch.rand(n, k, device="cuda") * 2 - 1) * k ** -0.5, SPLIT_BASE[a.dtype])
+    if a.dtype == "f16m6":
+        Am, Wm = torch.empty_like(A), torch.empty_like(W)
+        _lib.check(lib.wseg_convert_operand(A.data_ptr(), Am.data_ptr(), m, k, 0, _lib.stream_ptr()))
+        _lib.check(lib.wseg_convert_operand(W.data_ptr(), Wm.data_ptr(), n, k, 1, _lib.stream_ptr()))
+        A, W = Am, Wm
+    pd = torch.float32
+bias = torch.rand(n, device="cuda").to(pd)
+od = torch.float32 if epi == 2 else pd
 res = torch.rand(m, n, device="cuda").to(od)
 out = torch.empty(m, n, device="cuda", dtype=od)
 ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
 for it in range(a.iters):
-    _lib.check(lib.wseg_debug_gemm(1, epi, m, n, k, A.data_ptr(), W.data_ptr(), bias.data_ptr(), res.data_ptr(), out.data_ptr(), ws.data_ptr(),
+    _lib.check(lib.wseg_debug_gemm(DT, epi, m, n, k, A.data_ptr(), W.data_ptr(), bias.data_ptr(), res.data_ptr(), out.data_ptr(), ws.data_ptr(),
                                    ws.numel(), _lib.stream_ptr()))
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 132)()
 raw.wseg_debug_pp_stamps(buf)
 S = [[[[buf[((g * 4 + t) * 4 + p) * 4 + i] for i in range(4)] for p in range(4)] for t in range(4)] for g in range(2)]
-print(f"shape M={m} N={n} K={k} epi={epi}")
+print(f"shape M={m} N={n} K={k} epi={epi} {a.dtype}")
 for g in range(2):
     for t in range(1, 3):
         row = []

@@ -1,6 +1,6 @@
 """Build libwseg.so (hand-written HIP for gfx950) in-tree with hipcc.
 
-    python -m whisperseg_amd.build [--force] [--stamps N]
+    python -m whisperseg_amd.build [--force] [--stamps N] [--variant TAG -DNAME=V ...]
 
 The shared library lands in whisperseg_amd/lib/libwseg.so; it is git-ignored but travels with the
 gpurun snapshot.  hipcc cross-compiles without a GPU.
@@ -8,6 +8,8 @@ gpurun snapshot.  hipcc cross-compiles without a GPU.
 --stamps N builds a SECOND library, lib/libwseg_stamps<N>.so, with -DWSEG_STAMPS=N: decode kernel N (1 self-attention,
 2 packed cross-attention, 3 24-bit cross-attention) records s_memrealtime stamps at its phase boundaries (tools/stamps.py
 loads it through WSEG_LIB).  The product library never carries them.
+--variant TAG -D... builds lib/libwseg_<TAG>.so with the extra defines: A/B timing of an experiment knob against the product
+library on one box (WSEG_LIB=whisperseg_amd/lib/libwseg_<TAG>.so python tools/gemm_bench.py ...).
 """
 import os
 import subprocess
@@ -31,11 +33,15 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force=False, verbose=True, stamps=0):
+def build(force=False, verbose=True, stamps=0, variant="", defines=()):
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(HERE, "build" if not stamps else "build/stamps%d" % stamps)
     lib = LIB if not stamps else os.path.join(LIBDIR, "libwseg_stamps%d.so" % stamps)
     flags = FLAGS + (["-DWSEG_STAMPS=%d" % stamps] if stamps else [])
+    if variant:
+        objdir = os.path.join(HERE, "build", "variant_" + variant)
+        lib = os.path.join(LIBDIR, "libwseg_%s.so" % variant)
+        flags = flags + list(defines)
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "wseg.h"))
@@ -67,4 +73,5 @@ def build(force=False, verbose=True, stamps=0):
 
 if __name__ == "__main__":
     n = int(sys.argv[sys.argv.index("--stamps") + 1]) if "--stamps" in sys.argv else 0
-    print(build(force="--force" in sys.argv, stamps=n))
+    v = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
+    print(build(force="--force" in sys.argv, stamps=n, variant=v, defines=[x for x in sys.argv if x.startswith("-D")]))

@@ -1055,13 +1055,16 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
       const unsigned aT = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)(cur + wr * HTILE);      // this row group's 128-row A half-tile
       const unsigned bT = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)(cur + (2 + (wc >> 1)) * HTILE + (wc & 1) * 64 * BK);   // this wave's 64 W rows
       MxFrag7 bm[NI], am[4];
+      WSEG_PP_STAMP(0, 0);
       bm[0] = ld_mx_frag7<0>(bT, mxo); bm[1] = ld_mx_frag7<2048>(bT, mxo); bm[2] = ld_mx_frag7<4096>(bT, mxo); bm[3] = ld_mx_frag7<6144>(bT, mxo);
       am[0] = ld_mx_frag7<0>(aT, mxo); am[1] = ld_mx_frag7<2048>(aT, mxo); am[2] = ld_mx_frag7<4096>(aT, mxo); am[3] = ld_mx_frag7<6144>(aT, mxo);
       if (first && g + 1 < KT) { issue_b(0); issue_b(1); }
       if (g + 1 < KT) { issue_a(0); issue_a(1); }
       __builtin_amdgcn_sched_barrier(0);
+      WSEG_PP_STAMP(0, 1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      WSEG_PP_STAMP(0, 2);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1070,13 +1073,17 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
         for (int j = 0; j < 4; ++j) mfma_mx6_asm(acc[i][j], bm[i], am[j]);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
+      WSEG_PP_STAMP(0, 3);
       __builtin_amdgcn_s_barrier();
+      WSEG_PP_STAMP(1, 0);
       am[0] = ld_mx_frag7<8192>(aT, mxo); am[1] = ld_mx_frag7<10240>(aT, mxo); am[2] = ld_mx_frag7<12288>(aT, mxo); am[3] = ld_mx_frag7<14336>(aT, mxo);
       if (!final && g + 2 < KT) { issue_b(0); issue_b(1); wait_vmcnt<4>(); }
       else wait_vmcnt<0>();
       __builtin_amdgcn_sched_barrier(0);
+      WSEG_PP_STAMP(1, 1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      WSEG_PP_STAMP(1, 2);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1085,6 +1092,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
         for (int j = 0; j < 4; ++j) mfma_mx6_asm(acc[i][4 + j], bm[i], am[j]);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
+      WSEG_PP_STAMP(1, 3);
       if (!final) __builtin_amdgcn_s_barrier();
   };
   if constexpr (MXM) {
