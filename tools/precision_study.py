@@ -16,6 +16,8 @@ POLICY = comma-separated  class=fmt  pairs, classes:
     egemm / dgemm / ckvg / lm   per-STAGE override of `gemm`: encoder Linears + convs / decoder-layer Linears / the cross-K|V
            projections / the LM head.  Extra formats for the GEMM classes: f16x2w | bf16x2w (weights hi + lo, activations rounded
            once: 2 MFMAs per product) and f16x2a | bf16x2a (activations hi + lo, weights rounded once)
+    e.qkv / e.o / e.fc1 / e.fc2 / e.conv / d.qkv / d.o / d.cq / d.co / d.fc1 / d.fc2   per-OPERATOR override inside a stage
+           (round 4: which GEMMs of the encoder / decoder layers carry the need for split operands?)
     all    shorthand: every class
 e.g.  "all=f16"   "gemm=bf16x3"   "gemm=bf16x3,ckv=f16"   "gemm=bf16x3,eattn=f16,ckv=f16,skv=f16"
 The special policy "margins" dumps the histogram of top-1 / top-2 logit margins of the fp32 oracle over the sweep.
@@ -95,8 +97,12 @@ class Policy:
     def __init__(self, text):
         self.fmt = dict(gemm="f32", eattn="f32", ck="f32", cv="f32", skv="f32", dq="f32")
         stage = {}
+        self.sub = {}
         for part in filter(None, text.split(",")):
             k, v = part.split("=")
+            if k[:2] in ("e.", "d."):
+                self.sub[k] = v
+                continue
             if k in STAGES:
                 stage[k] = v
                 continue
@@ -116,8 +122,17 @@ class Policy:
             return "lm"
         return "dgemm"
 
+    @staticmethod
+    def sub_of(prefix):
+        side = "e." if prefix.startswith("model.encoder.") else "d."
+        for suffix, name in (("encoder_attn.q_proj", "cq"), ("encoder_attn.out_proj", "co"), ("self_attn.out_proj", "o"),
+                             ("self_attn.q_proj", "qkv"), ("self_attn.k_proj", "qkv"), ("self_attn.v_proj", "qkv"), ("fc1", "fc1"), ("fc2", "fc2")):
+            if prefix.endswith(suffix):
+                return side + name
+        return ""
+
     def linear(self, x, sd, prefix, bias=True):
-        fmt = self.fmt[self.stage_of(prefix)]
+        fmt = self.sub.get(self.sub_of(prefix)) or self.fmt[self.stage_of(prefix)]
         w = sd[prefix + ".weight"]
         b = sd[prefix + ".bias"] if bias else None
         if fmt == "f32":
@@ -172,7 +187,7 @@ class Policy:
         return F.linear(rnd(x, fmt), rnd(w, fmt), b)
 
     def conv(self, x, w, b, **kw):
-        fmt = self.fmt["egemm"]
+        fmt = self.sub.get("e.conv") or self.fmt["egemm"]
         if fmt == "f32":
             return F.conv1d(x, w, b, **kw)
         if fmt == "f16m8u":

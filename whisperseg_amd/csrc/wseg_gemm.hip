@@ -828,8 +828,10 @@ template <typename T, int EPI, bool STAGED_RESID = false, bool SPLITK = false>
 __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::H* __restrict__ A, int lda, const typename IO<T>::H* __restrict__ W,
                                                           int ldw, int M, int N, int K, EpiParams ep, int ntm, int GM, int S) {
   typedef typename IO<T>::H HT;
-  constexpr bool MXM = IsMx<T>::v;        // M6 rows: odd K tiles are MX tiles (16 scaled MFMAs per phase instead of 32 plain ones)
-  constexpr bool X3M = IO<T>::split && !MXM;      // hi | lo K tiles: 24 instead of 16 MFMAs per phase, (W hi, A hi) (W hi, A lo) (W lo, A hi)
+  constexpr bool HIONLY = HiOnly<T>::v;   // M6H: M6 rows, hi tiles only — the K-tile stream steps over the MX tiles (KS = 2)
+  constexpr int KS = HIONLY ? 2 : 1;
+  constexpr bool MXM = IsMx<T>::v && !HIONLY;      // M6 rows: odd K tiles are MX tiles (16 scaled MFMAs per phase instead of 32 plain ones)
+  constexpr bool X3M = IO<T>::split && !IsMx<T>::v;      // hi | lo K tiles: 24 instead of 16 MFMAs per phase, (W hi, A hi) (W hi, A lo) (W lo, A hi)
   // Residual epilogue without LDS and without barriers (EPI_RESID, opt-in: WSEG_PP_DIRECT_RESID=1; the LDS-staged one is the
   // default): the accumulators of a tile START as its fp32 residual rows (loaded in the MFMA accumulator layout: a lane owns 4
   // consecutive columns of a row, 16 bytes), the MFMAs add A W^T on top, and the epilogue is bias + 32 direct 16-byte stores
@@ -852,7 +854,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   GM &= 0xff;
 #endif
   const int fr = lane & 15, fg = lane >> 4;
-  const int ntn = N / BN, ntmn = ntm * ntn, ntiles = SPLITK ? ntmn * S : ntmn, nk = K / BK;
+  const int ntn = N / BN, ntmn = ntm * ntn, ntiles = SPLITK ? ntmn * S : ntmn, nk = K / (BK * KS);
   const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3, bpx = gridDim.x >> 3;
   const int q = ntiles >> 3, r = ntiles & 7;
   const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
@@ -901,7 +903,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   int ca_k0 = k_first(tile_z(start + loc)), ca_nk = SPLITK ? k_first(tile_z(start + loc) + 1) - ca_k0 : nk, cb_k0 = ca_k0, cb_nk = ca_nk;
   auto issue_a = [&](int half) {                       // half-tile A<half> of K tile ca_g; the cursor advances after A1
     HT* dst = smem + (ca_g & 1) * BUF + half * HTILE + wave * 512;
-    const char* sbase = (const char*)(A + (ca_row + (size_t)(half * 128) * lda + ((SPLITK ? ca_k0 : 0) + ca_kt) * BK));      // uniform
+    const char* sbase = (const char*)(A + (ca_row + (size_t)(half * 128) * lda + ((SPLITK ? ca_k0 : 0) + ca_kt) * (BK * KS)));      // uniform
     const unsigned al = lane_off(lda, a_lane);
     WSEG_GLDS16(sbase + (size_t)al, dst);
     WSEG_GLDS16(sbase + (size_t)64 * lda * sizeof(HT) + (size_t)al, dst + 4096);
@@ -920,7 +922,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   };
   auto issue_b = [&](int half) {
     HT* dst = smem + (cb_g & 1) * BUF + (2 + half) * HTILE + wave * 512;
-    const char* sbase = (const char*)(W + (cb_row + (size_t)(half * 128) * ldw + ((SPLITK ? cb_k0 : 0) + cb_kt) * BK));      // uniform
+    const char* sbase = (const char*)(W + (cb_row + (size_t)(half * 128) * ldw + ((SPLITK ? cb_k0 : 0) + cb_kt) * (BK * KS)));      // uniform
     const unsigned wl = lane_off(ldw, w_lane);
     WSEG_GLDS16(sbase + (size_t)wl, dst);
     WSEG_GLDS16(sbase + (size_t)64 * ldw * sizeof(HT) + (size_t)wl, dst + 4096);
@@ -1603,6 +1605,17 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
         // A/B knob: register-resident residual epilogue (measured slower, profiles/README.md r03: all CUs reach their epilogue
         // together and its 1.3 GB of fp32 residual traffic is an HBM-bound burst either way; staged 540 / 1513 us, direct 590 / 1525 us)
         static const bool resid_staged = getenv("WSEG_PP_DIRECT_RESID") == nullptr;
+        // WSEG_F16M6, hi-only permission: the M6H instantiation (encoder q|k|v and o-proj: the EPIs it is built for)
+        if constexpr (std::is_same<T, M6>::value && (EPI == EPI_QKV_ENC || EPI == EPI_RESID)) {
+          static const bool no_hi = getenv("WSEG_NO_HI_ONLY") != nullptr;      // A/B knob
+          if (g0.hi_only && !no_hi && g.K >= 256) {
+            hipLaunchKernelGGL((gemm_h16_pp_kernel<M6H, EPI, EPI == EPI_RESID>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K,
+                               g.ep, ntm, group_m, 1);
+            if (e1) (void)hipEventRecord(e1, s);
+            WSEG_LAUNCH_CHECK();
+            return WSEG_OK;
+          }
+        }
         if (EPI == EPI_RESID && resid_staged)
           hipLaunchKernelGGL((gemm_h16_pp_kernel<T, EPI, true>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K, g.ep, ntm,
                              group_m, 1);
@@ -1831,8 +1844,11 @@ extern "C" int wseg_debug_gemm(int32_t dtype, int32_t epi, int32_t M, int32_t N,
                                const void* bias, const void* resid, void* out, void* splitk_ws, size_t splitk_ws_bytes,
                                void* stream) {
   using namespace wseg;
+  const bool hi_only = (epi & 0x100) != 0;
+  epi &= 0xff;
   if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || epi < 0 || epi > 2) { set_error("wseg_debug_gemm: bad argument"); return WSEG_ERR_INVALID; }
   GemmArgs g;
+  g.hi_only = hi_only;
   g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K;
   g.ep.bias = bias; g.ep.out = out; g.ep.ldc = N; g.ep.resid = resid;
   g.splitk_ws = (float*)splitk_ws; g.splitk_ws_bytes = splitk_ws_bytes;

@@ -65,6 +65,8 @@ struct GemmArgs {
   EpiParams ep;
   float* splitk_ws = nullptr;     // fp32 [splits][M_pad][N] when the launcher decides to split K
   size_t splitk_ws_bytes = 0;
+  bool hi_only = false;           // WSEG_F16M6, experiment (off in the model): the 256x256 kernel multiplies the hi
+                                  // halves only (M6H); kernels without that variant multiply the full M6 rows
 };
 
 // dtype: WSEG_F32 (exact kernels), WSEG_BF16 / WSEG_F16 (MFMA) or WSEG_BF16X3 / WSEG_F16X3 (split-precision MFMA: A and W

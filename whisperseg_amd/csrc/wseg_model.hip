@@ -75,6 +75,7 @@ struct wseg_model {
   size_t es;                 // element size of the model dtype
   bool x3 = false;           // split-precision mode (GEMM operands are hi | lo rows, everything else fp32)
   bool mx = false;           // WSEG_F16M6: GEMM operands are M6 rows (weights attached converted; activations converted before each GEMM)
+  bool attn_hi = false;      // WSEG_F16M6 experiment (WSEG_ATTN_HI=1): the encoder's attention projections (q|k|v, o) multiply the hi halves only
   int sdt = 0;               // dtype of every non-GEMM kernel (WSEG_F16M6 -> WSEG_F16X3)
   const void* dec_tok_f32 = nullptr;      // WSEG_F16M6: fp32 copy of the token embedding for the embedding lookup
   size_t ckv_es = 0;         // bytes per cross-attention K / V element: es, or 3 (24-bit planes) in the split modes with <= 4 beams
@@ -236,9 +237,10 @@ int to_mx(const wseg_model* m, const void*& A, int M, int K, char* scratch, hipS
 
 // mxa: scratch for the M6 image of A (WSEG_F16M6; null when A already is M6 rows)
 int gemm(const wseg_model* m, EpiKind epi, const void* A, int lda, const void* Wt, int ldw, int M, int N, int K,
-         const EpiParams& ep, const DecPlan* p, hipStream_t s, char* mxa = nullptr) {
+         const EpiParams& ep, const DecPlan* p, hipStream_t s, char* mxa = nullptr, bool hi_only = false) {
   if (m->mx && mxa) { const int st = to_mx(m, A, M, K, mxa, s); if (st != WSEG_OK) return st; }
   GemmArgs g;
+  g.hi_only = hi_only;
   g.A = A; g.lda = lda; g.W = Wt; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.ep = ep;
   if (p) { g.splitk_ws = (float*)p->splitk; g.splitk_ws_bytes = p->splitk_bytes; }
   return launch_gemm(m->cfg.dtype, epi, g, s);
@@ -271,11 +273,11 @@ int run_encoder(wseg_model* m, const float* feats, int W, Plan& p, void* enc_out
     e = EpiParams();
     e.bias = L.qkv_b; e.q = p.q; e.k = p.k; e.v = p.vt; e.d_model = d; e.t_len = T; e.t_pad = Tp; e.n_heads = H; e.scale = 0.125f;
     if (m->x3) { e.qkv_mode = x3_enc_attention_mode(); e.qkv_plane = (size_t)W * H * Tp * 64; }
-    WSEG_TRY(gemm(m, EPI_QKV_ENC, p.y, d, L.qkv_w, d, M, 3 * d, d, e, nullptr, s));
+    WSEG_TRY(gemm(m, EPI_QKV_ENC, p.y, d, L.qkv_w, d, M, 3 * d, d, e, nullptr, s, nullptr, m->attn_hi));
     WSEG_TRY(launch_enc_attention(gdt, p.q, p.k, p.vt, p.y, W, H, T, Tp, d, s));
     e = EpiParams();
     e.bias = L.o_b; e.out = p.x; e.resid = p.x; e.ldc = d;
-    WSEG_TRY(gemm(m, EPI_RESID, p.y, d, L.o_w, d, M, d, d, e, nullptr, s, attn_mx ? nullptr : p.mxa));
+    WSEG_TRY(gemm(m, EPI_RESID, p.y, d, L.o_w, d, M, d, d, e, nullptr, s, attn_mx ? nullptr : p.mxa, m->attn_hi));
     WSEG_TRY(launch_layernorm(gdt, (const float*)p.x, L.ln2_g, L.ln2_b, p.y, M, d, s));
     e = EpiParams();
     e.bias = L.fc1_b; e.out = p.hbuf; e.ldc = ffn;
@@ -376,6 +378,7 @@ extern "C" int wseg_model_create(const wseg_model_config* cfg, wseg_model** out)
   m->es = (cfg->dtype == WSEG_BF16 || cfg->dtype == WSEG_F16) ? 2 : 4;
   m->x3 = cfg->dtype == WSEG_BF16X3 || cfg->dtype == WSEG_F16X3 || cfg->dtype == WSEG_F16M6;
   m->mx = cfg->dtype == WSEG_F16M6;
+  m->attn_hi = m->mx && getenv("WSEG_ATTN_HI") != nullptr;      // experiment knob, off: 19x the logit error at 32 layers
   m->sdt = storage_dtype(cfg->dtype);
   m->ckv_es = m->es;
   m->kp1 = (int)align_up((size_t)3 * cfg->n_mels, 64);
