@@ -11,7 +11,7 @@ from whisperseg_amd import _lib
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=200)
 ap.add_argument("--hog", default="both")
-ap.add_argument("--dtype", type=int, default=1)
+ap.add_argument("--dtype", type=int, default=1, help="1 bf16, 2 f16, 5 f16m6 (M6 operand rows from fp32 values)")
 ap.add_argument("--only", default="", help="substring filter on the shape names")
 a = ap.parse_args()
 lib = _lib.load(require_device=True)
@@ -42,12 +42,23 @@ for name, m, n, k, epi in shapes:
     mp = (m + 255) // 256 * 256
     g = torch.Generator(device="cuda").manual_seed(1)
     td = torch.bfloat16 if a.dtype == 1 else torch.float16
-    A = (torch.rand(mp, k, device="cuda", generator=g) * 2 - 1).to(td)
-    W = (torch.rand(n, k, device="cuda", generator=g) * 2 - 1).to(td)
-    bias = torch.rand(n, device="cuda", generator=g).to(td)
-    od = torch.float32 if epi == 2 else td
-    res = torch.rand(mp, n, device="cuda", generator=g).to(od)
-    out = torch.empty(mp, n, device="cuda", dtype=od)
+    if a.dtype == 5:
+        from whisperseg_amd.engine import split_operand
+        As = split_operand(torch.rand(mp, k, device="cuda", generator=g) * 2 - 1, torch.float16)
+        Ws = split_operand((torch.rand(n, k, device="cuda", generator=g) * 2 - 1) * k ** -0.5, torch.float16)
+        A, W = torch.empty_like(As), torch.empty_like(Ws)
+        _lib.check(lib.wseg_convert_operand(As.data_ptr(), A.data_ptr(), mp, k, 0, _lib.stream_ptr()))
+        _lib.check(lib.wseg_convert_operand(Ws.data_ptr(), W.data_ptr(), n, k, 1, _lib.stream_ptr()))
+        bias = torch.rand(n, device="cuda", generator=g)
+        res = torch.rand(mp, n, device="cuda", generator=g)
+        out = torch.empty(mp, n, device="cuda") if epi == 2 else torch.empty(mp, 2 * n, device="cuda", dtype=torch.int16)
+    else:
+        A = (torch.rand(mp, k, device="cuda", generator=g) * 2 - 1).to(td)
+        W = (torch.rand(n, k, device="cuda", generator=g) * 2 - 1).to(td)
+        bias = torch.rand(n, device="cuda", generator=g).to(td)
+        od = torch.float32 if epi == 2 else td
+        res = torch.rand(mp, n, device="cuda", generator=g).to(od)
+        out = torch.empty(mp, n, device="cuda", dtype=od)
     st = _lib.stream_ptr()
 
     def run():
@@ -75,7 +86,7 @@ for name, m, n, k, epi in shapes:
                     rows = dm.any(1).nonzero().flatten()
                     cols = dm.any(0).nonzero().flatten()
                     zero = (cur[dm] == 0).float().mean().item()
-                    if k // 64 <= 80 and len(cols) % 8 == 0 and len(cols) <= 32:
+                    if a.dtype != 5 and k // 64 <= 80 and len(cols) % 8 == 0 and len(cols) <= 32:
                         # which K tile's weight piece was stale, and what did the LDS hold instead?  (per 8-row weight piece)
                         r0 = int(rows[0])
                         Af = A[r0:r0 + len(rows)].float()
