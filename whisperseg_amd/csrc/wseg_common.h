@@ -257,7 +257,10 @@ __device__ __forceinline__ void op_st8_m6(void* base, size_t row, int ld, int c,
   uint4 c0, c1;
   mx_chunk(gw, want_hi ? ah : al, c0, c1);      // ONE conversion per lane: the chunk this lane stores half of
   const int chunk = (c >> 5) & 1;
-  *(uint4*)(blk + 128 + 32 * ((piece >> 1) * 2 + chunk) + 16 * (piece & 1)) = (piece & 1) ? c1 : c0;
+  // (component-wise: the whole-vector select went through scratch in the GELU epilogue instantiations)
+  const bool second = (piece & 1) != 0;
+  const uint4 cs = make_uint4(second ? c1.x : c0.x, second ? c1.y : c0.y, second ? c1.z : c0.z, second ? c1.w : c0.w);
+  *(uint4*)(blk + 128 + 32 * ((piece >> 1) * 2 + chunk) + 16 * (piece & 1)) = cs;
 }
 
 template <typename T> __device__ __forceinline__ void op_st8(void* base, size_t row, int ld, int c, const float v[8]) {

@@ -307,18 +307,25 @@ __device__ __forceinline__ MxFrag ld_mx_frag(const void* block16, const MxOff& m
 // there the fragment is exactly what the instruction reads — a 6-register tuple of codes + one scale register (b128 + b96 LDS
 // reads: the chunk's padding dword never takes a register) — and the instruction is issued through inline assembly.  Its
 // accumulator is written by builtin MFMAs and asm MFMAs alternately, always with a barrier and a round of LDS reads in between.
+typedef unsigned mx_u2 __attribute__((ext_vector_type(2)));
 typedef unsigned mx_u3 __attribute__((ext_vector_type(3)));
 typedef unsigned mx_u4 __attribute__((ext_vector_type(4)));
 struct MxFrag7 { mx_u6 v; unsigned s; };
+typedef const char __attribute__((address_space(3))) * lds_cp;
+// p0 / p1: LDS byte pointers of the lane's two 16-byte slots in 16-row block 0 (operand tile base + MxOff); OFF (a multiple of the
+// 2048-byte block) lands in the instruction's offset field — pointer arithmetic, no address VALU per read
 template <int OFF>
-__device__ __forceinline__ MxFrag7 ld_mx_frag7(unsigned lds_block16, const MxOff& m) {
+__device__ __forceinline__ MxFrag7 ld_mx_frag7(lds_cp p0, lds_cp p1) {
   typedef const mx_u4 __attribute__((address_space(3))) * lds_u4;
-  typedef const mx_u3 __attribute__((address_space(3))) * lds_u3;
-  const mx_u4 p0 = *(lds_u4)(uintptr_t)(lds_block16 + (unsigned)m.p0 + OFF);
-  const mx_u3 p1 = *(lds_u3)(uintptr_t)(lds_block16 + (unsigned)m.p1 + OFF);      // 16-byte aligned 12-byte read: ds_read_b96
+  typedef const mx_u2 __attribute__((address_space(3))) * lds_u2;
+  typedef const unsigned __attribute__((address_space(3))) * lds_u1;
+  // b128 + b64 + b32: every load fills a whole sub-range of the operand tuple (codes 0..3 | 4..5) or the scale register — no register
+  // copies (a b96 for codes 4, 5 + scale needed two v_mov per fragment) and 8 instead of 12 LDS cycles
+  const mx_u4 q0 = *(lds_u4)(p0 + OFF);
+  const mx_u2 q1 = *(lds_u2)(p1 + OFF);
   MxFrag7 f;
-  f.v = (mx_u6){p0[0], p0[1], p0[2], p0[3], p1[0], p1[1]};
-  f.s = p1[2];
+  f.v = (mx_u6){q0[0], q0[1], q0[2], q0[3], q1[0], q1[1]};
+  f.s = *(lds_u1)(p1 + OFF + 8);
   return f;
 }
 __device__ __forceinline__ void mfma_mx6_asm(f32x4& c, const MxFrag7& a, const MxFrag7& b) {
@@ -884,31 +891,38 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   // SGPR-base + 32-bit-VGPR-offset form of global_load_lds — no 64-bit address arithmetic (and no 64-bit lane offsets to spill:
   // a spilled pair was reloaded behind an s_waitcnt vmcnt(0) in every phase, draining the prefetch stream)
   const unsigned a_lane = (unsigned)(prow * lda + pslot * 8) * (unsigned)sizeof(HT), w_lane = (unsigned)(prow * ldw + pslot * 8) * (unsigned)sizeof(HT);
-  // M6 instantiation (at the 256-register cap): the lane offset is RECOMPUTED from the thread index at every issue (a few VALU
-  // operations in an L part that has room for them) behind an opaque copy of tid, so that no 64-bit lane offset is kept alive
-  // across the loop — and spilled, and reloaded behind a vmcnt(0).  Other modes keep the precomputed value.
-  auto lane_off = [&](int ld, unsigned kept) -> unsigned {
-    if constexpr (!MXM) return kept;
-    else {
-      unsigned t = (unsigned)tid;
-      asm volatile("" : "+v"(t));
-      const unsigned pr = t >> 3, ps = (t & 7) ^ (pr & 7);
-      return (pr * (unsigned)ld + ps * 8) * (unsigned)sizeof(HT);
-    }
+  // The L part of a phase is a serial chain of instruction issue (r04: every VALU / SALU instruction taken out of it shortens the
+  // barrier interval): the lane offsets stay in two 32-bit registers — behind an opaque copy at each use, so that the compiler
+  // neither hoists a zero-extended 64-bit pair out of the loop (it spilled one in the M6 instantiation, reloaded behind a
+  // vmcnt(0)) nor gives up the SGPR-base form of the instruction — and the operand streams are uniform pointers advanced by one
+  // K tile per A1 / B1 issue instead of being rebuilt from the cursors.  (Recomputing the offsets from the thread index at every
+  // issue, r04's first fix for the spill, cost 2.5-3 % of the f16m6 GEMMs.)
+  auto lane_off = [&](unsigned kept) -> unsigned {
+    unsigned t = kept;
+    asm volatile("" : "+v"(t));
+    return t;
   };
   int ca_idx = loc, ca_kt = 0, ca_g = 0, cb_idx = loc, cb_kt = 0, cb_g = 0;
   int tm, tn;
   tile_coords(start + loc, tm, tn);
   size_t ca_row = (size_t)tm * lda, cb_row = (size_t)tn * ldw;                    // scalar
   int ca_k0 = k_first(tile_z(start + loc)), ca_nk = SPLITK ? k_first(tile_z(start + loc) + 1) - ca_k0 : nk, cb_k0 = ca_k0, cb_nk = ca_nk;
+  // uniform byte pointers of the two operand streams (row 0 of the current output tile's rows, current K tile) and the constant
+  // strides of their pieces
+  const size_t a_half = (size_t)128 * lda * sizeof(HT), a_piece = (size_t)64 * lda * sizeof(HT);
+  const size_t w_half = (size_t)128 * ldw * sizeof(HT), w_piece = (size_t)64 * ldw * sizeof(HT);
+  constexpr size_t K_STEP = (size_t)BK * KS * sizeof(HT);
+  const char* ca_ptr = (const char*)(A + (ca_row + (size_t)(SPLITK ? ca_k0 : 0) * (BK * KS)));
+  const char* cb_ptr = (const char*)(W + (cb_row + (size_t)(SPLITK ? cb_k0 : 0) * (BK * KS)));
   auto issue_a = [&](int half) {                       // half-tile A<half> of K tile ca_g; the cursor advances after A1
     HT* dst = smem + (ca_g & 1) * BUF + half * HTILE + wave * 512;
-    const char* sbase = (const char*)(A + (ca_row + (size_t)(half * 128) * lda + ((SPLITK ? ca_k0 : 0) + ca_kt) * (BK * KS)));      // uniform
-    const unsigned al = lane_off(lda, a_lane);
+    const char* sbase = ca_ptr + (half ? a_half : (size_t)0);      // uniform
+    const unsigned al = lane_off(a_lane);
     WSEG_GLDS16(sbase + (size_t)al, dst);
-    WSEG_GLDS16(sbase + (size_t)64 * lda * sizeof(HT) + (size_t)al, dst + 4096);
+    WSEG_GLDS16(sbase + a_piece + (size_t)al, dst + 4096);
     if (half == 1) {
       ++ca_g;
+      ca_ptr += K_STEP;
       if (++ca_kt == (SPLITK ? ca_nk : nk)) {
         ca_kt = 0;
         ca_idx += bpx;
@@ -916,18 +930,20 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
           tile_coords(start + ca_idx, tm, tn);
           ca_row = (size_t)tm * lda;
           if constexpr (SPLITK) { const int z = tile_z(start + ca_idx); ca_k0 = k_first(z); ca_nk = k_first(z + 1) - ca_k0; }
+          ca_ptr = (const char*)(A + (ca_row + (size_t)(SPLITK ? ca_k0 : 0) * (BK * KS)));
         }
       }
     }
   };
   auto issue_b = [&](int half) {
     HT* dst = smem + (cb_g & 1) * BUF + (2 + half) * HTILE + wave * 512;
-    const char* sbase = (const char*)(W + (cb_row + (size_t)(half * 128) * ldw + ((SPLITK ? cb_k0 : 0) + cb_kt) * (BK * KS)));      // uniform
-    const unsigned wl = lane_off(ldw, w_lane);
+    const char* sbase = cb_ptr + (half ? w_half : (size_t)0);      // uniform
+    const unsigned wl = lane_off(w_lane);
     WSEG_GLDS16(sbase + (size_t)wl, dst);
-    WSEG_GLDS16(sbase + (size_t)64 * ldw * sizeof(HT) + (size_t)wl, dst + 4096);
+    WSEG_GLDS16(sbase + w_piece + (size_t)wl, dst + 4096);
     if (half == 1) {
       ++cb_g;
+      cb_ptr += K_STEP;
       if (++cb_kt == (SPLITK ? cb_nk : nk)) {
         cb_kt = 0;
         cb_idx += bpx;
@@ -935,6 +951,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
           tile_coords(start + cb_idx, tm, tn);
           cb_row = (size_t)tn * ldw;
           if constexpr (SPLITK) { const int z = tile_z(start + cb_idx); cb_k0 = k_first(z); cb_nk = k_first(z + 1) - cb_k0; }
+          cb_ptr = (const char*)(W + (cb_row + (size_t)(SPLITK ? cb_k0 : 0) * (BK * KS)));
         }
       }
     }
@@ -1009,9 +1026,13 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   // One K tile = two phases.  The tile bodies are lambdas so that the M6 instantiation can run a (hi tile, MX tile) PAIR per loop
   // iteration as straight-line code: with both bodies behind a branch inside one loop the register allocator spilled ~60 VGPRs into
   // the loop, and every scratch reload waits (vmcnt is in order) for the whole LDS-DMA prefetch stream: 4x slower than f16x3.
-  auto hi_tile = [&](int kt) {
+  // MID (a compile-time tag): a K tile in the middle of an output tile — not its first, not its last, and at least two more K tiles
+  // to come: every prefetch condition is known, the L parts lose their compares and branches (the L part is a serial chain of
+  // instruction issue; r04: ~1 % of the GEMM per 8-10 instructions taken out of it)
+  auto hi_tile = [&](int kt, auto mid_tag) {
+    constexpr bool MID = decltype(mid_tag)::value;
     // direct epilogue: the K-tile stream never pauses at an output-tile boundary (no staging buffer to protect)
-    const bool first = !(DIRECT && direct) && kt == 0 && g > 0, final = !(DIRECT && direct) && kt == nkt - 1;
+    const bool first = !MID && !(DIRECT && direct) && kt == 0 && g > 0, final = !MID && !(DIRECT && direct) && kt == nkt - 1;
     const HT* cur = smem + (g & 1) * BUF;
     bf16x8 afr[4][2], bfr[NI][2];
     // ---- phase A: b0, b1, a0 -> quadrants (a0, b0), (a0, b1); A pair of K tile g+1 ----
@@ -1030,7 +1051,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
     }
     if (DIRECT && direct && kt == 0) wait_vmcnt<0>();        // this tile's residual rows have landed in acc
     if (first && g + 1 < KT) { issue_b(0); issue_b(1); }        // B pair of K tile g+1, held back over the epilogue
-    if (g + 1 < KT) { issue_a(0); issue_a(1); }                 // A pair of K tile g+1
+    if (MID || g + 1 < KT) { issue_a(0); issue_a(1); }          // A pair of K tile g+1
     __builtin_amdgcn_sched_barrier(0);
     WSEG_PP_MFMA(0, 0, 1);
     __builtin_amdgcn_s_barrier();
@@ -1042,15 +1063,16 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
       afr[j][0] = *(const bf16x8*)(cur + (4 + j) * 16 * BK + fa0);
       afr[j][1] = *(const bf16x8*)(cur + (4 + j) * 16 * BK + fa1);
     }
-    if (!final && g + 2 < KT) { issue_b(0); issue_b(1); wait_vmcnt<4>(); }      // B pair of K tile g+2
+    if (MID || (!final && g + 2 < KT)) { issue_b(0); issue_b(1); wait_vmcnt<4>(); }      // B pair of K tile g+2
     else wait_vmcnt<0>();
     __builtin_amdgcn_sched_barrier(0);
     WSEG_PP_MFMA(1, 1, 0);
     if (!final) __builtin_amdgcn_s_barrier();
   };
-  [[maybe_unused]] auto mx_tile = [&](int kt) {
+  [[maybe_unused]] auto mx_tile = [&](int kt, auto mid_tag) {
+    constexpr bool MID = decltype(mid_tag)::value;
     // direct epilogue: the K-tile stream never pauses at an output-tile boundary (no staging buffer to protect)
-    const bool first = !(DIRECT && direct) && kt == 0 && g > 0, final = !(DIRECT && direct) && kt == nkt - 1;
+    const bool first = !MID && !(DIRECT && direct) && kt == 0 && g > 0, final = !MID && !(DIRECT && direct) && kt == nkt - 1;
     const HT* cur = smem + (g & 1) * BUF;
       // ---- MX tile (M6 rows): the same two phases, hand-overs and prefetch stream as below; the fragments are 24-byte e2m3
       // groups + a scale byte (ld_mx_frag), a quadrant pair is 16 scaled MFMAs ----
@@ -1058,10 +1080,12 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
       const unsigned bT = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)(cur + (2 + (wc >> 1)) * HTILE + (wc & 1) * 64 * BK);   // this wave's 64 W rows
       MxFrag7 bm[NI], am[4];
       WSEG_PP_STAMP(0, 0);
-      bm[0] = ld_mx_frag7<0>(bT, mxo); bm[1] = ld_mx_frag7<2048>(bT, mxo); bm[2] = ld_mx_frag7<4096>(bT, mxo); bm[3] = ld_mx_frag7<6144>(bT, mxo);
-      am[0] = ld_mx_frag7<0>(aT, mxo); am[1] = ld_mx_frag7<2048>(aT, mxo); am[2] = ld_mx_frag7<4096>(aT, mxo); am[3] = ld_mx_frag7<6144>(aT, mxo);
+      const lds_cp a0 = (lds_cp)(uintptr_t)(aT + (unsigned)mxo.p0), a1 = (lds_cp)(uintptr_t)(aT + (unsigned)mxo.p1);
+      const lds_cp b0 = (lds_cp)(uintptr_t)(bT + (unsigned)mxo.p0), b1 = (lds_cp)(uintptr_t)(bT + (unsigned)mxo.p1);
+      bm[0] = ld_mx_frag7<0>(b0, b1); bm[1] = ld_mx_frag7<2048>(b0, b1); bm[2] = ld_mx_frag7<4096>(b0, b1); bm[3] = ld_mx_frag7<6144>(b0, b1);
+      am[0] = ld_mx_frag7<0>(a0, a1); am[1] = ld_mx_frag7<2048>(a0, a1); am[2] = ld_mx_frag7<4096>(a0, a1); am[3] = ld_mx_frag7<6144>(a0, a1);
       if (first && g + 1 < KT) { issue_b(0); issue_b(1); }
-      if (g + 1 < KT) { issue_a(0); issue_a(1); }
+      if (MID || g + 1 < KT) { issue_a(0); issue_a(1); }
       __builtin_amdgcn_sched_barrier(0);
       WSEG_PP_STAMP(0, 1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1078,8 +1102,8 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
       WSEG_PP_STAMP(0, 3);
       __builtin_amdgcn_s_barrier();
       WSEG_PP_STAMP(1, 0);
-      am[0] = ld_mx_frag7<8192>(aT, mxo); am[1] = ld_mx_frag7<10240>(aT, mxo); am[2] = ld_mx_frag7<12288>(aT, mxo); am[3] = ld_mx_frag7<14336>(aT, mxo);
-      if (!final && g + 2 < KT) { issue_b(0); issue_b(1); wait_vmcnt<4>(); }
+      am[0] = ld_mx_frag7<8192>(a0, a1); am[1] = ld_mx_frag7<10240>(a0, a1); am[2] = ld_mx_frag7<12288>(a0, a1); am[3] = ld_mx_frag7<14336>(a0, a1);
+      if (MID || (!final && g + 2 < KT)) { issue_b(0); issue_b(1); wait_vmcnt<4>(); }
       else wait_vmcnt<0>();
       __builtin_amdgcn_sched_barrier(0);
       WSEG_PP_STAMP(1, 1);
@@ -1097,12 +1121,30 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
       WSEG_PP_STAMP(1, 3);
       if (!final) __builtin_amdgcn_s_barrier();
   };
-  if constexpr (MXM) {
+  constexpr std::false_type EDGE{};
+  constexpr std::true_type MIDDLE{};
+  // three stretches of straight-line code (one loop body behind a branch spilled hundreds of bytes): leading edge tile(s), the
+  // middle tiles, trailing edge tiles
+  if constexpr (MXM) {      // K ranges are whole (hi, MX) tile pairs starting at a hi tile
+    int kt = 0;
+    hi_tile(kt, EDGE); ++g; mx_tile(kt + 1, EDGE); ++g;
+    kt = 2;
+    if constexpr (!DIRECT) {
 #pragma nounroll
-    for (int kt = 0; kt < nkt; kt += 2) { hi_tile(kt); ++g; mx_tile(kt + 1); ++g; }      // K ranges are whole tile pairs starting at a hi tile
+      for (; kt + 3 < nkt; kt += 2) { hi_tile(kt, MIDDLE); ++g; mx_tile(kt + 1, MIDDLE); ++g; }
+    }
+#pragma nounroll
+    for (; kt < nkt; kt += 2) { hi_tile(kt, EDGE); ++g; mx_tile(kt + 1, EDGE); ++g; }
   } else {
+    int kt = 0;
+    hi_tile(kt, EDGE); ++g;
+    kt = 1;
+    if constexpr (!DIRECT) {
 #pragma nounroll
-    for (int kt = 0; kt < nkt; ++kt, ++g) hi_tile(kt);
+      for (; kt + 2 < nkt; ++kt, ++g) hi_tile(kt, MIDDLE);
+    }
+#pragma nounroll
+    for (; kt < nkt; ++kt, ++g) hi_tile(kt, EDGE);
   }
   // Epilogue: group 0 gives up its one-barrier lead (it idles while group 1 finishes its last 16 MFMAs), both groups run
   // their epilogues in the SAME interval — back to back they cost two epilogue times with the matrix pipe idle, side by
@@ -1593,7 +1635,9 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
     const long nt256 = (long)cdiv(g.M, 256) * (g.N / 256);
     const long rounds256 = (nt256 + n_cu - 1) / n_cu;
     static const bool quant_rule = getenv("WSEG_GEMM_NO_QUANT_RULE") == nullptr;   // tuning knob
-    const bool ragged256 = quant_rule && rounds256 < 4 && nt256 * 5 < rounds256 * n_cu * 4;
+    // (split / mixed modes: a K tile pair costs twice the bf16 K tile while the 128x128 kernel's fixed costs do not shrink — since the
+    // r04 K-loop work the 256x256 kernel wins down to 3/5 of a last round: decoder fc1 at 4 096 rows, 320 tiles, 152 against 161 us)
+    const bool ragged256 = quant_rule && rounds256 < 4 && nt256 * 5 < rounds256 * n_cu * (IO<T>::split ? 3 : 4);
     if (big256 && g.N % 256 == 0 && nt256 >= 192 && !ragged256) {
       const int ntm = cdiv(g.M, 256), ntiles = ntm * (g.N / 256);
       static const bool pingpong = getenv("WSEG_GEMM_NO_PP") == nullptr;   // ping-pong kernel by default (tuning knob)
