@@ -914,52 +914,53 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   constexpr size_t K_STEP = (size_t)BK * KS * sizeof(HT);
   const char* ca_ptr = (const char*)(A + (ca_row + (size_t)(SPLITK ? ca_k0 : 0) * (BK * KS)));
   const char* cb_ptr = (const char*)(W + (cb_row + (size_t)(SPLITK ? cb_k0 : 0) * (BK * KS)));
-  auto issue_a = [&](int half) {                       // half-tile A<half> of K tile ca_g; the cursor advances after A1
-    HT* dst = smem + (ca_g & 1) * BUF + half * HTILE + wave * 512;
-    const char* sbase = ca_ptr + (half ? a_half : (size_t)0);      // uniform
+  // par: LDS buffer of the K tile being issued, when the caller knows it at compile time (M6 rows: a K range is whole (hi, MX) tile
+  // pairs, so hi tiles always live in buffer 0 and MX tiles in buffer 1 — the buffer selects and the fragment address arithmetic fold
+  // away); -1: the stream index decides
+  auto issue_a = [&](int par = -1) {                   // both halves of the A pair of K tile ca_g; the cursor advances
+    HT* dst = smem + (par >= 0 ? par : (ca_g & 1)) * BUF + wave * 512;
     const unsigned al = lane_off(a_lane);
-    WSEG_GLDS16(sbase + (size_t)al, dst);
-    WSEG_GLDS16(sbase + a_piece + (size_t)al, dst + 4096);
-    if (half == 1) {
-      ++ca_g;
-      ca_ptr += K_STEP;
-      if (++ca_kt == (SPLITK ? ca_nk : nk)) {
-        ca_kt = 0;
-        ca_idx += bpx;
-        if (ca_idx < count) {
-          tile_coords(start + ca_idx, tm, tn);
-          ca_row = (size_t)tm * lda;
-          if constexpr (SPLITK) { const int z = tile_z(start + ca_idx); ca_k0 = k_first(z); ca_nk = k_first(z + 1) - ca_k0; }
-          ca_ptr = (const char*)(A + (ca_row + (size_t)(SPLITK ? ca_k0 : 0) * (BK * KS)));
-        }
+    WSEG_GLDS16(ca_ptr + (size_t)al, dst);
+    WSEG_GLDS16(ca_ptr + a_piece + (size_t)al, dst + 4096);
+    WSEG_GLDS16(ca_ptr + a_half + (size_t)al, dst + HTILE);
+    WSEG_GLDS16(ca_ptr + a_half + a_piece + (size_t)al, dst + HTILE + 4096);
+    ++ca_g;
+    ca_ptr += K_STEP;
+    if (++ca_kt == (SPLITK ? ca_nk : nk)) {
+      ca_kt = 0;
+      ca_idx += bpx;
+      if (ca_idx < count) {
+        tile_coords(start + ca_idx, tm, tn);
+        ca_row = (size_t)tm * lda;
+        if constexpr (SPLITK) { const int z = tile_z(start + ca_idx); ca_k0 = k_first(z); ca_nk = k_first(z + 1) - ca_k0; }
+        ca_ptr = (const char*)(A + (ca_row + (size_t)(SPLITK ? ca_k0 : 0) * (BK * KS)));
       }
     }
   };
-  auto issue_b = [&](int half) {
-    HT* dst = smem + (cb_g & 1) * BUF + (2 + half) * HTILE + wave * 512;
-    const char* sbase = cb_ptr + (half ? w_half : (size_t)0);      // uniform
+  auto issue_b = [&](int par = -1) {
+    HT* dst = smem + (par >= 0 ? par : (cb_g & 1)) * BUF + 2 * HTILE + wave * 512;
     const unsigned wl = lane_off(w_lane);
-    WSEG_GLDS16(sbase + (size_t)wl, dst);
-    WSEG_GLDS16(sbase + w_piece + (size_t)wl, dst + 4096);
-    if (half == 1) {
-      ++cb_g;
-      cb_ptr += K_STEP;
-      if (++cb_kt == (SPLITK ? cb_nk : nk)) {
-        cb_kt = 0;
-        cb_idx += bpx;
-        if (cb_idx < count) {
-          tile_coords(start + cb_idx, tm, tn);
-          cb_row = (size_t)tn * ldw;
-          if constexpr (SPLITK) { const int z = tile_z(start + cb_idx); cb_k0 = k_first(z); cb_nk = k_first(z + 1) - cb_k0; }
-          cb_ptr = (const char*)(W + (cb_row + (size_t)(SPLITK ? cb_k0 : 0) * (BK * KS)));
-        }
+    WSEG_GLDS16(cb_ptr + (size_t)wl, dst);
+    WSEG_GLDS16(cb_ptr + w_piece + (size_t)wl, dst + 4096);
+    WSEG_GLDS16(cb_ptr + w_half + (size_t)wl, dst + HTILE);
+    WSEG_GLDS16(cb_ptr + w_half + w_piece + (size_t)wl, dst + HTILE + 4096);
+    ++cb_g;
+    cb_ptr += K_STEP;
+    if (++cb_kt == (SPLITK ? cb_nk : nk)) {
+      cb_kt = 0;
+      cb_idx += bpx;
+      if (cb_idx < count) {
+        tile_coords(start + cb_idx, tm, tn);
+        cb_row = (size_t)tn * ldw;
+        if constexpr (SPLITK) { const int z = tile_z(start + cb_idx); cb_k0 = k_first(z); cb_nk = k_first(z + 1) - cb_k0; }
+        cb_ptr = (const char*)(W + (cb_row + (size_t)(SPLITK ? cb_k0 : 0) * (BK * KS)));
       }
     }
   };
 
   // prologue: K tile 0 complete, B pair of K tile 1 in flight
-  issue_b(0); issue_b(1); issue_a(0); issue_a(1);
-  if (KT > 1) { issue_b(0); issue_b(1); wait_vmcnt<4>(); }
+  issue_b(); issue_a();
+  if (KT > 1) { issue_b(); wait_vmcnt<4>(); }
   else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();          // stagger: group 1 runs one barrier behind group 0
@@ -1033,7 +1034,9 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
     constexpr bool MID = decltype(mid_tag)::value;
     // direct epilogue: the K-tile stream never pauses at an output-tile boundary (no staging buffer to protect)
     const bool first = !MID && !(DIRECT && direct) && kt == 0 && g > 0, final = !MID && !(DIRECT && direct) && kt == nkt - 1;
-    const HT* cur = smem + (g & 1) * BUF;
+    constexpr int PAR = MXM ? 0 : -1;                  // this tile's LDS buffer (M6 rows: hi tiles in buffer 0), -1: g & 1
+    constexpr int NPAR = MXM ? 1 : -1;
+    const HT* cur = smem + (MXM ? 0 : (g & 1)) * BUF;
     bf16x8 afr[4][2], bfr[NI][2];
     // ---- phase A: b0, b1, a0 -> quadrants (a0, b0), (a0, b1); A pair of K tile g+1 ----
     [[maybe_unused]] int pp_phase = 0;
@@ -1050,8 +1053,8 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
       afr[j][1] = *(const bf16x8*)(cur + j * 16 * BK + fa1);
     }
     if (DIRECT && direct && kt == 0) wait_vmcnt<0>();        // this tile's residual rows have landed in acc
-    if (first && g + 1 < KT) { issue_b(0); issue_b(1); }        // B pair of K tile g+1, held back over the epilogue
-    if (MID || g + 1 < KT) { issue_a(0); issue_a(1); }          // A pair of K tile g+1
+    if (first && g + 1 < KT) issue_b(NPAR);                     // B pair of K tile g+1, held back over the epilogue
+    if (MID || g + 1 < KT) issue_a(NPAR);                       // A pair of K tile g+1
     __builtin_amdgcn_sched_barrier(0);
     WSEG_PP_MFMA(0, 0, 1);
     __builtin_amdgcn_s_barrier();
@@ -1063,7 +1066,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
       afr[j][0] = *(const bf16x8*)(cur + (4 + j) * 16 * BK + fa0);
       afr[j][1] = *(const bf16x8*)(cur + (4 + j) * 16 * BK + fa1);
     }
-    if (MID || (!final && g + 2 < KT)) { issue_b(0); issue_b(1); wait_vmcnt<4>(); }      // B pair of K tile g+2
+    if (MID || (!final && g + 2 < KT)) { issue_b(PAR); wait_vmcnt<4>(); }      // B pair of K tile g+2
     else wait_vmcnt<0>();
     __builtin_amdgcn_sched_barrier(0);
     WSEG_PP_MFMA(1, 1, 0);
@@ -1073,7 +1076,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
     constexpr bool MID = decltype(mid_tag)::value;
     // direct epilogue: the K-tile stream never pauses at an output-tile boundary (no staging buffer to protect)
     const bool first = !MID && !(DIRECT && direct) && kt == 0 && g > 0, final = !MID && !(DIRECT && direct) && kt == nkt - 1;
-    const HT* cur = smem + (g & 1) * BUF;
+    const HT* cur = smem + BUF;                        // MX tiles live in buffer 1
       // ---- MX tile (M6 rows): the same two phases, hand-overs and prefetch stream as below; the fragments are 24-byte e2m3
       // groups + a scale byte (ld_mx_frag), a quadrant pair is 16 scaled MFMAs ----
       const unsigned aT = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)(cur + wr * HTILE);      // this row group's 128-row A half-tile
@@ -1084,8 +1087,8 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
       const lds_cp b0 = (lds_cp)(uintptr_t)(bT + (unsigned)mxo.p0), b1 = (lds_cp)(uintptr_t)(bT + (unsigned)mxo.p1);
       bm[0] = ld_mx_frag7<0>(b0, b1); bm[1] = ld_mx_frag7<2048>(b0, b1); bm[2] = ld_mx_frag7<4096>(b0, b1); bm[3] = ld_mx_frag7<6144>(b0, b1);
       am[0] = ld_mx_frag7<0>(a0, a1); am[1] = ld_mx_frag7<2048>(a0, a1); am[2] = ld_mx_frag7<4096>(a0, a1); am[3] = ld_mx_frag7<6144>(a0, a1);
-      if (first && g + 1 < KT) { issue_b(0); issue_b(1); }
-      if (MID || g + 1 < KT) { issue_a(0); issue_a(1); }
+      if (first && g + 1 < KT) issue_b(0);
+      if (MID || g + 1 < KT) issue_a(0);
       __builtin_amdgcn_sched_barrier(0);
       WSEG_PP_STAMP(0, 1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1103,7 +1106,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
       __builtin_amdgcn_s_barrier();
       WSEG_PP_STAMP(1, 0);
       am[0] = ld_mx_frag7<8192>(a0, a1); am[1] = ld_mx_frag7<10240>(a0, a1); am[2] = ld_mx_frag7<12288>(a0, a1); am[3] = ld_mx_frag7<14336>(a0, a1);
-      if (MID || (!final && g + 2 < KT)) { issue_b(0); issue_b(1); wait_vmcnt<4>(); }
+      if (MID || (!final && g + 2 < KT)) { issue_b(1); wait_vmcnt<4>(); }
       else wait_vmcnt<0>();
       __builtin_amdgcn_sched_barrier(0);
       WSEG_PP_STAMP(1, 1);
