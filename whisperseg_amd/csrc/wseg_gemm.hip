@@ -271,6 +271,9 @@ __device__ unsigned long long g_pp_stamps[2 * 4 * 4 * 4 + 4];  // [group][K tile
 #define WSEG_PP_CLOCK() do { } while (0)
 #endif
 
+#ifndef WSEG_PP_LATEWAIT
+#define WSEG_PP_LATEWAIT 1
+#endif
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // Barrier that closes the fragment reads of an LDS stage: every ds_read this wave has issued must have RETURNED before
@@ -819,11 +822,16 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 2 : 1) voi
 //     B0, B1 (read by both groups in phase A):     from interval 4g + 2
 //     A0 (read by group 0 only, phases A and B):   from interval 4g + 3
 //     A1 (read by group 1 only):                   from interval 4g + 4
-// and the prefetch stream is      phase B of g: B pair of K tile g+2 (intervals 4g+2 / 4g+3), then s_waitcnt vmcnt(4)
-//                                 phase A of g: A pair of K tile g+1 (it overwrites K tile g-1: free since 4g - 1 / 4g)
-// The counted wait in the L part of phase B retires K tile g+1 (A pair issued one phase, B pair two phases earlier) and
-// leaves the B pair of g+2 in flight across the barrier; group 1's wait (interval 4g+3) is followed by the barrier that
-// opens interval 4g+4, in which group 0 is the first to read K tile g+1.
+// and the prefetch stream is      phase B of g: B pair of K tile g+2 (intervals 4g+2 / 4g+3)
+//                                 phase A of g: A half of K tile g+1 (it overwrites K tile g-1: free since 4g - 1 / 4g)
+// All 8 waves share the B pair (every wave streams its eighth of both halves); the A halves are GROUP-LOCAL: the 4 waves of group x
+// stream A<x>, the half only they read.  Retirement of K tile g+1, first read by group 0 in interval 4g+4 (issue order per wave:
+// B pair of g+1, A half of g+1, B pair of g+2):
+//     group 1, end of its phase-B L part (interval 4g+3):   s_waitcnt vmcnt(8) — its pieces of the B pair of g+1
+//     both groups, behind their phase-B MFMAs (4g+3 / 4g+4): s_waitcnt vmcnt(4) — own A half (+ group 0's B pieces); the B pair of
+//                                                            g+2 stays in flight across the barrier
+// (Until r04 every wave streamed an eighth of all four half-tiles and retired K tile g+1 with one vmcnt(4) in its phase-B L part —
+// 280-370 cycles of exposed load latency in that L part according to the stamps.)
 // The K-tile stream is continuous across the output tiles a workgroup owns.  The last K tile e of an output tile
 // leaves buffer e & 1 to the epilogue as its staging area: the B pair of K tile e+2 is held back to phase A of K tile
 // e+1, which both groups reach only after the barrier that closes the (shared) epilogue interval.
@@ -847,6 +855,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   // stores: -16 us per tile) show the epilogue is the HBM-bound burst of all CUs hitting their tile boundary together
   // (1.31 GB of fp32 residual traffic at ~4.6 TB/s), not a per-wave latency chain — kept as an experiment knob.
   constexpr bool DIRECT = EPI == EPI_RESID && !STAGED_RESID;
+  constexpr bool LATEWAIT = WSEG_PP_LATEWAIT != 0 && !DIRECT;      // see hi_tile, phase B
   constexpr int BM = 256, BN = 256, BK = 64, TM = 128, TN = 64, MI = 8, NI = 4;
   constexpr int HTILE = 128 * BK;                      // elements per half-tile (16 KB)
   constexpr int BUF = 4 * HTILE;                       // elements per K-tile buffer: [A0 | A1 | B0 | B1]
@@ -887,10 +896,14 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   // thread's piece of a half-tile: LDS 16-B slot p = it*512 + tid (it = 0, 1) holds row p >> 3, logical slot
   // (p & 7) ^ (row & 7) (swizzle on the source side); piece 1 is 64 rows below piece 0, same slot.
   const int prow = tid >> 3, pslot = (tid & 7) ^ (prow & 7);
+  // The A half-tiles are GROUP-LOCAL (r04): row group x streams its own half-tile A<x> (its 4 waves cover the 128 rows with 4
+  // pieces of 32 rows: LDS slot p = it*256 + (tid & 255), row p >> 3), so nothing a group reads from an A half depends on the other
+  // group's loads — a group may retire its A pieces as late as the end of the phase-B M part before the tile is read.
+  const int arow = (tid & 255) >> 3;                     // row within a 32-row piece; (arow & 7) == (prow & 7): the same slot swizzle
   // per-lane BYTE offsets, unsigned 32-bit (rows of a tile span < 2^31 bytes): with a wave-uniform 64-bit base they select the
   // SGPR-base + 32-bit-VGPR-offset form of global_load_lds — no 64-bit address arithmetic (and no 64-bit lane offsets to spill:
   // a spilled pair was reloaded behind an s_waitcnt vmcnt(0) in every phase, draining the prefetch stream)
-  const unsigned a_lane = (unsigned)(prow * lda + pslot * 8) * (unsigned)sizeof(HT), w_lane = (unsigned)(prow * ldw + pslot * 8) * (unsigned)sizeof(HT);
+  const unsigned a_lane = (unsigned)((wr * 128 + arow) * lda + pslot * 8) * (unsigned)sizeof(HT), w_lane = (unsigned)(prow * ldw + pslot * 8) * (unsigned)sizeof(HT);
   // The L part of a phase is a serial chain of instruction issue (r04: every VALU / SALU instruction taken out of it shortens the
   // barrier interval): the lane offsets stay in two 32-bit registers — behind an opaque copy at each use, so that the compiler
   // neither hoists a zero-extended 64-bit pair out of the loop (it spilled one in the M6 instantiation, reloaded behind a
@@ -909,7 +922,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   int ca_k0 = k_first(tile_z(start + loc)), ca_nk = SPLITK ? k_first(tile_z(start + loc) + 1) - ca_k0 : nk, cb_k0 = ca_k0, cb_nk = ca_nk;
   // uniform byte pointers of the two operand streams (row 0 of the current output tile's rows, current K tile) and the constant
   // strides of their pieces
-  const size_t a_half = (size_t)128 * lda * sizeof(HT), a_piece = (size_t)64 * lda * sizeof(HT);
+  const size_t a_piece = (size_t)32 * lda * sizeof(HT);
   const size_t w_half = (size_t)128 * ldw * sizeof(HT), w_piece = (size_t)64 * ldw * sizeof(HT);
   constexpr size_t K_STEP = (size_t)BK * KS * sizeof(HT);
   const char* ca_ptr = (const char*)(A + (ca_row + (size_t)(SPLITK ? ca_k0 : 0) * (BK * KS)));
@@ -917,13 +930,13 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   // par: LDS buffer of the K tile being issued, when the caller knows it at compile time (M6 rows: a K range is whole (hi, MX) tile
   // pairs, so hi tiles always live in buffer 0 and MX tiles in buffer 1 — the buffer selects and the fragment address arithmetic fold
   // away); -1: the stream index decides
-  auto issue_a = [&](int par = -1) {                   // both halves of the A pair of K tile ca_g; the cursor advances
-    HT* dst = smem + (par >= 0 ? par : (ca_g & 1)) * BUF + wave * 512;
+  auto issue_a = [&](int par = -1) {                   // this row group's half A<wr> of K tile ca_g; the cursor advances
+    HT* dst = smem + (par >= 0 ? par : (ca_g & 1)) * BUF + wr * HTILE + wc * 512;
     const unsigned al = lane_off(a_lane);
     WSEG_GLDS16(ca_ptr + (size_t)al, dst);
-    WSEG_GLDS16(ca_ptr + a_piece + (size_t)al, dst + 4096);
-    WSEG_GLDS16(ca_ptr + a_half + (size_t)al, dst + HTILE);
-    WSEG_GLDS16(ca_ptr + a_half + a_piece + (size_t)al, dst + HTILE + 4096);
+    WSEG_GLDS16(ca_ptr + a_piece + (size_t)al, dst + 2048);
+    WSEG_GLDS16(ca_ptr + 2 * a_piece + (size_t)al, dst + 4096);
+    WSEG_GLDS16(ca_ptr + 3 * a_piece + (size_t)al, dst + 6144);
     ++ca_g;
     ca_ptr += K_STEP;
     if (++ca_kt == (SPLITK ? ca_nk : nk)) {
@@ -1066,10 +1079,20 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
       afr[j][0] = *(const bf16x8*)(cur + (4 + j) * 16 * BK + fa0);
       afr[j][1] = *(const bf16x8*)(cur + (4 + j) * 16 * BK + fa1);
     }
-    if (MID || (!final && g + 2 < KT)) { issue_b(PAR); wait_vmcnt<4>(); }      // B pair of K tile g+2
-    else wait_vmcnt<0>();
+    // Retirement of K tile g+1 (LATEWAIT, r04; the stamps showed 280 cycles of exposed load latency in this L part): group 1's pieces
+    // of its B pair — group 0 reads them at the start of the next interval but one — are retired here, everything else (a group's
+    // own A half, group 0's B pieces) only behind this phase's MFMAs, one interval later.  Issue order per wave: B pair of g+1,
+    // A half of g+1, B pair of g+2.
+    const bool pb = MID || (!final && g + 2 < KT);
+    if (pb) issue_b(PAR);                                           // B pair of K tile g+2
+    if constexpr (LATEWAIT) {
+      if (wr == 1) { if (pb) wait_vmcnt<8>(); else wait_vmcnt<4>(); }
+    } else {
+      if (pb) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    }
     __builtin_amdgcn_sched_barrier(0);
     WSEG_PP_MFMA(1, 1, 0);
+    if constexpr (LATEWAIT) { if (pb) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
     if (!final) __builtin_amdgcn_s_barrier();
   };
   [[maybe_unused]] auto mx_tile = [&](int kt, auto mid_tag) {
@@ -1106,8 +1129,13 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
       __builtin_amdgcn_s_barrier();
       WSEG_PP_STAMP(1, 0);
       am[0] = ld_mx_frag7<8192>(a0, a1); am[1] = ld_mx_frag7<10240>(a0, a1); am[2] = ld_mx_frag7<12288>(a0, a1); am[3] = ld_mx_frag7<14336>(a0, a1);
-      if (MID || (!final && g + 2 < KT)) { issue_b(1); wait_vmcnt<4>(); }
-      else wait_vmcnt<0>();
+      const bool pb = MID || (!final && g + 2 < KT);
+      if (pb) issue_b(1);
+      if constexpr (LATEWAIT) {
+        if (wr == 1) { if (pb) wait_vmcnt<8>(); else wait_vmcnt<4>(); }
+      } else {
+        if (pb) wait_vmcnt<4>(); else wait_vmcnt<0>();
+      }
       __builtin_amdgcn_sched_barrier(0);
       WSEG_PP_STAMP(1, 1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1121,6 +1149,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
         for (int j = 0; j < 4; ++j) mfma_mx6_asm(acc[i][4 + j], bm[i], am[j]);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (LATEWAIT) { if (pb) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
       WSEG_PP_STAMP(1, 3);
       if (!final) __builtin_amdgcn_s_barrier();
   };
