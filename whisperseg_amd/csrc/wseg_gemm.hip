@@ -1818,7 +1818,11 @@ int launch_gemm_partial(int dtype, const GemmArgs& g, PartialInfo* info, bool* o
 // rows: 16 x 5 = 80 tiles on 256 CUs; the 128x64 stream kernel needs 99 us for it, hipBLASLt 56): S = n_cu / tiles copies of the
 // tile grid, each multiplying 1/S of the K tiles into an fp32 partial plane.  Returns 0 when the shape does not qualify.
 template <typename T> static int pp_splitk_plan(const GemmArgs& g) {
-  static const int min_rows = getenv("WSEG_PP_SPLITK_MIN_ROWS") ? atoi(getenv("WSEG_PP_SPLITK_MIN_ROWS")) : 2048;   // tuning knobs
+  // tuning knobs.  Split / mixed modes (twice the K tiles per logical column, r04 K loop): the split-K 256x256 kernel beats the
+  // 128x64 stream kernel from 512 rows up (decode step at 128 / 256 / 384 slots: 9.9 -> 9.3, 15.2 -> 14.5, 18.4 -> 17.7 ms; at 64
+  // slots the stream kernel wins, 6.2 against 6.7 ms)
+  static const int min_rows_env = getenv("WSEG_PP_SPLITK_MIN_ROWS") ? atoi(getenv("WSEG_PP_SPLITK_MIN_ROWS")) : 0;
+  const int min_rows = min_rows_env ? min_rows_env : (IO<T>::split ? 512 : 2048);
   static const int min_kt = getenv("WSEG_PP_SPLITK_MIN_KT") ? atoi(getenv("WSEG_PP_SPLITK_MIN_KT")) : 40;
   if (g.M < min_rows || g.N % 256 || g.K % 64 || g.K / 64 < min_kt || !g.splitk_ws) return 0;
   const int nt = cdiv(g.M, 256) * (g.N / 256), nk = g.K / 64, n_cu = device_cu_count();
