@@ -1,4 +1,4 @@
-"""Parity of WhisperSegmenter.segment() in every engine mode (f32, f16x3, bf16x3, f16, bf16) against the reference's own rows over tests/golden/tiny_sweep.json:
+"""Parity of WhisperSegmenter.segment() in every engine mode (f32, f16m6, f16x3, bf16x3, f16, bf16) against the reference's own rows over tests/golden/tiny_sweep.json:
 200 recordings (50 seeds x trials {1, 3} x beams {1, 4}) of the tiny trained model, expected rows recorded by driving HF fp32
 through the reference's WhisperSegmenterForEval (tools/make_golden.py, G8).
 
@@ -72,7 +72,7 @@ def main():
     with open(os.path.join(ROOT, "tests", "golden", "tiny_sweep.json")) as f:
         sweep = json.load(f)
     res = {}
-    modes = [m for m in sys.argv[2:]] or ["f32", "f16x3", "bf16x3", "f16", "bf16"]
+    modes = [m for m in sys.argv[2:]] or ["f32", "f16m6", "f16x3", "bf16x3", "f16", "bf16"]
     segs = {}
     for dtype in modes:
         if "+" in dtype:       # "enc:f32+dec:bf16"
