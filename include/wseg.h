@@ -243,7 +243,8 @@ int wseg_debug_gemm(int32_t dtype, int32_t epi, int32_t M, int32_t N, int32_t K,
                     const void* bias, const void* resid, void* out, void* splitk_ws, size_t splitk_ws_bytes, void* stream);
 
 /* WSEG_F16M6: 1 when wseg_debug_gemm with epi 0 / 1 writes its output as M6 rows (the LDS-staged epilogues of the large-tile
- * kernels), 0 when it writes hi | lo IEEE-half rows (skinny family); always 0 for the other dtypes. */
+ * kernels; the skinny family when it splits K — assumed here: a workspace that never limits the split), 0 when it writes hi | lo
+ * IEEE-half rows (skinny family, K not split); always 0 for the other dtypes. */
 int wseg_debug_gemm_out_is_mx(int32_t dtype, int32_t M, int32_t N, int32_t K);
 
 /* Test / tuning tap of the decoder's fused step x += A W^T + bias; y = LayerNorm(x) * gamma + beta (x: fp32 residual stream [M][N],

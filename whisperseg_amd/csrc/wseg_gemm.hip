@@ -1240,6 +1240,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   epi_apply<EPI, T>(ep, m, n0, v);
 }
 
+// The same with 8 columns per thread through the 8-column epilogue: in WSEG_F16M6 mode (EPI_STORE / EPI_GELU, N % 32 == 0) the four
+// lanes of a quad cover one 32-column block and write M6 rows directly — the split-K skinny path then hands the next GEMM its operand
+// without a conversion launch (small batches: one graph node per decoder layer less).  Same summation order as the 4-column kernel.
+template <int EPI, typename T>
+__global__ __launch_bounds__(256) void splitk_reduce8_kernel(const float* __restrict__ part, int splits, int m_pad,
+                                                             int M, int N, EpiParams ep) {
+  const int n8 = N >> 3;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * n8) return;      // M * n8 is a multiple of 4 (N % 32 == 0): whole quads leave together
+  const int m = idx / n8, n0 = (idx - m * n8) << 3;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < splits; ++z) {
+    const float* p = part + ((size_t)z * m_pad + m) * N + n0;
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+  }
+  epi_apply8<EPI, T>(ep, m, n0, v);
+}
+
 // ------------------------------------------------------------------------------------------------
 // f32 exact kernel: 64x64 tile, 4x4 micro-tile per thread, sequential-k fmaf chain.
 // ------------------------------------------------------------------------------------------------
@@ -1635,6 +1654,11 @@ template <typename T> static GemmArgs kernel_view(const GemmArgs& g0) {
   return g;
 }
 
+static bool skinny_split_writes_mx(int N) {
+  static const bool off = getenv("WSEG_NO_MX_REDUCE") != nullptr;      // A/B knob
+  return !off && N % 32 == 0;
+}
+
 template <int EPI, typename T>
 static int launch_h16(const GemmArgs& g0, hipStream_t s) {
   typedef typename IO<T>::H HT;
@@ -1739,6 +1763,14 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
     return WSEG_OK;
   }
   WSEG_TRY_(launch_skinny_partial<T>(g, sp, s));
+  if constexpr (IsMx<T>::v && (EPI == EPI_STORE || EPI == EPI_GELU)) {
+    if (skinny_split_writes_mx(g.N)) {      // M6 rows straight from the reduction (gemm_out_is_mx predicts exactly this)
+      hipLaunchKernelGGL((splitk_reduce8_kernel<EPI, T>), dim3(cdiv(g.M * (g.N / 8), 256)), dim3(256), 0, s, g.splitk_ws, sp.splits, sp.m_pad, g.M,
+                         g.N, g.ep);
+      WSEG_LAUNCH_CHECK();
+      return WSEG_OK;
+    }
+  }
   const int work = g.M * (g.N / 4);
   hipLaunchKernelGGL((splitk_reduce_kernel<EPI, T>), dim3(cdiv(work, 256)), dim3(256), 0, s, g.splitk_ws, sp.splits, sp.m_pad, g.M, g.N, g.ep);
   WSEG_LAUNCH_CHECK();
@@ -1894,11 +1926,15 @@ int launch_gemm_resid_ln(int dtype, const GemmArgs& g, const void* gamma, const 
 
 // WSEG_F16M6: are the operand rows an EPI_STORE / EPI_GELU launch of this shape writes M6 rows (LDS-staged 8-column epilogues of the
 // large-tile kernels: cooperative op_st8) or hi | lo rows (4-column epilogues of the skinny family and its split-K reduction)?
-bool gemm_out_is_mx(int dtype, int M, int N, int K) {
+bool gemm_out_is_mx(int dtype, int M, int N, int K, size_t splitk_ws_bytes) {
   if (dtype != WSEG_F16M6) return false;
   GemmArgs g;
   g.M = M; g.N = N; g.K = 2 * K;
-  return big_tile_path(g);
+  if (big_tile_path(g)) return true;
+  if (!splitk_ws_bytes || g.K % 128 || N % 64) return false;
+  g.splitk_ws = (float*)(uintptr_t)16;      // any non-null value: plan_skinny only asks whether a workspace exists and how large it is
+  g.splitk_ws_bytes = splitk_ws_bytes;
+  return plan_skinny(g, true).splits > 1 && skinny_split_writes_mx(N);
 }
 
 int launch_gemm(int dtype, EpiKind epi, const GemmArgs& g, hipStream_t s) {
@@ -1935,7 +1971,9 @@ extern "C" int wseg_debug_gemm(int32_t dtype, int32_t epi, int32_t M, int32_t N,
   return launch_gemm(dtype, epi == 0 ? EPI_STORE : (epi == 1 ? EPI_GELU : EPI_RESID), g, (hipStream_t)stream);
 }
 
-extern "C" int wseg_debug_gemm_out_is_mx(int32_t dtype, int32_t M, int32_t N, int32_t K) { return wseg::gemm_out_is_mx(dtype, M, N, K) ? 1 : 0; }
+extern "C" int wseg_debug_gemm_out_is_mx(int32_t dtype, int32_t M, int32_t N, int32_t K) {
+  return wseg::gemm_out_is_mx(dtype, M, N, K, (size_t)1 << 40) ? 1 : 0;      // wseg_debug_gemm with a workspace that never limits the split
+}
 
 extern "C" int wseg_debug_gemm_resid_ln(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, const void* W, const void* bias,
                                         void* x, const void* gamma, const void* beta, void* y, void* splitk_ws, size_t splitk_ws_bytes,

@@ -75,7 +75,8 @@ struct GemmArgs {
 // (K % 32 == 0 in the split-precision modes).
 int launch_gemm(int dtype, EpiKind epi, const GemmArgs& g, hipStream_t s);
 // WSEG_F16M6: does an EPI_STORE / EPI_GELU launch of this (logical) shape write M6 rows (true) or hi | lo rows (false)?
-bool gemm_out_is_mx(int dtype, int M, int N, int K);
+// splitk_ws_bytes: the split-K workspace the launch will be given (0: none) — the skinny family writes M6 rows when it splits K
+bool gemm_out_is_mx(int dtype, int M, int N, int K, size_t splitk_ws_bytes = 0);
 // Split-K partial sums only (bf16 decoder rows): part[z][m_pad][N] fp32 in g.splitk_ws, no epilogue.  The consumer
 // kernel (decoder self-/cross-attention) finishes the reduction itself.  Returns false in *ok when the shape is not
 // served by the skinny family (caller falls back to launch_gemm).

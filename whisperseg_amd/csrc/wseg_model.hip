@@ -303,7 +303,7 @@ int run_decoder_step(wseg_model* m, DecPlan& p, char* mxa, bool want_logits, hip
   EpiParams e;
   // WSEG_F16M6: LayerNorm outputs (dy) and attention outputs (dattn) are M6 rows already; the FFN hidden (dh) is when its GEMM
   // ran on a large-tile kernel (a_mx: the operand needs no conversion)
-  const bool dh_mx = gemm_out_is_mx(gdt, R, ffn, d);
+  const bool dh_mx = gemm_out_is_mx(gdt, R, ffn, d, p.splitk_bytes);
   auto gemm_resid_ln = [&](const void* A, int K, const void* Wt, const void* bias, const void* g_, const void* b_, bool a_mx) -> int {
     if (!a_mx) WSEG_TRY(to_mx(m, A, R, K, mxa, s));
     GemmArgs g;
