@@ -1654,6 +1654,8 @@ template <typename T> static GemmArgs kernel_view(const GemmArgs& g0) {
   return g;
 }
 
+template <typename T> static int launch_pp_splitk(const GemmArgs& g, int S, hipStream_t s);
+
 static bool skinny_split_writes_mx(int N) {
   static const bool off = getenv("WSEG_NO_MX_REDUCE") != nullptr;      // A/B knob
   return !off && N % 32 == 0;
@@ -1697,6 +1699,37 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
     if (big256 && g.N % 256 == 0 && nt256 >= 192 && !ragged256) {
       const int ntm = cdiv(g.M, 256), ntiles = ntm * (g.N / 256);
       static const bool pingpong = getenv("WSEG_GEMM_NO_PP") == nullptr;   // ping-pong kernel by default (tuning knob)
+      // WSEG_F16M6, M6-row outputs, between one and two rounds of 256x256 tiles (decoder fc1 at 4 096 rows: 320 tiles on 256 CUs — the
+      // second round runs on a quarter of the chip): the columns that fill ONE round go through the kernel as usual; the remaining
+      // column tiles are multiplied as split-K copies that fill the chip once more for 1 / S of the K range, and the 8-column
+      // reduction writes their M6 rows.
+      if constexpr (IsMx<T>::v && (EPI == EPI_STORE || EPI == EPI_GELU)) {
+        static const bool tail_split = getenv("WSEG_NO_TAIL_SPLIT") == nullptr;      // A/B knob
+        const int ntn = g.N / 256, full_cols = n_cu / ntm, pairs = g.K / 128;
+        if (tail_split && pingpong && rounds256 == 2 && g.splitk_ws && full_cols >= 1 && full_cols < ntn && g.K >= 256) {
+          const int rem_tiles = (ntn - full_cols) * ntm, n1 = full_cols * 256, n2 = g.N - n1;
+          int S = n_cu / rem_tiles;
+          while (S >= 2 && ((rem_tiles * S) % 8 || pairs / S < 2 || (size_t)S * g.M * n2 * sizeof(float) > g.splitk_ws_bytes)) --S;
+          if (S >= 2 && rem_tiles * S * 4 >= n_cu * 3) {
+            int grid = ntm * full_cols < n_cu ? ntm * full_cols : n_cu;
+            grid &= ~7;
+            hipLaunchKernelGGL((gemm_h16_pp_kernel<T, EPI, false>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, n1, g.K, g.ep, ntm,
+                               group_m, 1);
+            GemmArgs g2 = g;
+            g2.W = W + (size_t)n1 * g.ldw;
+            g2.N = n2;
+            WSEG_TRY_(launch_pp_splitk<T>(g2, S, s));
+            typedef typename IO<T>::P PT;
+            EpiParams e3 = g.ep;
+            if (e3.bias) e3.bias = (const PT*)g.ep.bias + n1;
+            e3.out = (char*)g.ep.out + (size_t)(n1 >> 6) * 256;      // M6 rows: 256 bytes per 64 logical columns; ldc stays the full row
+            hipLaunchKernelGGL((splitk_reduce8_kernel<EPI, T>), dim3(cdiv(g.M * (n2 / 8), 256)), dim3(256), 0, s, g.splitk_ws, S, g.M, g.M, n2, e3);
+            if (e1) (void)hipEventRecord(e1, s);
+            WSEG_LAUNCH_CHECK();
+            return WSEG_OK;
+          }
+        }
+      }
       // (Measured and dropped, r04: the generic kernel as 4 waves x 128x128 wave tiles, one wave per SIMD — a third fewer fragment
       // reads per MFMA, but with nothing to hide its per-K-tile barriers behind: 640 against 1 080 TFLOP/s on the encoder shapes.)
       if (pingpong && g.K >= 128) {
