@@ -9,9 +9,10 @@ RCCL) unless it is already running under one (RANK / WORLD_SIZE in the environme
 One "step" = one pass of the whole hot path over one batch of synthetic windows per GPU: PCM already
 resident in HBM -> log-mel kernels -> Whisper encoder -> cross-K/V -> beam-search decode (libwseg) ->
 token ids to the host -> detokenise + regex parse (the CPU epilogue).  Workload (BASELINE.json metric):
-whisperseg-large geometry (1550 M), 30 s windows, in the split-precision mode `bf16x3` — bf16 MFMA tiles on hi + lo operand pairs
-(three MFMAs per product), fp32 everywhere else: the fastest mode that MEETS the north-star tolerance (200 / 200 recordings of
-the parity sweep identical to the reference's fp32 rows; plain bf16: 170 / 200, reported under `extra.plain_16bit_modes` and
+whisperseg-large geometry (1550 M), 30 s windows, in the mixed split-precision mode `f16m6` (the product default) — operands as
+hi + lo IEEE-half pairs, hi x hi on the f16 MFMA tiles and both cross terms in one block-scaled fp6 MX MFMA, fp32 everywhere else:
+the fastest mode that MEETS the north-star tolerance (200 / 200 recordings of the parity sweep identical to the reference's fp32
+rows; `bf16x3` / `f16x3` under `extra.other_tolerance_meeting_modes`; plain bf16: 170 / 200, under `extra.plain_16bit_modes`,
 labelled as outside the tolerance) — (spec_time_step 0.03 @ 16 kHz, 480 000 samples,
 SURVEY §8d), by default 1024 concurrent windows (8 h 32 min of audio) per GPU per step — the engine's default slot count,
 i.e. how a long queue of clips is actually decoded; sharded weakly: every GPU gets its own 1024 windows; `--windows 256`
@@ -23,7 +24,7 @@ windows per GPU); the only exchange is the all_gather of token ids to every rank
 
 The timed configuration is CHECKED, not only timed (`check` in the JSON; the bench exits non-zero when it fails):
 every step must produce the same tokens (determinism), and the first-step logits / tokens of a subset of the
-windows are compared with the exact-parity f32 mode of the same kernels on the same bf16-rounded weights.
+windows are compared with the exact-parity f32 mode of the same kernels on the same weights.
 
 Prints ONE JSON line (rank 0) with the contract keys plus `roofline`, `cpu_baseline`, `check` and `extra`
 (the other SURVEY §8d lines: 128 generated tokens, 10 s / 2.5 s windows, the front-end's HBM rate, a one-hour
@@ -381,9 +382,11 @@ def main(argv=None, backend=make_backend):
     me = {"rank": rank, "local_rank": local_rank, "device": str(device),
           "name": torch.cuda.get_device_name(device) if on_gpu else "cpu", "pid": os.getpid()}
     ranks = [me]
+    ranks_seen = 1
     if distributed:
         ranks = [None] * world
         torch.distributed.all_gather_object(ranks, me)
+        ranks_seen = torch.distributed.get_world_size()      # the size of the group the collectives above actually ran in
 
     roofline = None
     if on_gpu and not args.no_roofline and args.dtype != "f32":
@@ -412,6 +415,15 @@ def main(argv=None, backend=make_backend):
         except Exception as exc:
             cpu = {"error": f"{type(exc).__name__}: {exc}"[:500]}
 
+    # Slot-count invariance of the tokens: ASSERTED by the GPU tests on the tested geometries (tiny model 1 / 5 / 8 /
+    # 23 slots, large geometry 256 vs 1 024 slots) in the exact and the split modes, and MEASURED here on 4 096 random-weight windows
+    # (256 vs the timed slot count): anything below 1.0 in those modes fails the check — their GEMM plans follow the row count, so
+    # the property is empirical, not structural.
+    if check is not None and extra and isinstance(extra.get("inflight_batching"), dict) and args.dtype in ("f32", "f16m6", "f16x3", "bf16x3"):
+        agree = extra["inflight_batching"].get("windows_with_tokens_identical_across_slot_counts")
+        if agree is not None:
+            check["slot_count_invariance"] = {"windows_identical": agree, "required": 1.0}
+            check["ok"] = bool(check["ok"] and agree >= 1.0)
     failed = bool(check and not check["ok"])
     if rank == 0:
         out = {
@@ -430,7 +442,7 @@ def main(argv=None, backend=make_backend):
                        "windows_per_gpu": W, "window_slots": slots, "beams": args.beams, "gen_tokens": args.gen_tokens,
                        "parallelism": f"clip-sharded x{world}"},
             "world_size": world, "collectives": ("RCCL (torch.distributed nccl)" if on_gpu else "gloo") if distributed else None,
-            "ranks": ranks,
+            "ranks": ranks, "rccl_ranks_seen": ranks_seen,      # (gloo ranks in the CPU tests; the key name is the contract)
             "windows_per_s": windows_per_s, "realtime_factor_per_gpu": value / world,
             "stage_ms_last_call": {"encoder": enc_ms, "cross_kv": ckv_ms, "decode": dec_ms, "decode_steps": n_steps},
             "scheduler": sched,
@@ -797,8 +809,10 @@ def extra_lines(args, eng, step, main_in, make_extractor, device, W, slots):
                                                         "tokens_identical_to_batch_by_batch": bool(same)},
                                     "batch_by_batch_audio_sec_per_s": asec / dtb, "batch": W,
                                     "windows_with_tokens_identical_across_slot_counts": agree,
-                                    "note": "in the 16-bit modes a window's tokens may depend on the slot COUNT (GEMM plans follow the row "
-                                            "count), never on its neighbours; identical in f32 mode (tests/test_scheduler_gpu.py)"}
+                                    "note": "plain 16-bit modes: a window's tokens may depend on the slot COUNT (GEMM plans follow the row "
+                                            "count), never on its neighbours.  f32 and split modes: asserted identical on the tested "
+                                            "geometries (tests/test_scheduler_gpu.py, tests/test_large_geometry_gpu.py) and required to be 1.0 "
+                                            "here (check.slot_count_invariance)"}
         # concurrency: 4 x W windows of fixed decode length through W, 2W, 4W slots
         audio_4 = torch.cat([audio] * 4)
         st_4 = (torch.arange(4 * W, dtype=torch.int64) * wl).to(device)

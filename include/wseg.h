@@ -38,7 +38,8 @@ typedef enum {
 } wseg_status;
 
 typedef enum {
-  WSEG_F32 = 0,             /* exact-parity mode: fp32 storage, VALU GEMM with fmaf chains in k order */
+  WSEG_F32 = 0,             /* exact-parity mode: fp32 storage; GEMMs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4_f32 are
+                             * k-ordered fmaf chains bit for bit: tested identical to the VALU kernels they replaced) */
   WSEG_BF16 = 1,            /* bfloat16 storage + MFMA, fp32 accumulation */
   WSEG_F16 = 2,             /* IEEE half storage + MFMA, fp32 accumulation (reference WhisperSegmenterFast: CT2 float16, model.py:691) */
   /* Split-precision modes (the reference's own arithmetic is fp32 everywhere, model.py:655-666): fp32 storage and fp32

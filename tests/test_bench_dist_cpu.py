@@ -41,6 +41,24 @@ def test_gpus_2_self_launches_two_ranks():
     assert out["config"]["windows_per_gpu"] == 5
 
 
+@pytest.mark.timeout(600)
+def test_gpus_8_first_contact_shape():
+    """The driver's 8-GPU scaling run is the first time RCCL meets more than one rank (no multi-GPU box is available to the
+    builder): everything that does not need a GPU is driven here at world size 8 — port selection and the self-launch of 8 ranks,
+    the WORLD_SIZE check, rank 0's weights reaching all 8 ranks, 8 x per-rank rows through the token all_gather, the 8-entry
+    `ranks` list, the rank-0-only self-check beside 7 ranks waiting at the final barrier, and `rccl_ranks_seen`."""
+    args = [a for a in ARGS] + ["--check-on-cpu", "--check-windows", "3"]
+    res = subprocess.run([sys.executable, DRIVER, "--gpus", "8"] + args, env=clean_env(), capture_output=True, text=True, timeout=560)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = last_json(res.stdout)
+    assert out["n_gpus"] == 8 and out["world_size"] == 8 and out["rccl_ranks_seen"] == 8 and out["scaling"] == "weak"
+    assert sorted(r["rank"] for r in out["ranks"]) == list(range(8)) and len({r["pid"] for r in out["ranks"]}) == 8
+    assert sorted(r["local_rank"] for r in out["ranks"]) == list(range(8))
+    assert out["config"]["windows_per_gpu"] == 5 and out["config"]["parallelism"] == "clip-sharded x8"
+    assert out["value"] == pytest.approx(8 * 5 * 1.0 * 2 / (out["ms_per_step"] * 2 / 1e3), rel=1e-6)
+    assert out["check"]["ok"] and out["check"]["deterministic"]      # the stub decodes 15 + 0 only once rank 0's weights arrived everywhere
+
+
 @pytest.mark.timeout(300)
 def test_single_process_default_and_mismatch():
     res = subprocess.run([sys.executable, DRIVER] + ARGS, env=clean_env(), capture_output=True, text=True, timeout=120)

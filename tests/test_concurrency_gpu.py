@@ -23,19 +23,32 @@ SHAPES = [  # name, M, N, K, epilogue (0 store, 1 GELU, 2 fp32 residual)
 ]
 
 
-@pytest.mark.parametrize("dtype_id,td", [(1, torch.bfloat16), (2, torch.float16)])
+@pytest.mark.parametrize("dtype_id,td", [(1, torch.bfloat16), (2, torch.float16), (5, None)], ids=["bf16", "f16", "f16m6"])
 @pytest.mark.parametrize("name,m,n,k,epi", SHAPES, ids=[s[0] for s in SHAPES])
 def test_gemm_is_bit_stable_under_a_hog_stream(gpu_lib, dtype_id, td, name, m, n, k, epi):
+    """dtype 5 = f16m6, the product default: its 256x256 kernel interleaves compiler-scheduled half MFMAs with inline-assembly MX
+    MFMAs (wseg_gemm.hip, mfma_mx6_asm) on M6 operand rows."""
     from whisperseg_amd import _lib
     lib = gpu_lib
     g = torch.Generator(device="cuda").manual_seed(7)
     mp = (m + 255) // 256 * 256
-    A = (torch.rand(mp, k, device="cuda", generator=g) * 2 - 1).to(td)
-    W = (torch.rand(n, k, device="cuda", generator=g) * 2 - 1).to(td)
-    bias = torch.rand(n, device="cuda", generator=g).to(td)
-    od = torch.float32 if epi == 2 else td
-    res = torch.rand(mp, n, device="cuda", generator=g).to(od)
-    out = torch.empty(mp, n, device="cuda", dtype=od)
+    if dtype_id == 5:
+        from whisperseg_amd.engine import split_operand
+        As = split_operand(torch.rand(mp, k, device="cuda", generator=g) * 2 - 1, torch.float16)
+        Ws = split_operand(torch.rand(n, k, device="cuda", generator=g) * 2 - 1, torch.float16)
+        A, W = torch.empty_like(As), torch.empty_like(Ws)
+        _lib.check(lib.wseg_convert_operand(As.data_ptr(), A.data_ptr(), mp, k, 0, _lib.stream_ptr()))
+        _lib.check(lib.wseg_convert_operand(Ws.data_ptr(), W.data_ptr(), n, k, 1, _lib.stream_ptr()))
+        bias = torch.rand(n, device="cuda", generator=g)
+        res = torch.rand(mp, n, device="cuda", generator=g)
+        out = torch.empty(mp, n if epi == 2 else 2 * n, device="cuda", dtype=torch.float32 if epi == 2 else torch.int16)
+    else:
+        A = (torch.rand(mp, k, device="cuda", generator=g) * 2 - 1).to(td)
+        W = (torch.rand(n, k, device="cuda", generator=g) * 2 - 1).to(td)
+        bias = torch.rand(n, device="cuda", generator=g).to(td)
+        od = torch.float32 if epi == 2 else td
+        res = torch.rand(mp, n, device="cuda", generator=g).to(od)
+        out = torch.empty(mp, n, device="cuda", dtype=od)
     ws = torch.empty(128 << 20, dtype=torch.uint8, device="cuda")
     st = _lib.stream_ptr()
 
@@ -64,7 +77,8 @@ def test_gemm_is_bit_stable_under_a_hog_stream(gpu_lib, dtype_id, td, name, m, n
     assert bad == 0, f"{name}: {bad} of {iters} runs differ from the solo result"
 
 
-def test_decode_beside_a_second_stream_is_deterministic_at_large_width(gpu_lib):
+@pytest.mark.parametrize("dtype", ["bf16", "f16m6"])
+def test_decode_beside_a_second_stream_is_deterministic_at_large_width(gpu_lib, dtype):
     """A decode of d_model 1280 while a second stream keeps the CUs busy with load-heavy work: run to run identical and
     identical to the solo result (before the LDS stage-release fix ~15 % of the windows differed when the decoder GEMMs shared
     CUs with another stream's attention loads — found with the round-2 decode lanes, which are gone; the race guard stays)."""
@@ -72,7 +86,7 @@ def test_decode_beside_a_second_stream_is_deterministic_at_large_width(gpu_lib):
     cfg = dict(d_model=D, encoder_attention_heads=20, decoder_attention_heads=20, encoder_layers=2, decoder_layers=6,
                encoder_ffn_dim=F, decoder_ffn_dim=F, vocab_size=51865, num_mel_bins=80, max_source_positions=500,
                max_target_positions=448)
-    eng = Engine.random(cfg, "cuda:0", "bf16")
+    eng = Engine.random(cfg, "cuda:0", dtype)
     W = 128
     feats = torch.randn(W, 80, 1000, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)) * 0.5
     prompt, eos = [50258, 50259, 50363], 50257

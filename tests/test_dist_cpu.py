@@ -258,7 +258,9 @@ def small_worker(rank, world, port, q, pool_windows):
     seg = FakeSegmenter()
     audios = make_small() if rank == 0 else None
     srs = [b[0] for b in SMALL] if rank == 0 else None
-    kw = small_kwargs(pool_windows=pool_windows) if rank == 0 else dict(batch_size=2, max_length=L, pool_windows=pool_windows)
+    # only rank 0 names the grouping cap (the function's contract: other ranks may pass None for the parameters); the cap travels
+    # with the broadcast metadata, else the ranks would form different groups and hang in the per-group collectives
+    kw = small_kwargs(pool_windows=pool_windows) if rank == 0 else dict(batch_size=2, max_length=L)
     res = wd.segment_batch_distributed(seg, audios, srs, **kw)
     q.put((rank, res, seg.pcm_samples_seen))
     dist.barrier()

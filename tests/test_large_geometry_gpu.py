@@ -203,9 +203,13 @@ def full_large():
     return Engine.random(large_cfg(32), "cuda:0", "bf16", seed=0)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f16m6"])
 @pytest.mark.parametrize("n", [8, 120])
-def test_full_large_properties(gpu_lib, full_large, n):
-    eng = full_large
+def test_full_large_properties(gpu_lib, full_large, n, dt):
+    """configs[2] (large x 8) and the single-GPU share of configs[3] (120 windows) at full depth, in plain bf16 and in the product
+    default f16m6 (same bf16-representable weights)."""
+    from whisperseg_amd.engine import Engine
+    eng = full_large if dt == "bf16" else Engine(full_large.geo, {k: v.float() for k, v in full_large.weights.items()}, full_large.device, dt)
     x = feats(n, seed=7 + n)
     a = gen(eng, x, 4, 3 + 12, return_first_logits=True)
     b = gen(eng, x, 4, 3 + 12, return_first_logits=True)

@@ -99,6 +99,26 @@ def test_generate_tokens_f32_random_weights(gpu_lib, nb, ml, dtype):
         assert a == b, (i, a, b)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16x3", "f16m6"])
+@pytest.mark.parametrize("nb", [5, 8])
+def test_five_to_eight_beams(gpu_lib, nb, dtype):
+    """num_beams 5..8 (MAX_BEAMS = 8): the 24-bit cross-K/V kernel exists for up to 4 beams, above that cross-attention runs the
+    general fp32-K/V kernel — in the product default f16m6 its hi | lo output rows are converted to M6 rows for the co-proj GEMM
+    (the default mode used to reject these calls after the encoder had already run).  Token-exact vs the oracle."""
+    cfg = hf_cfg()
+    rc, sd, eng = make(cfg, dtype)
+    x = feats(3)
+    gp = gen_params(nb, 16)
+    want = R.generate(sd, rc, x, gp)
+    toks, lens = eng.generate(x.cuda(), PROMPT, EOS, EOS, max_length=16, num_beams=nb, suppress_tokens=gp.suppress_tokens,
+                              begin_suppress_tokens=gp.begin_suppress_tokens)
+    toks, lens = toks.cpu().numpy(), lens.cpu().numpy()
+    for i in range(3):
+        a = R.canonical(want[i].tolist(), 3, EOS, PROMPT)
+        b = R.canonical(toks[i, :lens[i]].tolist(), 3, EOS, PROMPT)
+        assert a == b, (i, a, b)
+
+
 def test_real_vocab_logits_bf16(gpu_lib):
     """Whisper's real vocabulary size (51865, not a tile multiple) through the tied LM head."""
     cfg = hf_cfg(vocab=51865)
@@ -139,8 +159,41 @@ def test_base_geometry_bf16(gpu_lib):
     assert lens.tolist() == [5, 5]
 
 
+def test_base_geometry_32_windows_default_mode(gpu_lib):
+    """BASELINE configs[1] as the product runs it: whisperseg-base geometry x 32 windows x 4 beams in the default mode f16m6.
+    The oracle (torch-CPU fp32) is run on a subset of the windows (windows are independent): encoder output and first-step
+    logits within the split modes' bound, beam sequences token-exact; the other windows through the size-independent
+    properties (beams equal at step 1, the same window gives the same tokens wherever it sits in the batch)."""
+    cfg = hf_cfg(d=512, heads=8, layers=6, ffn=2048, vocab=51865)
+    rc, sd, eng = make(cfg, "f16m6", seed=11)
+    x = feats(32, seed=17)
+    sub = [0, 13, 31]
+    prompt, eos = [50258, 50259, 50363], 50257
+    gp = R.GenParams(prompt=prompt, eos_token_id=eos, pad_token_id=eos, max_length=8, num_beams=4)
+    want_enc = R.encoder_forward(sd, rc, x[sub])
+    got_enc = eng.encode(x.cuda()).float().cpu()
+    assert (got_enc[sub] - want_enc).abs().max().item() <= 1e-3 * max(1.0, want_enc.abs().max().item())
+    want_seq, want = R.generate(sd, rc, x[sub], gp, return_first_logits=True)
+    toks, lens, got = eng.generate(x.cuda(), prompt, eos, eos, max_length=8, num_beams=4, return_first_logits=True)
+    got, toks, lens = got.cpu(), toks.cpu(), lens.cpu()
+    rows = [4 * i + b for i in sub for b in range(4)]
+    scale = max(1.0, want.abs().max().item())
+    assert (got[rows] - want).abs().max().item() <= 2e-3 * scale
+    assert torch.nn.functional.cosine_similarity(got[rows], want, dim=1).min().item() > 0.999999
+    assert torch.equal(got[0::4], got[1::4]) and torch.equal(got[0::4], got[3::4])
+    for k, i in enumerate(sub):
+        a = R.canonical(want_seq[k].tolist(), 3, eos, prompt)
+        b = R.canonical(toks[i, :lens[i]].tolist(), 3, eos, prompt)
+        if a != b:      # flat random-weight logits: a differing beam result must be a near-tie under the oracle's own scores
+            from test_large_geometry_gpu import assert_equally_scored
+            assert_equally_scored(sd, rc, x[i:i + 1], gp, toks[i, :lens[i]].tolist(), want_seq[k].tolist(), ("base32", i))
+    perm = torch.randperm(32, generator=torch.Generator().manual_seed(2))
+    toks_p, lens_p = eng.generate(x[perm].cuda(), prompt, eos, eos, max_length=8, num_beams=4)
+    assert torch.equal(toks_p.cpu(), toks[perm]) and torch.equal(lens_p.cpu(), lens[perm])
+
+
 @pytest.mark.parametrize("dtype,tol_enc,tol_logit,cos_min", [("bf16", 8e-2, 0.1, 0.999), ("bf16x3", 1e-3, 2e-3, 0.999999),
-                                                             ("f16x3", 1e-3, 2e-3, 0.999999)])
+                                                             ("f16x3", 1e-3, 2e-3, 0.999999), ("f16m6", 1e-3, 2e-3, 0.999999)])
 def test_pingpong_gemm_epilogues_in_the_model_bf16(gpu_lib, dtype, tol_enc, tol_logit, cos_min):
     """50 windows at d=512 / 8 heads / ffn 2048 (2+2 layers): every large GEMM of the path has >= 192 tiles of 256x256, so
     conv2 (+pos-emb), the QKV head split incl. V^T, o-proj / fc2 (residual), fc1 (GELU) and the cross-K/V head split all

@@ -78,7 +78,7 @@ def test_slot_refill_gives_the_same_tokens(gpu_lib, dtype, nb):
         assert torch.equal(tb, t6[lo:lo + 6]) and torch.equal(lb, l6[lo:lo + 6]), (dtype, lo)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f16x3", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "f16x3", "f16m6", "bf16"])
 def test_non_default_stream_and_graph_reuse(gpu_lib, dtype):
     """The call is stream-ordered on the caller's stream; the captured decode-step graph survives calls that differ only in
     per-call data (sampling seed, per-window length caps: both live in device memory / the admission kernel)."""
@@ -106,7 +106,7 @@ def test_non_default_stream_and_graph_reuse(gpu_lib, dtype):
     assert torch.equal(l3, ref_l) and torch.equal(t3, ref_t)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f16x3", "bf16x3", "bf16", "f16"])
+@pytest.mark.parametrize("dtype", ["f32", "f16x3", "bf16x3", "f16m6", "bf16", "f16"])
 def test_default_slot_count_with_a_long_queue(gpu_lib, dtype):
     """1 100 windows (23 distinct recordings repeated) through the engine's default 1 024 slots: copies of a window give the
     same tokens wherever they ran (first batch, refilled slot, drain), in every mode; in f32 mode they also equal the
@@ -120,12 +120,12 @@ def test_default_slot_count_with_a_long_queue(gpu_lib, dtype):
     assert st["n_slots"] == min(DEFAULT_SLOTS, 1100) and st["n_windows"] == 1100
     for i in range(23, 1100):
         assert int(l[i]) == int(l[i % 23]) and torch.equal(t[i], t[i % 23]), (dtype, i)
-    if dtype in ("f32", "f16x3", "bf16x3"):       # ... and in the split-precision modes (23 slots against 1 024: see the refill test)
+    if dtype in ("f32", "f16x3", "bf16x3", "f16m6"):       # ... and in the split-precision modes (23 slots against 1 024: see the refill test)
         ref_t, ref_l = gen(eng, base, 4)
         assert torch.equal(l[:23], ref_l) and torch.equal(t[:23], ref_t)
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f16x3"])
+@pytest.mark.parametrize("dtype", ["bf16", "f16x3", "f16m6"])
 def test_early_stop_executes_few_steps(gpu_lib, dtype):
     """with max_length 448 and EOS after 10-40 tokens the GPU used to run every queued step at full cost."""
     eng = tiny_engine(dtype)
@@ -140,7 +140,7 @@ def test_early_stop_executes_few_steps(gpu_lib, dtype):
     assert eng.last_timing()[3] == steps
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f16x3"])
+@pytest.mark.parametrize("dtype", ["f32", "f16x3", "f16m6"])
 def test_per_window_length_caps(gpu_lib, dtype):
     eng = tiny_engine(dtype)
     x = tiny_feats(9, seed0=700)
@@ -281,7 +281,7 @@ def _units(eng, slots, nb, ml, per):
     return eng.lib.wseg_workspace_bytes_kv(eng.handle, slots, nb, ml, per)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f16x3"])
+@pytest.mark.parametrize("dtype", ["f32", "f16x3", "f16m6"])
 def test_paged_kv_default_pool_equals_full_pool(gpu_lib, dtype):
     """max_length = 448 with the DEFAULT pool (64 positions per slot on average instead of 448 reserved per slot) gives exactly
     the tokens of a fully provisioned pool — paging only changes where a K / V row lives — in a fraction of the workspace."""
@@ -301,12 +301,14 @@ def test_paged_kv_default_pool_equals_full_pool(gpu_lib, dtype):
     assert _units(eng, 23, 4, 448, 0) == _units(eng, 23, 4, 448, 64) >= _units(eng, 23, 4, 64, 0)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16m6"])
 @pytest.mark.parametrize("nb", [1, 4])
-def test_paged_kv_short_pool_preempts_and_still_gives_the_same_tokens(gpu_lib, nb):
+def test_paged_kv_short_pool_preempts_and_still_gives_the_same_tokens(gpu_lib, nb, dtype):
     """A pool far too small for the windows in flight: the scheduler preempts the youngest slot (device-side abort, window
     re-queued, decoded again from scratch later) instead of failing, the oldest window always progresses, and every window
-    still gets exactly the tokens of the uncontended run (f32 mode: bit-exact whatever the slot history)."""
-    eng = tiny_engine("f32")
+    still gets exactly the tokens of the uncontended run (f32 mode: bit-exact whatever the slot history; the product default
+    f16m6: abort + re-admission run through the M6-row operand writers, tokens asserted equal as in the refill test)."""
+    eng = tiny_engine(dtype)
     x = tiny_feats(23)
     ref_t, ref_l = gen(eng, x, nb, 448, kv_positions=448)
     longest = int(ref_l.max())

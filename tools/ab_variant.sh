@@ -1,6 +1,6 @@
 #!/bin/bash
 # same-box A/B of experiment builds of the library (python -m whisperseg_amd.build --variant TAG -D...) on the GEMM shapes:
-#   tools/ab_ilv.sh TAG [dtype ...]
+#   tools/ab_variant.sh TAG [dtype ...]
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; shift
 DTS=${@:-f16m6}

@@ -5,15 +5,22 @@
 The shared library lands in whisperseg_amd/lib/libwseg.so; it is git-ignored but travels with the
 gpurun snapshot.  hipcc cross-compiles without a GPU.
 
+Every source is compiled with -save-temps: the device assembly hipcc leaves behind is digested by tools/isa_lint.py into
+build/<name>.lint.json (per kernel: VGPRs, AGPRs, SGPRs, LDS, scratch bytes, spill counts; hazards around inline-asm MFMAs) and
+deleted; tests/test_isa_lint.py asserts on the digests, i.e. on the very objects the library is linked from.
+
 --stamps N builds a SECOND library, lib/libwseg_stamps<N>.so, with -DWSEG_STAMPS=N: decode kernel N (1 self-attention,
 2 packed cross-attention, 3 24-bit cross-attention) records s_memrealtime stamps at its phase boundaries (tools/stamps.py
 loads it through WSEG_LIB).  The product library never carries them.
 --variant TAG -D... builds lib/libwseg_<TAG>.so with the extra defines: A/B timing of an experiment knob against the product
 library on one box (WSEG_LIB=whisperseg_amd/lib/libwseg_<TAG>.so python tools/gemm_bench.py ...).
 """
+import json
 import os
+import shutil
 import subprocess
 import sys
+import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -50,15 +57,33 @@ def build(force=False, verbose=True, stamps=0, variant="", defines=()):
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
-        if force or _newer(s, o) or any(_newer(h, o) for h in headers):
+        if force or _newer(s, o) or any(_newer(h, o) for h in headers) or not os.path.exists(o[:-2] + ".lint.json"):
             jobs.append((s, o))
 
     def cc(job):
         s, o = job
-        cmd = [HIPCC] + flags + ["-c", s, "-o", o]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        name = os.path.basename(o)[:-2]
+        tmp = tempfile.mkdtemp(prefix="wseg_" + name + "_", dir=objdir)
+        try:
+            to = os.path.join(tmp, name + ".o")
+            cmd = [HIPCC] + flags + ["-save-temps=obj", "-c", s, "-o", to]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            asm = [f for f in os.listdir(tmp) if f.endswith("gfx950.s")]
+            digest = {"kernels": {}, "findings": [], "error": "no device assembly"}
+            if asm:
+                sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+                try:
+                    import isa_lint
+                    digest = isa_lint.analyze(os.path.join(tmp, asm[0]))
+                finally:
+                    sys.path.pop(0)
+            with open(o[:-2] + ".lint.json", "w") as f:
+                json.dump(digest, f)
+            os.replace(to, o)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
 
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:

@@ -4,7 +4,22 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include "../../include/wseg.h"
+
+// Experiment knobs.  The PRODUCT library reads no tuning environment variable: the macros below fold to their defaults.  An A/B
+// build keeps them live:  python -m whisperseg_amd.build --variant knobs -DWSEG_KNOBS=1  (tools/ab_variant.sh).  What the product
+// does read are the TEST knobs that select an alternative kernel computing the same bits (WSEG_F32_GEMM, WSEG_F32_ATTN,
+// WSEG_CROSS_NO_PK, WSEG_LOGMEL_GENERIC, WSEG_NO_GRAPH: tests compare both sides on the shipped library).
+#ifdef WSEG_KNOBS
+#define WSEG_KNOB_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#define WSEG_KNOB_SET(name) (getenv(name) != nullptr)
+#define WSEG_KNOB_IS(name, val) (getenv(name) && !strcmp(getenv(name), val))
+#else
+#define WSEG_KNOB_INT(name, dflt) (dflt)
+#define WSEG_KNOB_SET(name) false
+#define WSEG_KNOB_IS(name, val) false
+#endif
 
 namespace wseg {
 

@@ -61,6 +61,8 @@ int launch_dec_self_attn(int dtype, const DecodeState& st, const void* q, void* 
 // q_part != nullptr: the query arrives as split-K partials [z][m_pad][d] (+ q_bias, scaled by `scale`)
 int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const void* ck, const void* cv, void* out,
                           int H, int Tk, int d, const PartialInfo* q_part, const void* q_bias, float scale, hipStream_t s);
+// WSEG_F16M6: M6 rows (24-bit K / V kernel, <= 4 beams) or hi | lo rows that the caller converts (5..8 beams)?
+bool dec_cross_attn_writes_mx(int dtype, int nb);
 // log-softmax + suppress + running score -> top-2nb per row (beam) / argmax of the processed logits (greedy)
 // scratch: part_val/part_idx [R][16][16], part_stat [R][16][2]
 int launch_row_topk(const DecodeState& st, const float* logits, float* part_val, int* part_idx, float* part_stat, hipStream_t s);

@@ -305,8 +305,10 @@ __global__ __launch_bounds__(64, 8) void dec_self_attn_kernel(DecodeState st, co
 // HBM-bound (128 KiB of K/V per workgroup).  8 lanes cover one 128-byte K/V row (16 B each), so a wave
 // reads 8 consecutive rows = 1 KiB fully coalesced per instruction and 4 rows are in flight per lane.
 // ------------------------------------------------------------------------------------------------
+// (NB = 8, beams 5..8: 64 query registers per lane — two workgroups per CU instead of four; under the 128-register cap that
+// instantiation spilled 350 bytes per lane)
 template <typename T, typename TO, int NB>
-__global__ __launch_bounds__(256, 4) void dec_cross_attn_kernel(DecodeState st, const T* __restrict__ q, const T* __restrict__ ck,
+__global__ __launch_bounds__(256, NB > 4 ? 2 : 4) void dec_cross_attn_kernel(DecodeState st, const T* __restrict__ q, const T* __restrict__ ck,
                                                              const T* __restrict__ cv, void* __restrict__ out, int H, int Tk, int d,
                                                              PartialInfo pi, const T* __restrict__ q_bias, float scale) {
   __shared__ float sc[NB][512];
@@ -1206,17 +1208,19 @@ static void launch_cross_t(const DecodeState& st, const void* q, const void* ck,
 #undef WSEG_CA
 }
 bool x3_cross_kv24() {
-  static const bool v = !(getenv("WSEG_X3_CKV") && !strcmp(getenv("WSEG_X3_CKV"), "f32"));
+  static const bool v = !WSEG_KNOB_IS("WSEG_X3_CKV", "f32");      // (attribution knob, variant builds)
   return v;
 }
+// WSEG_F16M6: does the cross-attention write its output (the co-proj GEMM's operand) as M6 rows?  The 24-bit K / V kernel does (it
+// exists for up to 4 beams); 5..8 beams run the general fp32-K/V kernel, which writes hi | lo rows that the caller converts.
+bool dec_cross_attn_writes_mx(int dtype, int nb) { return dtype == WSEG_F16M6 && x3_cross_kv24() && nb <= 4; }
 
 int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const void* ck, const void* cv, void* out, int H, int Tk, int d,
                           const PartialInfo* q_part, const void* q_bias, float scale, hipStream_t s) {
   if (Tk > 512) { set_error("cross-attention: %d encoder positions > 512", Tk); return WSEG_ERR_INVALID; }
   PartialInfo pi;
   if (q_part) pi = *q_part;
-  const bool m6 = dtype == WSEG_F16M6;      // cross-attention output (the co-proj GEMM's operand) as M6 rows: 24-bit K / V kernel only
-  if (m6 && !(x3_cross_kv24() && st.nb <= 4)) { set_error("f16m6: cross-attention needs the 24-bit K/V kernel (beams <= 4)"); return WSEG_ERR_INVALID; }
+  const bool m6 = dtype == WSEG_F16M6;      // M6-row output from the 24-bit K / V kernel only (dec_cross_attn_writes_mx)
   if ((dtype == WSEG_BF16X3 || dtype == WSEG_F16X3 || m6) && x3_cross_kv24() && st.nb <= 4) {
     dim3 grid(st.W * H), block(256);
 #define WSEG_K24(TO_, NB_) hipLaunchKernelGGL((dec_cross_attn_k24_kernel<TO_, NB_>), grid, block, 0, s, st, (const float*)q, (const unsigned char*)ck, (const unsigned char*)cv, out, H, Tk, d, pi, (const float*)q_bias, scale)
@@ -1237,7 +1241,7 @@ int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const
   } else if (dtype == WSEG_BF16) launch_cross_t<bf16_t, bf16_t>(st, q, ck, cv, out, H, Tk, d, pi, q_bias, scale, s);
   else if (dtype == WSEG_F16) launch_cross_t<f16_t, f16_t>(st, q, ck, cv, out, H, Tk, d, pi, q_bias, scale, s);
   else if (dtype == WSEG_BF16X3) launch_cross_t<float, X3<bf16_t>>(st, q, ck, cv, out, H, Tk, d, pi, q_bias, scale, s);
-  else if (dtype == WSEG_F16X3) launch_cross_t<float, X3<f16_t>>(st, q, ck, cv, out, H, Tk, d, pi, q_bias, scale, s);
+  else if (dtype == WSEG_F16X3 || m6) launch_cross_t<float, X3<f16_t>>(st, q, ck, cv, out, H, Tk, d, pi, q_bias, scale, s);      // (f16m6, 5..8 beams: hi | lo rows)
   else launch_cross_t<float, float>(st, q, ck, cv, out, H, Tk, d, pi, q_bias, scale, s);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;

@@ -172,6 +172,9 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
   float m_run = -1.0e30f, l_run = 0.f;
 
   const int n_tiles = (T + 63) / 64;
+  // per-lane byte offsets of the MFMA fragment reads (see the key-block loop)
+  const unsigned kfrag = (unsigned)(qi * 128 + ((g2 ^ ((qi >> 1) & 7)) << 4));
+  const unsigned vfrag = (unsigned)(qi * 128 + ((g2 ^ ((qi >> 1) & 15)) << 3));
   // K tile and V^T tile (each 8 KiB = 512 16-byte chunks, 2 per thread; rows are padded to Tp, so a tile is always readable).
   // The NEXT tile is requested while the current one is multiplied: K by LDS-DMA straight into the other sK buffer (the
   // swizzle is applied on the source side: LDS slot c holds global slot (c & 7) ^ ((row >> 1) & 7) of its row), V^T into 8
@@ -233,13 +236,21 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
-      const int krow = sub * 32 + qi;
+      // fragment addresses: row sub*32 + qi, 16-byte slot (2 hs + g2) ^ ((row >> 1) & 7)  ==  sub*4096 + (kfrag ^ (hs << 5)) bytes.  One
+      // lane offset per operand, made opaque once per key block so that the variants are v_xor'ed with a constant at the read instead
+      // of living in 8 + 16 loop-invariant registers: under the 168-register cap of the SPLIT instantiations the compiler spilled
+      // three of them and reloaded them in every key block behind an s_waitcnt vmcnt(0) — the K / V^T prefetch of the next tile
+      // drained three times per block (r05, found by tools/isa_lint.py: scratch accesses inside a loop)
+      unsigned kfo = kfrag, vfo = vfrag;
+      asm volatile("" : "+v"(kfo), "+v"(vfo));
+      const char* cKs = (const char*)cK + sub * 4096;
+      [[maybe_unused]] const char* cKls = (const char*)sKl[kt & 1] + sub * 4096;
 #pragma unroll
       for (int hs = 0; hs < 4; ++hs) {
-        const bf16x8 kf = *(const bf16x8*)(cK + krow * 64 + (((hs * 2 + g2) ^ ((krow >> 1) & 7)) << 3));
+        const bf16x8 kf = *(const bf16x8*)(cKs + (kfo ^ (hs << 5)));
         s = H16<HT>::mfma32(kf, qf[hs], s);
         if constexpr (SPLIT) {
-          const bf16x8 kfl = *(const bf16x8*)(sKl[kt & 1] + krow * 64 + (((hs * 2 + g2) ^ ((krow >> 1) & 7)) << 3));
+          const bf16x8 kfl = *(const bf16x8*)(cKls + (kfo ^ (hs << 5)));
           s = H16<HT>::mfma32(kf, qfl[hs], s);
           s = H16<HT>::mfma32(kfl, qf[hs], s);
         }
@@ -258,8 +269,10 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __expf(m_run - m_new);
       float ps = 0.f;
+      // exp(s - m) = exp2(s log2e - m log2e): one v_fma + v_exp per probability (__expf: v_sub, v_mul, v_exp)
+      const float m_l2 = -m_new * 1.4426950408889634f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - m_new); ps += s[r]; }
+      for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], 1.4426950408889634f, m_l2)); ps += s[r]; }
       ps += lane_xor<32>(ps);
       l_run = l_run * alpha + ps;
       m_run = m_new;
@@ -279,18 +292,18 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
           for (int j = 0; j < 4; ++j)
             pfl.u[j] = H16<HT>::pack(s[8 * mm + 2 * j] - H16<HT>::lo(pf.u[j]), s[8 * mm + 2 * j + 1] - H16<HT>::hi(pf.u[j]));
         }
-        const int gran = sub * 8 + 4 * mm + g2;
+        // V^T row hd = ht*32 + qi, 8-byte granule (sub*8 + 4 mm + g2 [+ 2]) ^ ((hd >> 1) & 15)  ==  ht*4096 + (vfrag ^ (c << 3)) bytes
+        const unsigned va = vfo ^ ((sub * 8 + 4 * mm) << 3), vb = vfo ^ ((sub * 8 + 4 * mm + 2) << 3);
 #pragma unroll
         for (int ht = 0; ht < 2; ++ht) {
-          const int hd = ht * 32 + qi, sw = (hd >> 1) & 15;
           union { bf16x8 v; uint2 u[2]; } vf, vfl;
-          vf.u[0] = *(const uint2*)(sV + hd * 64 + ((gran ^ sw) << 2));
-          vf.u[1] = *(const uint2*)(sV + hd * 64 + (((gran + 2) ^ sw) << 2));
+          vf.u[0] = *(const uint2*)((const char*)sV + ht * 4096 + va);
+          vf.u[1] = *(const uint2*)((const char*)sV + ht * 4096 + vb);
           if (ht == 0) o0 = H16<HT>::mfma32(vf.v, pf.v, o0);
           else o1 = H16<HT>::mfma32(vf.v, pf.v, o1);
           if constexpr (SPLIT) {
-            vfl.u[0] = *(const uint2*)(sVl + hd * 64 + ((gran ^ sw) << 2));
-            vfl.u[1] = *(const uint2*)(sVl + hd * 64 + (((gran + 2) ^ sw) << 2));
+            vfl.u[0] = *(const uint2*)((const char*)sVl + ht * 4096 + va);
+            vfl.u[1] = *(const uint2*)((const char*)sVl + ht * 4096 + vb);
             if (ht == 0) { o0 = H16<HT>::mfma32(vf.v, pfl.v, o0); o0 = H16<HT>::mfma32(vfl.v, pf.v, o0); }
             else { o1 = H16<HT>::mfma32(vf.v, pfl.v, o1); o1 = H16<HT>::mfma32(vfl.v, pf.v, o1); }
           }
@@ -518,8 +531,7 @@ __global__ __launch_bounds__(256) void enc_attention_f32_mfma_kernel(const float
 static bool is_x3(int dtype) { return dtype == WSEG_BF16X3 || dtype == WSEG_F16X3; }
 // attribution knob (tools/parity_sweep.py, profiles/): fp32-MFMA encoder attention in the split-precision modes
 int x3_enc_attention_mode() {
-  static const char* e = getenv("WSEG_X3_ENC_ATTN");
-  static const int v = !e ? 2 : (!strcmp(e, "f32") ? 1 : (!strcmp(e, "f16") ? 0 : 2));
+  static const int v = WSEG_KNOB_IS("WSEG_X3_ENC_ATTN", "f32") ? 1 : (WSEG_KNOB_IS("WSEG_X3_ENC_ATTN", "f16") ? 0 : 2);      // (variant builds)
   return v;
 }
 

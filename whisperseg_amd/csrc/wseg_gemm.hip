@@ -1526,7 +1526,7 @@ static SkinnyPlan plan_skinny(const GemmArgs& g, bool pairs = false) {      // p
   SkinnyPlan sp;
   // largest row tile that still yields >= 160 workgroups without splitting K; otherwise 128 rows + split-K
   sp.bm = g.M <= 32 ? 32 : (g.M <= 64 ? 64 : 128);
-  static const int force_bm = getenv("WSEG_SKINNY_BM") ? atoi(getenv("WSEG_SKINNY_BM")) : 0;   // tuning knob
+  static const int force_bm = WSEG_KNOB_INT("WSEG_SKINNY_BM", 0);   // tuning knob (variant builds)
   if (g.M > 64) {
     const int nt = g.N / 64;
     if (nt * cdiv(g.M, 128) < 160 && nt * cdiv(g.M, 64) >= 160) sp.bm = 64;
@@ -1540,7 +1540,7 @@ static SkinnyPlan plan_skinny(const GemmArgs& g, bool pairs = false) {      // p
   if (g.splitk_ws) {
     // split K (in whole 64-wide tiles, >= 2 tiles per split) until ~256 workgroups stream the weights
     const int nk = g.K / 64;
-    static const int target = getenv("WSEG_SKINNY_TARGET") ? atoi(getenv("WSEG_SKINNY_TARGET")) : 256;   // tuning knob
+    static const int target = WSEG_KNOB_INT("WSEG_SKINNY_TARGET", 256);   // tuning knob (variant builds)
     for (int cand = 2; cand <= 16 && blocks * sp.splits < target; ++cand) {
       if (nk % cand || nk / cand < 2 || (pairs && (nk / cand) % 2)) continue;
       if ((size_t)cand * sp.m_pad * g.N * sizeof(float) > g.splitk_ws_bytes) break;
@@ -1643,7 +1643,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_resid_ln_kernel(const float
 // 320 blocks of 128x128) is better in the stream family (decode step 10.71 -> 10.23 ms); at 1536 rows q|k|v (360 blocks)
 // and fc1 (480) are better on large tiles (13.50 vs 13.70 ms).
 static bool big_tile_path(const GemmArgs& g) {
-  static const long big_min = getenv("WSEG_BIG_MIN_BLOCKS") ? atol(getenv("WSEG_BIG_MIN_BLOCKS")) : 340;   // tuning knob
+  static const long big_min = WSEG_KNOB_INT("WSEG_BIG_MIN_BLOCKS", 340);   // tuning knob (variant builds)
   return g.M > 128 && g.N % 128 == 0 && (long)cdiv(g.M, 128) * (g.N / 128) >= big_min;
 }
 
@@ -1657,7 +1657,7 @@ template <typename T> static GemmArgs kernel_view(const GemmArgs& g0) {
 template <typename T> static int launch_pp_splitk(const GemmArgs& g, int S, hipStream_t s);
 
 static bool skinny_split_writes_mx(int N) {
-  static const bool off = getenv("WSEG_NO_MX_REDUCE") != nullptr;      // A/B knob
+  static const bool off = WSEG_KNOB_SET("WSEG_NO_MX_REDUCE");      // A/B knob (variant builds)
   return !off && N % 32 == 0;
 }
 
@@ -1669,22 +1669,22 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
   const HT* W = (const HT*)g.W;
   if (g.K % 64 || g.N % 64 || (IsMx<T>::v && g.K % 128)) { set_error("gemm h16: K %d / N %d not tile multiples", g.K, g.N); return WSEG_ERR_INVALID; }
   if (big_tile_path(g)) {
-    static const bool no_swz = getenv("WSEG_NO_XCD_SWIZZLE") != nullptr;
-    static const bool big256 = getenv("WSEG_GEMM_128") == nullptr;   // 256x256 tiles by default where they fill the chip
+    static const bool no_swz = WSEG_KNOB_SET("WSEG_NO_XCD_SWIZZLE");
+    static const bool big256 = !WSEG_KNOB_SET("WSEG_GEMM_128");   // 256x256 tiles by default where they fill the chip
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g_prof.on) {
       std::lock_guard<std::mutex> lk(g_prof.mu);
       e0 = g_prof.get(); e1 = g_prof.get(); g_prof.flops.push_back(2.0 * g0.M * g0.N * g0.K); (void)hipEventRecord(e0, s);
     }
-    static const bool persist = getenv("WSEG_GEMM_NO_PERSIST") == nullptr;
+    static const bool persist = !WSEG_KNOB_SET("WSEG_GEMM_NO_PERSIST");
     // m-tiles per tile group of the persistent order: the 32 tiles in flight on one XCD then span ~4 activation tiles x 8
     // weight tiles, the smallest operand footprint for 32 tiles (a + b = 12 operand tiles; 2-row groups re-stream the
     // whole weight matrix per tile pair: PMC FETCH_SIZE 2-3x the algorithmic bytes, profiles/).  Measured at 256
     // windows: 4 beats 2 by 2-8 % on the K = 1280 shapes, 6 and 8 lose on K = 5120.
 #if defined(WSEG_STAMPS) && WSEG_STAMPS == 4
-    static const int group_m = (getenv("WSEG_GEMM_GROUP_M") ? atoi(getenv("WSEG_GEMM_GROUP_M")) : 4) | (getenv("WSEG_PP_SOLO") ? 0x100 : 0);
+    static const int group_m = WSEG_KNOB_INT("WSEG_GEMM_GROUP_M", 4) | (getenv("WSEG_PP_SOLO") ? 0x100 : 0);
 #else
-    static const int group_m = getenv("WSEG_GEMM_GROUP_M") ? atoi(getenv("WSEG_GEMM_GROUP_M")) : 4;
+    static const int group_m = WSEG_KNOB_INT("WSEG_GEMM_GROUP_M", 4);
 #endif
     const int n_cu = device_cu_count();
     // 256x256 tiles need whole rounds of the chip: with fewer than 4 rounds, a last round that leaves more than a fifth of
@@ -1692,19 +1692,19 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
     // 1.25 rounds, 118 us against 1280 tiles of 128x128 in 2.5 rounds of 512 workgroups).
     const long nt256 = (long)cdiv(g.M, 256) * (g.N / 256);
     const long rounds256 = (nt256 + n_cu - 1) / n_cu;
-    static const bool quant_rule = getenv("WSEG_GEMM_NO_QUANT_RULE") == nullptr;   // tuning knob
+    static const bool quant_rule = !WSEG_KNOB_SET("WSEG_GEMM_NO_QUANT_RULE");   // tuning knob (variant builds)
     // (split / mixed modes: a K tile pair costs twice the bf16 K tile while the 128x128 kernel's fixed costs do not shrink — since the
     // r04 K-loop work the 256x256 kernel wins down to 3/5 of a last round: decoder fc1 at 4 096 rows, 320 tiles, 152 against 161 us)
     const bool ragged256 = quant_rule && rounds256 < 4 && nt256 * 5 < rounds256 * n_cu * (IO<T>::split ? 3 : 4);
-    if (big256 && g.N % 256 == 0 && nt256 >= 192 && !ragged256) {
+    if (big256 && g.N % 256 == 0 && nt256 >= 192 && !ragged256 && g.K >= 128) {      // (K = 64 words: one K tile, 128x128 kernel)
       const int ntm = cdiv(g.M, 256), ntiles = ntm * (g.N / 256);
-      static const bool pingpong = getenv("WSEG_GEMM_NO_PP") == nullptr;   // ping-pong kernel by default (tuning knob)
+      constexpr bool pingpong = true;      // (r05: the generic / persistent kernels' 256x256 instantiations — knob-only paths that spilled 200-330 bytes per lane — are gone)
       // WSEG_F16M6, M6-row outputs, between one and two rounds of 256x256 tiles (decoder fc1 at 4 096 rows: 320 tiles on 256 CUs — the
       // second round runs on a quarter of the chip): the columns that fill ONE round go through the kernel as usual; the remaining
       // column tiles are multiplied as split-K copies that fill the chip once more for 1 / S of the K range, and the 8-column
       // reduction writes their M6 rows.
       if constexpr (IsMx<T>::v && (EPI == EPI_STORE || EPI == EPI_GELU)) {
-        static const bool tail_split = getenv("WSEG_NO_TAIL_SPLIT") == nullptr;      // A/B knob
+        static const bool tail_split = !WSEG_KNOB_SET("WSEG_NO_TAIL_SPLIT");      // A/B knob (variant builds)
         const int ntn = g.N / 256, full_cols = n_cu / ntm, pairs = g.K / 128;
         if (tail_split && pingpong && rounds256 == 2 && g.splitk_ws && full_cols >= 1 && full_cols < ntn && g.K >= 256) {
           const int rem_tiles = (ntn - full_cols) * ntm, n1 = full_cols * 256, n2 = g.N - n1;
@@ -1732,15 +1732,15 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
       }
       // (Measured and dropped, r04: the generic kernel as 4 waves x 128x128 wave tiles, one wave per SIMD — a third fewer fragment
       // reads per MFMA, but with nothing to hide its per-K-tile barriers behind: 640 against 1 080 TFLOP/s on the encoder shapes.)
-      if (pingpong && g.K >= 128) {
+      {
         int grid = ntiles < n_cu ? ntiles : n_cu;
         grid &= ~7;
         // A/B knob: register-resident residual epilogue (measured slower, profiles/README.md r03: all CUs reach their epilogue
         // together and its 1.3 GB of fp32 residual traffic is an HBM-bound burst either way; staged 540 / 1513 us, direct 590 / 1525 us)
-        static const bool resid_staged = getenv("WSEG_PP_DIRECT_RESID") == nullptr;
+        static const bool resid_staged = !WSEG_KNOB_SET("WSEG_PP_DIRECT_RESID");
         // WSEG_F16M6, hi-only permission: the M6H instantiation (encoder q|k|v and o-proj: the EPIs it is built for)
         if constexpr (std::is_same<T, M6>::value && (EPI == EPI_QKV_ENC || EPI == EPI_RESID)) {
-          static const bool no_hi = getenv("WSEG_NO_HI_ONLY") != nullptr;      // A/B knob
+          static const bool no_hi = WSEG_KNOB_SET("WSEG_NO_HI_ONLY");      // A/B knob (variant builds)
           if (g0.hi_only && !no_hi && g.K >= 256) {
             hipLaunchKernelGGL((gemm_h16_pp_kernel<M6H, EPI, EPI == EPI_RESID>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K,
                                g.ep, ntm, group_m, 1);
@@ -1755,14 +1755,6 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
         else
           hipLaunchKernelGGL((gemm_h16_pp_kernel<T, EPI, false>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K, g.ep, ntm,
                              group_m, 1);
-      } else if (persist) {
-        int grid = ntiles < n_cu ? ntiles : n_cu;
-        grid &= ~7;
-        hipLaunchKernelGGL((gemm_h16_persist_kernel<T, 256, 256, 2, 4, EPI>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
-                           g.K, g.ep, ntm, group_m);
-      } else {
-        hipLaunchKernelGGL((gemm_h16_kernel<T, 256, 256, 2, 4, EPI, false>), dim3(ntiles), dim3(512), 0, s, A, g.lda, W, g.ldw,
-                           g.M, g.N, g.K, g.ep, (float*)nullptr, 0, ntm);
       }
     } else {
       const int ntm = cdiv(g.M, 128), ntiles = ntm * (g.N / 128);
@@ -1886,9 +1878,9 @@ template <typename T> static int pp_splitk_plan(const GemmArgs& g) {
   // tuning knobs.  Split / mixed modes (twice the K tiles per logical column, r04 K loop): the split-K 256x256 kernel beats the
   // 128x64 stream kernel from 512 rows up (decode step at 128 / 256 / 384 slots: 9.9 -> 9.3, 15.2 -> 14.5, 18.4 -> 17.7 ms; at 64
   // slots the stream kernel wins, 6.2 against 6.7 ms)
-  static const int min_rows_env = getenv("WSEG_PP_SPLITK_MIN_ROWS") ? atoi(getenv("WSEG_PP_SPLITK_MIN_ROWS")) : 0;
+  static const int min_rows_env = WSEG_KNOB_INT("WSEG_PP_SPLITK_MIN_ROWS", 0);
   const int min_rows = min_rows_env ? min_rows_env : (IO<T>::split ? 512 : 2048);
-  static const int min_kt = getenv("WSEG_PP_SPLITK_MIN_KT") ? atoi(getenv("WSEG_PP_SPLITK_MIN_KT")) : 40;
+  static const int min_kt = WSEG_KNOB_INT("WSEG_PP_SPLITK_MIN_KT", 40);
   if (g.M < min_rows || g.N % 256 || g.K % 64 || g.K / 64 < min_kt || !g.splitk_ws) return 0;
   const int nt = cdiv(g.M, 256) * (g.N / 256), nk = g.K / 64, n_cu = device_cu_count();
   int S = n_cu / nt;
@@ -1898,7 +1890,7 @@ template <typename T> static int pp_splitk_plan(const GemmArgs& g) {
 
 template <typename T> static int launch_pp_splitk(const GemmArgs& g, int S, hipStream_t s) {
   typedef typename IO<T>::H HT;
-  static const int group_m = getenv("WSEG_GEMM_GROUP_M") ? atoi(getenv("WSEG_GEMM_GROUP_M")) : 4;
+  static const int group_m = WSEG_KNOB_INT("WSEG_GEMM_GROUP_M", 4);
   const int ntm = cdiv(g.M, 256), ntiles = ntm * (g.N / 256) * S, n_cu = device_cu_count();
   int grid = ntiles < n_cu ? ntiles : n_cu;
   grid &= ~7;
@@ -1930,7 +1922,7 @@ static int gemm_resid_ln_t(const GemmArgs& g0, const void* gamma, const void* be
       g.N % 64)
     return WSEG_OK;
   SkinnyPlan sp = plan_skinny(g, IsMx<T>::v);
-  static const bool fuse_unsplit = getenv("WSEG_RESID_LN_ALWAYS_PARTIAL") == nullptr;   // tuning knob
+  static const bool fuse_unsplit = !WSEG_KNOB_SET("WSEG_RESID_LN_ALWAYS_PARTIAL");   // tuning knob (variant builds)
   // K not split (enough row tiles to fill the chip, 2048+ rows): the fp32 partial round trip buys nothing; the GEMM adds
   // the residual in its own epilogue and a LayerNorm launch follows (2048 rows: 21.6 + ~6 us against 26.7 + 8.9 us)
   if (!(sp.splits > 1 || !fuse_unsplit) || (size_t)sp.splits * sp.m_pad * g.N * sizeof(float) > g.splitk_ws_bytes) return WSEG_OK;

@@ -104,7 +104,7 @@ void add_slot(wseg_model* m, const std::string& name, const void** field, size_t
 // The encoder (and the cross-K/V GEMMs behind it) runs over at most ENC_CHUNK windows at a time: its activations (FFN hidden:
 // 10 MB per window in the 16-bit modes, 20 MB in the split modes) then stop growing with the slot count, and a pass of 256
 // windows (128 000 rows: the r01 / r02 headline workload) already fills the chip for tens of rounds.
-static const int ENC_CHUNK = getenv("WSEG_ENC_CHUNK") ? std::max(1, atoi(getenv("WSEG_ENC_CHUNK"))) : 256;      // (env: measurement knob)
+static const int ENC_CHUNK = std::max(1, WSEG_KNOB_INT("WSEG_ENC_CHUNK", 256));      // (measurement knob, variant builds)
 // Default self-K/V pool of wseg_workspace_bytes: positions per slot, or max_length if that is smaller.
 constexpr int KV_DEFAULT_POSITIONS = 64;
 
@@ -146,7 +146,7 @@ void make_plan(const wseg_model* m, int W, int nb, int L, int kv_units, char* ba
     // scratch for the activation operands that still arrive as hi | lo rows and are converted in front of their GEMM: the conv1
     // im2col always; conv2's operand, the attention output and the FFN hidden only when their producer is not one that writes
     // M6 rows directly (4-column epilogues of the skinny GEMM family on small problems; WSEG_X3_ENC_ATTN != split)
-    const int dtp = c.dtype, Me = We * c.enc_positions, M1e = We * c.spec_cols, R0 = W * nb;
+    const int dtp = c.dtype, R0 = W * nb;
     const size_t Rp0 = align_up((size_t)R0, 256);
     size_t big = M1p * (size_t)m->kp1;
     if (!enc_attention_writes_mx(dtp)) big = std::max(big, Mp * d);
@@ -155,8 +155,8 @@ void make_plan(const wseg_model* m, int W, int nb, int L, int kv_units, char* ba
       if (!gemm_out_is_mx(dtp, n * c.spec_cols, (int)d, m->kp1)) big = std::max(big, mp * 3 * d);
       if (!gemm_out_is_mx(dtp, n * c.enc_positions, (int)ffn, (int)d)) big = std::max(big, mp * ffn);
     }
-    (void)Me; (void)M1e;
     if (!gemm_out_is_mx(dtp, R0, (int)ffn, (int)d)) big = std::max(big, Rp0 * ffn);
+    if (!dec_cross_attn_writes_mx(dtp, nb)) big = std::max(big, Rp0 * d);      // 5..8 beams: cross-attention output as hi | lo rows
     p.mxa = take(big * 4);
     p.mxe = take(Mp * d * 4);
   }
@@ -350,7 +350,7 @@ int run_decoder_step(wseg_model* m, DecPlan& p, char* mxa, bool want_logits, hip
         WSEG_TRY(launch_dec_cross_attn(gdt, st, p.dq, p.ck + l * cross_stride, p.cv + l * cross_stride, p.dattn, H, Tk, d, nullptr, nullptr, 0.125f, s));
       }
     }
-    WSEG_TRY(gemm_resid_ln(p.dattn, d, L.co_w, L.co_b, L.ln3_g, L.ln3_b, m->mx));                  // x += cross Wo ; y = LN3(x)
+    WSEG_TRY(gemm_resid_ln(p.dattn, d, L.co_w, L.co_b, L.ln3_g, L.ln3_b, dec_cross_attn_writes_mx(gdt, st.nb)));      // x += cross Wo ; y = LN3(x)
     e = EpiParams();
     e.bias = L.fc1_b; e.out = p.dh; e.ldc = ffn;
     WSEG_TRY(gemm(m, EPI_GELU, p.dy, d, L.fc1_w, d, R, ffn, d, e, &p, s));
@@ -378,7 +378,7 @@ extern "C" int wseg_model_create(const wseg_model_config* cfg, wseg_model** out)
   m->es = (cfg->dtype == WSEG_BF16 || cfg->dtype == WSEG_F16) ? 2 : 4;
   m->x3 = cfg->dtype == WSEG_BF16X3 || cfg->dtype == WSEG_F16X3 || cfg->dtype == WSEG_F16M6;
   m->mx = cfg->dtype == WSEG_F16M6;
-  m->attn_hi = m->mx && getenv("WSEG_ATTN_HI") != nullptr;      // experiment knob, off: 19x the logit error at 32 layers
+  m->attn_hi = m->mx && WSEG_KNOB_SET("WSEG_ATTN_HI");      // experiment knob, off: 19x the logit error at 32 layers
   m->sdt = storage_dtype(cfg->dtype);
   m->ckv_es = m->es;
   m->kp1 = (int)align_up((size_t)3 * cfg->n_mels, 64);

@@ -224,14 +224,16 @@ def segment_batch_distributed(segmenter, audios, srs=None, decode_shard=None, **
             mf, sts, msl, e, tpf = _resolve(segmenter, mf, sts, msl, e, tpf)
             meta.append(dict(n=int(len(audio)), sr=sr, min_frequency=mf, spec_time_step=sts, min_segment_length=msl, eps=e,
                              frame=tpf, num_trials=int(nt), method=method))
-    meta = _broadcast_object(meta)
+    # (the grouping cap travels with the metadata: non-zero ranks may pass None for every parameter, and ranks that derived different
+    # groups would run different numbers of scatter / gather rounds and hang — ADVICE r04)
+    meta, pool_windows = _broadcast_object((meta, kwargs.get("pool_windows") if rank == 0 else None))
     cols = segmenter.total_spec_columns
     counts = [len(window_table(m["n"], m["sr"], m["spec_time_step"], m["num_trials"], cols)) for m in meta]
     # Recordings are processed in GROUPS of at most ~pool_windows x world windows (every rank derives the same grouping from the
     # metadata): scatter, front-end, decode and gather run per group, so a rank never holds more than ~pool_windows windows of
     # log-mel features (320 KB each) however large the dataset is — evaluate() sends whole datasets through here.
     from .model import POOL_WINDOWS
-    cap = max(1, int(kwargs.get("pool_windows") or POOL_WINDOWS)) * world
+    cap = max(1, int(pool_windows or POOL_WINDOWS)) * world
     groups, cur, cur_n = [], [], 0
     for i, c in enumerate(counts):
         if cur and cur_n + c > cap:

@@ -421,7 +421,21 @@ class Engine:
         max_length = int(min(max_length, self.geo["dec_positions"]))
         with torch.cuda.device(self.device):
             slots = self.pick_slots(W, num_beams, max_length, n_slots, kv_positions)
-            ws = self._workspace(slots, num_beams, max_length, kv_positions)
+            while True:
+                try:
+                    ws = self._workspace(slots, num_beams, max_length, kv_positions)
+                    break
+                except _lib.WsegError:
+                    # The budget ignores other residents of the GPU (a sibling engine, another process).  In the exact and the split
+                    # modes a window's tokens are tested independent of the slot count, so fewer slots is only slower: halve and warn
+                    # (last_stats()["n_slots"] reports what ran).  The plain 16-bit modes' logits follow the row count: there a silent
+                    # change of the slot count could change a recording's rows run to run, so the error stands.
+                    if slots <= 1 or n_slots is not None or self.dtype_name in ("bf16", "f16"):
+                        raise
+                    import warnings
+                    warnings.warn(f"decode workspace for {slots} window slots does not fit beside the GPU's other allocations: "
+                                  f"retrying with {(slots + 1) // 2} slots (tokens do not depend on the slot count in mode {self.dtype_name})")
+                    slots = (slots + 1) // 2
         sup = torch.tensor(list(suppress_tokens) or [0], dtype=torch.int32, device=self.device)
         bsup = torch.tensor(list(begin_suppress_tokens) or [0], dtype=torch.int32, device=self.device)
         gp = _lib.GenerateParams()
