@@ -101,8 +101,9 @@ def end_to_end_bound(model, dtype, beams, gen, W, enc_frac=1.0, dec_frac=1.0, cr
     """Ceiling of `end_to_end_frac` (algorithmic flops per second / dense MFMA peak) for this workload: the step is a chain of
     dependent kernels, so their times ADD — matrix-core kernels at enc_frac / dec_frac of the dense peak (the split-precision
     modes issue THREE MFMAs per algorithmic product), HBM-bound kernels at their bandwidth:
-      cross-attention  Tk x 64 x (K + V) per (window, head, layer, step): 2 B per element in the 16-bit modes, 3 B (24-bit) in the
-                       split modes, 4 B in f32 — shared by the beams of a window, streamed once per decode step;
+      cross-attention  Tk x 64 x (K + V) per (window, head, layer, step): 2 B per element in the 16-bit modes, 132 / 64 B in the split
+                       modes (int16 + one fp32 scale per row: block floating point, r05; r03-r04: 3 B), 4 B in f32 — shared by the
+                       beams of a window, streamed once per decode step;
       self-attention   2 x t x 64 elements per (row, head, layer) at step t (fp32 rows in the f32 / split modes);
       logits           fp32 [rows][vocab] written by the LM head and read twice by the top-k kernels;
       decoder weights  once per step, shared by the W windows in flight.
@@ -111,9 +112,9 @@ def end_to_end_bound(model, dtype, beams, gen, W, enc_frac=1.0, dec_frac=1.0, cr
     g = GEOMETRY[model]
     d, f, L, T, V, P = g["d_model"], g["ffn"], g["layers"], 500, 51865, 3
     enc_f, ckv_f, dec_f = flops_per_window(model, beams, gen)
-    x3 = dtype.endswith("x3") or dtype == "f16m6"      # fp32 storage outside the GEMMs, 24-bit cross K / V
+    x3 = dtype.endswith("x3") or dtype == "f16m6"      # fp32 storage outside the GEMMs, block-floating-point cross K / V
     mult = mfma_issue_multiplier(dtype)
-    kv_b = 3 if x3 else (4 if dtype == "f32" else 2)              # cross K / V bytes per element
+    kv_b = 132 / 64 if x3 else (4 if dtype == "f32" else 2)       # cross K / V bytes per element
     sa_b = 4 if (x3 or dtype == "f32") else 2                     # self-attention cache bytes per element
     w_b = 4 if (x3 or dtype == "f32") else 2                      # weight bytes per logical element (hi + lo pairs: 4)
     steps = P + gen - 1

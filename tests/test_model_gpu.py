@@ -109,14 +109,20 @@ def test_five_to_eight_beams(gpu_lib, nb, dtype):
     rc, sd, eng = make(cfg, dtype)
     x = feats(3)
     gp = gen_params(nb, 16)
-    want = R.generate(sd, rc, x, gp)
-    toks, lens = eng.generate(x.cuda(), PROMPT, EOS, EOS, max_length=16, num_beams=nb, suppress_tokens=gp.suppress_tokens,
-                              begin_suppress_tokens=gp.begin_suppress_tokens)
+    want, want_logits = R.generate(sd, rc, x, gp, return_first_logits=True)
+    toks, lens, got_logits = eng.generate(x.cuda(), PROMPT, EOS, EOS, max_length=16, num_beams=nb, suppress_tokens=gp.suppress_tokens,
+                                          begin_suppress_tokens=gp.begin_suppress_tokens, return_first_logits=True)
+    # first-step logits of EVERY beam row (r05: beams 4..7 of the general cross-attention kernel read their split-K queries from
+    # uninitialised LDS in every mode but f32 — errors of 0.1-3 on the logits while the tokens of flat random weights still agreed)
+    assert (got_logits.cpu() - want_logits).abs().max().item() <= 1e-3
     toks, lens = toks.cpu().numpy(), lens.cpu().numpy()
     for i in range(3):
         a = R.canonical(want[i].tolist(), 3, EOS, PROMPT)
         b = R.canonical(toks[i, :lens[i]].tolist(), 3, EOS, PROMPT)
-        assert a == b, (i, a, b)
+        if a != b:      # 8 hypotheses over flat random-weight logits: a differing result must be a near-tie under the ORACLE's own scores
+            from test_large_geometry_gpu import assert_equally_scored
+            assert dtype != "f32", (i, a, b)
+            assert_equally_scored(sd, rc, x[i:i + 1], gp, toks[i, :lens[i]].tolist(), want[i].tolist(), ("beams", nb, dtype, i))
 
 
 def test_real_vocab_logits_bf16(gpu_lib):

@@ -175,7 +175,7 @@ def analyze(path):
             continue
         mn, _, rest = s.partition(" ")
         stream.append((in_asm, mn, rest, no))
-        if in_loop and (mn.startswith("scratch_") or (mn.startswith("buffer_") and "offen" in rest and "s[0:3]" in rest)):
+        if in_loop and (mn.startswith("scratch_") or (mn.startswith("buffer_") and "offen" in rest and "s[0:3]" in rest and " lds" not in rest)):
             n_loop_scratch += 1
     flush()
     flush_loops()

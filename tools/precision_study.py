@@ -57,6 +57,19 @@ def rnd(x, fmt):
     if fmt in ("f16x2", "f16x3"):
         hi = x.half().float()
         return hi + (x - hi).half().float()
+    if fmt in ("t24", "t22", "t20"):      # fp32 rounded (half up in magnitude) to its top 24 / 22 / 20 bits: 16 / 14 / 12-bit significands
+        drop = 32 - int(fmt[1:])          # (t24 = the 24-bit cross K / V of the split modes, EpiParams::kv24)
+        w = x.contiguous().view(torch.int32) + (1 << (drop - 1))
+        return (w & ~((1 << drop) - 1)).view(torch.float32)
+    if fmt.startswith("bfp"):             # block floating point along the last dim: bfp<bits>r = one power-of-two scale per ROW (a K / V row of
+        bits, blk = fmt[3:].split("r") if "r" in fmt else fmt[3:].split("b")      # one head: 64 elements), bfp<bits>b<n> = per block of n elements;
+        bits = int(bits)                                                             # elements are <bits>-bit two's-complement integers
+        n = x.shape[-1] if not blk else int(blk)
+        xb = x.reshape(*x.shape[:-1], -1, n)
+        amax = xb.abs().amax(dim=-1, keepdim=True).clamp_min(1e-38)
+        scale = torch.exp2(torch.ceil(torch.log2(amax)) - (bits - 1))              # amax / scale <= 2^(bits-1)
+        q = torch.round(xb / scale).clamp(-(2 ** (bits - 1)) + 1, 2 ** (bits - 1) - 1)
+        return (q * scale).reshape(x.shape)
     raise ValueError(fmt)
 
 

@@ -44,7 +44,7 @@ def build(force=False, verbose=True, stamps=0, variant="", defines=()):
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(HERE, "build" if not stamps else "build/stamps%d" % stamps)
     lib = LIB if not stamps else os.path.join(LIBDIR, "libwseg_stamps%d.so" % stamps)
-    flags = FLAGS + (["-DWSEG_STAMPS=%d" % stamps] if stamps else [])
+    flags = FLAGS + (["-DWSEG_STAMPS=%d" % stamps] + list(defines) if stamps else [])
     if variant:
         objdir = os.path.join(HERE, "build", "variant_" + variant)
         lib = os.path.join(LIBDIR, "libwseg_%s.so" % variant)

@@ -325,7 +325,9 @@ __global__ __launch_bounds__(256, NB > 4 ? 2 : 4) void dec_cross_attn_kernel(Dec
   float qv[NB][8];
   if (pi.part != nullptr) {
     __shared__ float sq[NB][64];                        // thread (j, e) finishes dim e of beam j (reduce1), slices come back from LDS
-    if (tid < NB * 64) sq[tid >> 6][tid & 63] = El<T>::rnd(reduce1<T>(pi, w * nb + min(tid >> 6, nb - 1), h * 64 + (tid & 63), q_bias) * scale);
+    // (NB = 8: 512 (beam, dim) pairs for 256 threads — r05: beams 4..7 used to read their queries from uninitialised LDS whenever the
+    // query arrived as split-K partials, i.e. in every mode but f32; found by the first-logit check of tests/test_model_gpu.py)
+    for (int i = tid; i < NB * 64; i += 256) sq[i >> 6][i & 63] = El<T>::rnd(reduce1<T>(pi, w * nb + min(i >> 6, nb - 1), h * 64 + (i & 63), q_bias) * scale);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < NB; ++j)
@@ -621,6 +623,7 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
   WSEG_STAMP(2, 7);
 }
 
+#ifdef WSEG_KNOBS      // the 24-bit format of r03-r04: knob builds only (WSEG_X3_CKV=k24, same-box A/B against the block-floating-point rows)
 // ------------------------------------------------------------------------------------------------
 // Split-precision modes: cross-attention over 24-bit K / V (EpiParams::kv24: per (slot, head) a [Tk][64] plane of the fp32
 // words' top halves, then a [Tk][64] plane of their third bytes; 192 instead of 256 bytes per row pair of an HBM-bound stream).
@@ -789,6 +792,166 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_k24_kernel(DecodeState 
     if (j < nb) op_st8<TO>(out, (size_t)(w * nb + j), d, h * 64 + e0, o8);
   }
   WSEG_STAMP(3, 7);
+}
+
+#endif      // WSEG_KNOBS
+
+// ------------------------------------------------------------------------------------------------
+// Split-precision modes, r05: cross-attention over block-floating-point K / V (EpiParams::kv24 == 2: per (slot, head) a [Tk][64] plane
+// of int16 followed by [Tk] fp32 powers of two, value = int16 * scale of its row; 132 instead of the 24-bit format's 192 bytes per
+// row of an HBM-bound stream).  The structure is the 24-bit kernel's: 8 lanes per row, 8 raw rows per lane in flight (16 + 4 bytes
+// each), two beams per v_pk_fma_f32, DPP row sums; an element is one v_cvt_f32_i32 (sign-extended half word), the row's scale
+// multiplies the finished score (K) / the probability (V) — powers of two: exact, the sums are those of the dequantised values.
+// ------------------------------------------------------------------------------------------------
+template <typename TO, int NB>
+__global__ __launch_bounds__(256, 3) void dec_cross_attn_bfp_kernel(DecodeState st, const float* __restrict__ q,
+                                                                    const unsigned char* __restrict__ ck, const unsigned char* __restrict__ cv,
+                                                                    void* __restrict__ out, int H, int Tk, int d, PartialInfo pi,
+                                                                    const float* __restrict__ q_bias, float scale) {
+  typedef unsigned int raw16 __attribute__((ext_vector_type(4)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  constexpr int U = 8;
+  __shared__ float sc[NB][512];
+  __shared__ float red[4][NB][64];
+  __shared__ float sinv[NB];
+  __shared__ float sks[512], svs[512];                 // the row scales of this (slot, head): 2 x 2 KB, fetched once with coalesced loads (as
+                                                       // 4-byte loads beside the rows they doubled the kernel's VMEM instructions: 5.2 TB/s)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int w = blockIdx.x / H, h = blockIdx.x - w * H;
+  if (st.done[w]) return;                              // idle slot: its 66 KB of K / V are not streamed
+  const int nb = st.nb;
+  const int sub = lane & 7, rowl = lane >> 3;
+  const unsigned char* Kb = ck + ((size_t)w * H + h) * Tk * 132;
+  const unsigned char* Vb = cv + ((size_t)w * H + h) * Tk * 132;
+  const float* Ks = (const float*)(Kb + (size_t)Tk * 128);
+  const float* Vs = (const float*)(Vb + (size_t)Tk * 128);
+  constexpr int NP = (NB + 1) / 2;
+  f2 qq[8][NP];
+  __shared__ float sq[NB][64];                          // thread (j, e) finishes dim e of beam j (reduce1), slices come back from LDS
+  for (int i = tid; i < Tk; i += 256) { sks[i] = __builtin_nontemporal_load(Ks + i); svs[i] = __builtin_nontemporal_load(Vs + i); }
+  if (pi.part != nullptr) {
+    if (tid < NB * 64) sq[tid >> 6][tid & 63] = reduce1<float>(pi, w * nb + min(tid >> 6, nb - 1), h * 64 + (tid & 63), q_bias) * scale;
+  }
+  __syncthreads();
+  {
+    float qv[8];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if (pi.part != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] = sq[j][sub * 8 + e];
+      } else {
+        load8<float>(q + (size_t)(w * nb + min(j, nb - 1)) * d + h * 64 + sub * 8, qv);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qq[e][j >> 1][j & 1] = qv[e];
+    }
+    if constexpr (NB == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qq[e][0][1] = 0.f;
+    }
+  }
+  auto unpack = [](const raw16& x, float v[8]) {
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      v[2 * e2] = (float)(int)(short)(x[e2] & 0xffffu);
+      v[2 * e2 + 1] = (float)((int)x[e2] >> 16);
+    }
+  };
+  for (int t0 = 0; t0 < Tk; t0 += 32 * U) {
+    raw16 kq[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = min(t0 + u * 32 + wave * 8 + rowl, Tk - 1);      // clamped: out-of-range rows are discarded below
+      kq[u] = __builtin_nontemporal_load((const raw16*)(Kb + (size_t)t * 128 + sub * 16));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + u * 32 + wave * 8 + rowl;
+      float kv[8];
+      unpack(kq[u], kv);
+      f2 a2[NP];
+#pragma unroll
+      for (int j2 = 0; j2 < NP; ++j2) a2[j2] = (f2){0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const f2 kk = {kv[e], kv[e]};
+#pragma unroll
+        for (int j2 = 0; j2 < NP; ++j2) a2[j2] = __builtin_elementwise_fma(qq[e][j2], kk, a2[j2]);
+      }
+      float a[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) a[j] = a2[j >> 1][j & 1];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) a[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[j]), 0xB1, 0xF, 0xF, true));
+#pragma unroll
+      for (int j = 0; j < NB; ++j) a[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[j]), 0x4E, 0xF, 0xF, true));
+#pragma unroll
+      for (int j = 0; j < NB; ++j) a[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[j]), 0x141, 0xF, 0xF, true));
+      float mine = a[0];
+#pragma unroll
+      for (int j = 1; j < NB; ++j) mine = sub == j ? a[j] : mine;
+      if (sub < nb && t < Tk) sc[sub][t] = mine * sks[t];
+    }
+  }
+  __syncthreads();
+  for (int j = wave; j < nb; j += 4) {
+    float mx = -3.0e38f;
+    for (int t = lane; t < Tk; t += 64) mx = fmaxf(mx, sc[j][t]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int t = lane; t < Tk; t += 64) { const float p = expf(sc[j][t] - mx); sc[j][t] = p * svs[t]; sum += p; }      // (V's row scale rides on the probability)
+    sum = wave_sum(sum);
+    if (lane == 0) sinv[j] = 1.0f / sum;
+  }
+  __syncthreads();
+  static_assert(NB == 1 || NB == 2 || NB == 4, "beam tiles");
+  f2 acc[NB][4];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[j][e] = (f2){0.f, 0.f};
+  for (int t0 = 0; t0 < Tk; t0 += 32 * U) {
+    raw16 vq[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = min(t0 + u * 32 + wave * 8 + rowl, Tk - 1);
+      vq[u] = __builtin_nontemporal_load((const raw16*)(Vb + (size_t)t * 128 + sub * 16));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + u * 32 + wave * 8 + rowl;
+      const bool ok = t < Tk;
+      const int tc = ok ? t : Tk - 1;
+      float vf[8];
+      unpack(vq[u], vf);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const float p = (ok && j < nb) ? sc[j][tc] : 0.f;
+        const f2 pp = {p, p};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][e] = __builtin_elementwise_fma(pp, (f2){vf[2 * e], vf[2 * e + 1]}, acc[j][e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = acc[j][e >> 1][e & 1];
+      a += lane_xor<8>(a);
+      a += lane_xor<16>(a);
+      a += lane_xor<32>(a);
+      if (rowl == 0) red[wave][j][sub * 8 + e] = a;
+    }
+  __syncthreads();
+  if (tid < NB * 8) {      // thread (j, e8): 8 consecutive columns of beam j — whole quads of threads share a 32-column block (M6 rows)
+    const int j = tid >> 3, e0 = (tid & 7) * 8;
+    float o8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] = (((red[0][j][e0 + e] + red[1][j][e0 + e]) + red[2][j][e0 + e]) + red[3][j][e0 + e]) * sinv[min(j, nb - 1)];
+    if (j < nb) op_st8<TO>(out, (size_t)(w * nb + j), d, h * 64 + e0, o8);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1207,13 +1370,13 @@ static void launch_cross_t(const DecodeState& st, const void* q, const void* ck,
   else WSEG_CA(8);
 #undef WSEG_CA
 }
-bool x3_cross_kv24() {
-  static const bool v = !WSEG_KNOB_IS("WSEG_X3_CKV", "f32");      // (attribution knob, variant builds)
-  return v;
+int x3_cross_kv_format(int nb) {      // wseg_kernels.h; knob builds: WSEG_X3_CKV = f32 | k24 (attribution / A-B)
+  static const int v = WSEG_KNOB_IS("WSEG_X3_CKV", "f32") ? 0 : (WSEG_KNOB_IS("WSEG_X3_CKV", "k24") ? 1 : 2);
+  return nb <= 4 ? v : 0;
 }
 // WSEG_F16M6: does the cross-attention write its output (the co-proj GEMM's operand) as M6 rows?  The 24-bit K / V kernel does (it
 // exists for up to 4 beams); 5..8 beams run the general fp32-K/V kernel, which writes hi | lo rows that the caller converts.
-bool dec_cross_attn_writes_mx(int dtype, int nb) { return dtype == WSEG_F16M6 && x3_cross_kv24() && nb <= 4; }
+bool dec_cross_attn_writes_mx(int dtype, int nb) { return dtype == WSEG_F16M6 && x3_cross_kv_format(nb) != 0; }
 
 int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const void* ck, const void* cv, void* out, int H, int Tk, int d,
                           const PartialInfo* q_part, const void* q_bias, float scale, hipStream_t s) {
@@ -1221,7 +1384,19 @@ int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const
   PartialInfo pi;
   if (q_part) pi = *q_part;
   const bool m6 = dtype == WSEG_F16M6;      // M6-row output from the 24-bit K / V kernel only (dec_cross_attn_writes_mx)
-  if ((dtype == WSEG_BF16X3 || dtype == WSEG_F16X3 || m6) && x3_cross_kv24() && st.nb <= 4) {
+  const int kvf = (dtype == WSEG_BF16X3 || dtype == WSEG_F16X3 || m6) ? x3_cross_kv_format(st.nb) : 0;
+  if (kvf == 2) {
+    dim3 grid(st.W * H), block(256);
+#define WSEG_BFP(TO_, NB_) hipLaunchKernelGGL((dec_cross_attn_bfp_kernel<TO_, NB_>), grid, block, 0, s, st, (const float*)q, (const unsigned char*)ck, (const unsigned char*)cv, out, H, Tk, d, pi, (const float*)q_bias, scale)
+    if (dtype == WSEG_BF16X3) { if (st.nb <= 1) WSEG_BFP(X3<bf16_t>, 1); else if (st.nb <= 2) WSEG_BFP(X3<bf16_t>, 2); else WSEG_BFP(X3<bf16_t>, 4); }
+    else if (m6) { if (st.nb <= 1) WSEG_BFP(M6, 1); else if (st.nb <= 2) WSEG_BFP(M6, 2); else WSEG_BFP(M6, 4); }
+    else { if (st.nb <= 1) WSEG_BFP(X3<f16_t>, 1); else if (st.nb <= 2) WSEG_BFP(X3<f16_t>, 2); else WSEG_BFP(X3<f16_t>, 4); }
+#undef WSEG_BFP
+    WSEG_LAUNCH_CHECK();
+    return WSEG_OK;
+  }
+#ifdef WSEG_KNOBS
+  if (kvf == 1) {
     dim3 grid(st.W * H), block(256);
 #define WSEG_K24(TO_, NB_) hipLaunchKernelGGL((dec_cross_attn_k24_kernel<TO_, NB_>), grid, block, 0, s, st, (const float*)q, (const unsigned char*)ck, (const unsigned char*)cv, out, H, Tk, d, pi, (const float*)q_bias, scale)
     if (dtype == WSEG_BF16X3) { if (st.nb <= 1) WSEG_K24(X3<bf16_t>, 1); else if (st.nb <= 2) WSEG_K24(X3<bf16_t>, 2); else WSEG_K24(X3<bf16_t>, 4); }
@@ -1231,6 +1406,7 @@ int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const
     WSEG_LAUNCH_CHECK();
     return WSEG_OK;
   }
+#endif
   static const bool deep = getenv("WSEG_CROSS_NO_PK") == nullptr;         // tuning knob: fp32-FMA kernel
   if ((dtype == WSEG_BF16 || dtype == WSEG_F16) && deep && Tk <= 512 && st.nb <= 4) {
     dim3 grid(st.W * H), block(256);

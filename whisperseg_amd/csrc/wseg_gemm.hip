@@ -44,6 +44,36 @@ template <> struct Vec4<float> {
   static __device__ __forceinline__ void st(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
 };
 
+// Cross K / V as block floating point (EpiParams::kv24 == 2): the NL lanes that hold the 64 columns of one (position, head) row — 8
+// consecutive lanes with 8 columns each (LDS-staged epilogues) or 16 with 4 each (split-K reduction) — agree on the row's power-of-two
+// scale by DPP (the smallest 2^s with max|v| <= 2^15 * 2^s ... so that |v / 2^s| <= 32767 after the clamp), every lane stores its columns
+// as int16 (round to nearest even) and the first lane the scale.  blk: the (slot, head) block [t_len][64] int16 + [t_len] float.
+template <int NC>
+__device__ __forceinline__ void st_bfp16_row(unsigned char* blk, int t_len, int t, int e, const float (&v)[NC], bool first_lane) {
+  static_assert(NC == 4 || NC == 8, "4 or 8 columns per lane");
+  float am = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) am = fmaxf(am, fabsf(v[i]));
+  am = fmaxf(am, lane_xor<1>(am));
+  am = fmaxf(am, lane_xor<2>(am));
+  am = fmaxf(am, lane_xor<4>(am));
+  if constexpr (NC == 4) am = fmaxf(am, lane_xor<8>(am));
+  const unsigned bits = __float_as_uint(am);
+  int ex = (int)(bits >> 23) - 127 + ((bits & 0x7fffffu) ? 1 : 0) - 15;      // ceil(log2 max) - 15
+  ex = max(-110, min(ex, 110));
+  const float inv = __uint_as_float((unsigned)(127 - ex) << 23), scl = __uint_as_float((unsigned)(127 + ex) << 23);
+  int q[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) q[i] = max(-32767, min(32767, (int)__builtin_rintf(v[i] * inv)));
+  unsigned w[NC / 2];
+#pragma unroll
+  for (int i = 0; i < NC / 2; ++i) w[i] = ((unsigned)q[2 * i] & 0xffffu) | ((unsigned)q[2 * i + 1] << 16);
+  unsigned char* dst = blk + (size_t)t * 128 + e * 2;
+  if constexpr (NC == 8) *(uint4*)dst = make_uint4(w[0], w[1], w[2], w[3]);
+  else *(uint2*)dst = make_uint2(w[0], w[1]);
+  if (first_lane) *(float*)(blk + (size_t)t_len * 128 + (size_t)t * 4) = scl;
+}
+
 // T: element-type tag of the mode (float | bf16_t | f16_t | X3<HT>); PT: its plain parameter type (bias, positional table,
 // q / k / v storage: float in the split-precision modes).  Outputs that are the NEXT GEMM's operand (EPI_STORE, EPI_GELU) go
 // through op_st*, i.e. as hi | lo pairs in the split-precision modes.
@@ -111,7 +141,10 @@ __device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, fl
     const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
     const int b = m / ep.t_len, t = m - b * ep.t_len;
     const int bs = ep.slot_map ? ep.slot_map[b] : b;
-    if (IO<T>::split && ep.kv24) {
+    if (IO<T>::split && ep.kv24 == 2) {      // (reached from the split-K reduction only: 16 consecutive threads hold one row)
+      unsigned char* blk = (unsigned char*)(sec == 0 ? ep.k : ep.v) + ((size_t)bs * ep.n_heads + h) * ep.t_len * 132;
+      st_bfp16_row<4>(blk, ep.t_len, t, e, *(const float(*)[4])v, e == 0);
+    } else if (IO<T>::split && ep.kv24) {
       unsigned char* blk = (unsigned char*)(sec == 0 ? ep.k : ep.v) + ((size_t)bs * ep.n_heads + h) * ep.t_len * 192;
       unsigned w[4];
 #pragma unroll
@@ -231,7 +264,10 @@ __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, f
     const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
     const int b = m / ep.t_len, t = m - b * ep.t_len;
     const int bs = ep.slot_map ? ep.slot_map[b] : b;
-    if (IO<T>::split && ep.kv24) {
+    if (IO<T>::split && ep.kv24 == 2) {      // the 8 lanes of the row (LDS-staged epilogues: lane & 7 = column group)
+      unsigned char* blk = (unsigned char*)(sec == 0 ? ep.k : ep.v) + ((size_t)bs * ep.n_heads + h) * ep.t_len * 132;
+      st_bfp16_row<8>(blk, ep.t_len, t, e, *(const float(*)[8])v, e == 0);
+    } else if (IO<T>::split && ep.kv24) {
       EpiParams e2 = ep;                        // the bias has been added above
       e2.bias = nullptr;
       epi_apply<EPI, T>(e2, m, n0, v);
@@ -550,8 +586,10 @@ __global__ __launch_bounds__(WM * WN * 64, (BM <= 128 && BN <= 64 && WM * WN == 
 // gfx9, so a load issued after a store cannot be consumed before that store has completed — a bias load per
 // output row made each of the 16 stores a full round trip (measured 16-42 % of a launch).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int EPI, int MI, int NI>
-__device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NI][MI], float* stage, const EpiParams& ep, int M, int mb,
+// (NIT / I0: the accumulator array holds NIT column tiles of which I0 .. I0 + 3 are written — the 128x128 wave tiles of gemm_w4_kernel
+// go out as two 64-column halves)
+template <typename T, int EPI, int MI, int NI, int NIT = NI, int I0 = 0>
+__device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NIT][MI], float* stage, const EpiParams& ep, int M, int mb,
                                                 int nb, int lane, int wave) {
   static_assert(NI == 4, "64-column wave tiles");
   typedef typename IO<T>::P PT;
@@ -596,7 +634,7 @@ __device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NI][MI], floa
   for (int j = 0; j < MI; ++j) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
-      *(float4*)(strip + fr * LDT + i * 16 + fg * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      *(float4*)(strip + fr * LDT + i * 16 + fg * 4) = make_float4(acc[I0 + i][j][0], acc[I0 + i][j][1], acc[I0 + i][j][2], acc[I0 + i][j][3]);
     // same-wave LDS RAW: ds ops of one wave complete in order, the compiler waits lgkmcnt before the reads
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
@@ -1225,6 +1263,406 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   if (wr == 0) __builtin_amdgcn_s_barrier();          // pair group 1's extra barrier
 }
 
+// ================================================================================================
+// EXPERIMENT, knob builds only (python -m whisperseg_amd.build --variant w4 -DWSEG_KNOBS=1; WSEG_GEMM_W4=1): the one-wave-per-SIMD kernel
+// VERDICT r04 asked for.  Built, parity-green, measured with cycle stamps — and slower than the ping-pong kernel above, for a reason
+// the stamps name (profiles/r05_w4_experiments.txt): the product library does not carry it.
+// ================================================================================================
+#ifdef WSEG_KNOBS
+// ------------------------------------------------------------------------------------------------
+// Epilogue of gemm_w4_kernel: the wave tile is 4 x 4 accumulator tiles of 32 x 32 (v_mfma_f32_32x32x16: lane (c = lane & 31, h = lane >> 5)
+// holds, of output row m = c, the columns n = 8 q + 4 h + {0..3}, q = 0..3, in registers 4 q .. 4 q + 3).  One 32-row x 32-column tile
+// at a time goes through the wave's own LDS strip so that 4 lanes cover one 128-byte output row piece with 16-byte accesses and a quad
+// of lanes owns one 32-column block (what the cooperative M6 row writer needs).  As in staged_epilogue: every global load (bias,
+// residual rows, the slot map) is issued before the first store it could queue behind.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int EPI>
+__device__ __forceinline__ void staged_epilogue32(const f32x16 (&acc)[4][4], float* stage, const EpiParams& ep, int M, int mb, int nb, int lane,
+                                                  int wave) {
+  typedef typename IO<T>::P PT;
+  constexpr int LDT = 32 + 4;
+  float* strip = stage + (size_t)wave * 32 * LDT;
+  const int c32 = lane & 31, h = lane >> 5, rr = lane >> 2, cc = (lane & 3) * 8;
+  int kv_b0 = 0, kv_s0 = 0, kv_s1 = 0;
+  EpiParams ep2 = ep;
+  ep2.bias = nullptr;
+  if constexpr (EPI == EPI_KV_CROSS) {      // the (at most two: 128 rows <= t_len) windows this wave tile touches
+    if (ep.slot_map) {
+      const int nwin = (M + ep.t_len - 1) / ep.t_len;
+      kv_b0 = min(mb, M - 1) / ep.t_len;
+      kv_s0 = ep.slot_map[kv_b0];
+      kv_s1 = ep.slot_map[min(kv_b0 + 1, nwin - 1)];
+      ep2.slot_map = nullptr;
+    }
+  }
+  float bv[4][8];                           // the bias of all four column blocks, requested before the first store
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (ep.bias) ld8_h<PT>((const PT*)ep.bias + nb + i * 32 + cc, bv[i]);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[i][e] = 0.f;
+    }
+  }
+  // fp32 residual rows: a ring of 8 row pieces (16 rows x 32 columns each: two 16-byte loads per lane).  All 8 pieces of column block 0
+  // are requested before the first store; piece t of block i + 1 is requested right after piece t of block i has been stored, 7 stores
+  // ahead of its use, so it never waits for a store it was issued behind (vmcnt retires in order).
+  float4 rres[EPI == EPI_RESID ? 8 : 1][2];
+  auto resid_req = [&](int i, int t) __attribute__((always_inline)) {
+    const float* rp = (const float*)ep.resid + (size_t)min(mb + t * 16 + rr, M - 1) * ep.ldc + nb + i * 32 + cc;
+    rres[t][0] = *(const float4*)rp; rres[t][1] = *(const float4*)(rp + 4);
+  };
+  if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) resid_req(0, t);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {             // 32 columns nb + 32 i ..
+    const int nc = nb + i * 32 + cc;
+    // An UNCONDITIONAL use of the loaded registers (rows beyond M skip the real one): without it a load stays "pending" in the compiler's
+    // scoreboard across the loop back edge and costs an s_waitcnt vmcnt(0) — a drain of the LDS-DMA prefetch stream — in every K-tile
+    // pair of the caller's main loop (the compiler does not see the waits inside asm statements, but it does see asm operands)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) asm volatile("" :: "v"(bv[i][e]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {           // 32 rows mb + 32 j ..
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(float4*)(strip + c32 * LDT + 8 * q + 4 * h) = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+      // same-wave LDS RAW / WAR: the ds operations of one wave complete in order
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int rw = hh * 16 + rr;
+        const float4 a = *(const float4*)(strip + rw * LDT + cc), b = *(const float4*)(strip + rw * LDT + cc + 4);
+        float v[8] = {a.x + bv[i][0], a.y + bv[i][1], a.z + bv[i][2], a.w + bv[i][3], b.x + bv[i][4], b.y + bv[i][5], b.z + bv[i][6], b.w + bv[i][7]};
+        const int m = mb + j * 32 + rw;
+        if constexpr (EPI == EPI_RESID) {
+          const int t = j * 2 + hh;
+          const float4 r0 = rres[t][0], r1 = rres[t][1];
+          asm volatile("" :: "v"(r0.x), "v"(r0.y), "v"(r0.z), "v"(r0.w), "v"(r1.x), "v"(r1.y), "v"(r1.z), "v"(r1.w));
+          if (m < M) {
+            float* o = (float*)ep.out + (size_t)m * ep.ldc + nc;
+            *(float4*)o = make_float4(r0.x + v[0], r0.y + v[1], r0.z + v[2], r0.w + v[3]);
+            *(float4*)(o + 4) = make_float4(r1.x + v[4], r1.y + v[5], r1.z + v[6], r1.w + v[7]);
+          }
+          if (i + 1 < 4) resid_req(i + 1, t);
+        } else if constexpr (EPI == EPI_KV_CROSS) {
+          int mm = m;
+          if (ep.slot_map) { const int bw = m / ep.t_len; mm = (bw == kv_b0 ? kv_s0 : kv_s1) * ep.t_len + (m - bw * ep.t_len); }
+          if (m < M) epi_apply8<EPI, T>(ep2, mm, nc, v);
+        } else {
+          if (m < M) epi_apply8<EPI, T>(ep2, m, nc, v);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One-wave-per-SIMD persistent kernel for the large encoder GEMMs (r05): 256x256 tile, 4 waves = 2 x 2 wave tiles of 128x128 as 4 x 4
+// accumulator tiles of v_mfma_f32_32x32x16 — sixteen 16-register tuples: the 256 accumulator registers of a wave fill the AGPR half of
+// its 512-register file (sixty-four 4-register tuples of the 16x16 instruction made the register allocator shuffle accumulators
+// between the two halves with hundreds of v_accvgpr moves per K tile) —, 128 KB of LDS = two K-tile buffers of [A tile 256 x 64 words
+// | W tile 256 x 64 words] + an 18-KB epilogue staging area of its own (the K-tile stream never pauses at an output-tile boundary).
+// Against the 8-wave ping-pong kernel above: a third fewer fragment bytes per MFMA (32 ds_read_b128 per 64 K words of a 128x128 wave
+// tile instead of 24 per 128x64), half as many waves issuing LDS-DMA, ONE barrier per K tile and no hand-over between row groups:
+// the wave's own instruction stream interleaves fragment reads, LDS-DMA issue and MFMAs (sched_group_barrier).
+//
+// Stream of K tiles g = 0, 1, 2, ... (continuous across the output tiles a workgroup owns), tile g in buffer g & 1.  Per tile:
+//     first half :  32 MFMAs on the fragments of k-steps 0, 1 (in registers)   ||  ds_reads of k-steps 2, 3 of tile g
+//     mid        :  s_waitcnt vmcnt(0) lgkmcnt(0) ; s_barrier    -> every wave has finished READING buffer g & 1 and its pieces of
+//                                                                   tile g + 1 (requested half a tile + ago) have LANDED
+//     second half:  32 MFMAs on k-steps 2, 3   ||  ds_reads of k-steps 0, 1 of tile g + 1 (other buffer)  ||  LDS-DMA of tile g + 2
+//                                                                   into buffer g & 1 (16 pieces of 1 KB per wave)
+// so a tile has a whole half (>= 1024 matrix-pipe cycles) to land before anybody waits for it.
+// M6 rows (WSEG_F16M6): tiles alternate hi (buffer 0: the plain schedule) / MX (buffer 1): an MX tile is two scaled MFMAs
+// (v_mfma_scale_f32_32x32x64_f8f6f4, fp6 e2m3) per accumulator tile — instruction t takes chunk 2 t + (lane >> 5) of both operands'
+// MX blocks: t = 0 pairs activation lo6 with weight hi6, t = 1 activation hi6 with weight lo6 (wseg_common.h) — and its halves are
+// the two instructions: the t = 0 fragments are read during the hi tile's second half, the t = 1 fragments during the MX tile's first
+// half, the next hi tile's first fragments during its second half.  Every half reads 16 fragments; the 512-register file has room
+// for the builtin's 8-register operand tuples: no inline assembly.
+// LDS image: 128-byte rows, logical 16-byte slot s of row r at slot s ^ ((r >> 1) & 7) (conflict-free for 32-row fragments).
+// ------------------------------------------------------------------------------------------------
+// Measurement builds only (python -m whisperseg_amd.build --stamps 6, tools/w4_stamps.py): workgroup 0 records the shader clock of its
+// four waves at the boundaries of the halves of its first K tiles (4 stamps per tile) and around its epilogues.
+#if defined(WSEG_STAMPS) && WSEG_STAMPS == 6
+__device__ unsigned long long g_w4_stamps[4 * 512 + 32];      // + (shader cycles, 100-MHz ticks) at the epilogues of wave 0: the effective clock
+#ifdef WSEG_W4_STAMP_LIGHT      // tile tops and epilogue bounds only (a stamp costs ~130 cycles: six per K tile distort what they measure)
+#define WSEG_W4_STAMP(TAG) do { if ((TAG) == 1 || (TAG) == 5 || (TAG) == 9 || (TAG) == 10) { if (blockIdx.x == 0 && lane == 0 && sc < 512) { \
+    g_w4_stamps[wave * 512 + sc] = (__builtin_readcyclecounter() << 4) | (TAG); } ++sc; } } while (0)
+#else
+#define WSEG_W4_STAMP(TAG) do { if (blockIdx.x == 0 && lane == 0 && sc < 512) { \
+    g_w4_stamps[wave * 512 + sc] = (__builtin_readcyclecounter() << 4) | (TAG); } ++sc; } while (0)
+#endif
+#else
+#define WSEG_W4_STAMP(TAG) do { } while (0)
+#endif
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm_w4_kernel(const typename IO<T>::H* __restrict__ A, int lda, const typename IO<T>::H* __restrict__ W,
+                                                      int ldw, int M, int N, int K, EpiParams ep, int ntm, int GM) {
+  typedef typename IO<T>::H HT;
+  constexpr bool MXM = IsMx<T>::v;
+  static_assert(!IO<T>::split || MXM, "plain 16-bit operands or M6 rows");
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int OPER = 256 * BK;                   // elements of one operand tile (32 KB)
+  constexpr int BUF = 2 * OPER;                    // [A tile | W tile]
+  constexpr int LDT = 32 + 4;
+  __shared__ __attribute__((aligned(16))) HT smem[2 * BUF + 4 * 32 * LDT * 2];      // + staging: 4 strips of 32 x 36 floats
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 31, fh = lane >> 5;
+  [[maybe_unused]] int sc = 0, ec = 0;             // stamp / epilogue counters (measurement builds)
+  const int ntn = N / BN, ntiles = ntm * ntn, nk = K / BK;      // nk is even (launcher)
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int count = q8 + (xcd < r8 ? 1 : 0);
+  if (loc >= count) return;
+  auto tile_coords = [&](int swz, int& m0, int& n0) __attribute__((always_inline)) {
+    const int per_group = GM * ntn, grp = swz / per_group, rem = swz - grp * per_group;
+    const int gm = min(GM, ntm - grp * GM);
+    m0 = (grp * GM + rem % gm) * BM;
+    n0 = (rem / gm) * BN;
+  };
+
+  // ---- LDS-DMA stream: a wave streams 64 rows of each operand tile as 8 pieces of 8 rows (1 KB: lane l -> row l >> 3, LDS slot l & 7).
+  // Row r = 8 p + (l >> 3) of the wave's 64 holds logical slot (l & 7) ^ ((r >> 1) & 7) = (l & 7) ^ (4 (p & 1) + (l >> 4)): one lane
+  // offset for the even pieces, one for the odd ones.  The cursor is two uniform byte pointers; NOTHING inside a K-tile pair branches
+  // (a branch splits the basic block the scheduler interleaves MFMAs, fragment reads and LDS-DMA issue in, and the compiler sinks
+  // MFMAs across it): the pairs inside an output tile advance the pointers by one K tile per request, the pair that crosses into the
+  // next output tile takes that tile's pointers, computed once per output tile ----
+  // The requests are MUBUF instructions (buffer_load_dwordx4 ... lds: base in a 4-SGPR buffer descriptor per operand and output tile,
+  // the piece and K offsets in the scalar offset, the lane offset in a 32-bit VGPR): unlike global_load_lds they are VMEM to the
+  // compiler's sched_group_barrier, so they can be PLACED between the MFMAs — as FLAT instructions all 16 of a half were issued in one
+  // burst at its head, ~65 cycles each with the matrix pipe idle (cycle stamps: 2 200 instead of 1 100 cycles per half).
+  const int lrow = lane >> 3, lsl = lane & 7;
+  const int a_lane0 = (lrow * lda + ((lsl ^ (lane >> 4)) << 3)) * (int)sizeof(HT);
+  const int a_lane1 = (lrow * lda + ((lsl ^ (4 + (lane >> 4))) << 3)) * (int)sizeof(HT);
+  const int w_lane0 = (lrow * ldw + ((lsl ^ (lane >> 4)) << 3)) * (int)sizeof(HT);
+  const int w_lane1 = (lrow * ldw + ((lsl ^ (4 + (lane >> 4))) << 3)) * (int)sizeof(HT);
+  auto lane_off = [&](int kept) __attribute__((always_inline)) -> int { int t = kept; asm volatile("" : "+v"(t)); return t; };
+  const int a_piece = 8 * lda * (int)sizeof(HT), w_piece = 8 * ldw * (int)sizeof(HT);
+  constexpr int K_STEP = BK * (int)sizeof(HT);
+  typedef __amdgpu_buffer_rsrc_t rsrc_t;
+  auto tile_rsrc = [&](int seq, rsrc_t& pa, rsrc_t& pw) __attribute__((always_inline)) {
+    int tm, tn;
+    tile_coords(start + seq, tm, tn);
+    pa = __builtin_amdgcn_make_buffer_rsrc((void*)(A + ((size_t)tm + wave * 64) * lda), 0, -1, 0x00020000);
+    pw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + ((size_t)tn + wave * 64) * ldw), 0, -1, 0x00020000);
+  };
+  rsrc_t ra, rw;                                   // descriptors of this wave's 64 rows of the output tile the requests are in
+  int kofs = 0;                                    // ... and the byte offset of the next K tile to request
+  tile_rsrc(loc, ra, rw);
+  typedef __attribute__((address_space(3))) void* lds_vp;
+  auto issue = [&](auto btag) __attribute__((always_inline)) {      // this wave's 16 pieces of the K tile at the cursor into buffer B; the cursor advances
+    constexpr int B = decltype(btag)::value;
+    HT* dA = smem + B * BUF + wave * 4096;
+    HT* dW = dA + OPER;
+    const int al0 = lane_off(a_lane0), al1 = lane_off(a_lane1), wl0 = lane_off(w_lane0), wl1 = lane_off(w_lane1);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vp)(dA + p * 512), 16, (p & 1) ? al1 : al0, kofs + p * a_piece, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vp)(dW + p * 512), 16, (p & 1) ? wl1 : wl0, kofs + p * w_piece, 0, 0);
+    }
+    kofs += K_STEP;
+  };
+
+  // ---- fragment addresses (bytes): row t*32 + fr of the wave's 128 rows; hi tiles: k-step ks (16 words) = logical slot 2 ks + fh;
+  // MX tiles: instruction t reads chunk 2 t + fh = logical slots 4 t + 2 fh, + 1.  Buffer 1 is 64 KB up. ----
+  const char* const lds = (const char*)smem;
+  const int swz = (fr >> 1) & 7;
+  const int frag = fr * 128 + ((fh ^ swz) << 4);               // ks = 0; ks: ^ (ks << 5)
+  const int offA = wm * 16384, offW = 32768 + wn * 16384;
+  const char* const fa = lds + offA + frag, * const fw = lds + offW + frag;
+  [[maybe_unused]] const int mfrag = fr * 128 + (((2 * fh) ^ swz) << 4);      // t = 0, first slot; second slot ^ 16; t = 1: ^ 64
+  [[maybe_unused]] const char* const ma = lds + 65536 + offA + mfrag, * const mw = lds + 65536 + offW + mfrag;
+
+  f32x16 acc[4][4];                                // [n tile i][m tile j]
+  bf16x8 a0[2][4], w0[2][4], a1[2][4], w1[2][4];   // fragments of k-steps 0, 1 / 2, 3
+  [[maybe_unused]] MxFrag am0[4], wx0[4], am1[4], wx1[4];      // MX fragments of instruction t = 0 / 1
+
+  auto mid_barrier = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+#if defined(WSEG_STAMPS) && WSEG_STAMPS == 6 && !defined(WSEG_W4_STAMP_LIGHT)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    WSEG_W4_STAMP(11);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WSEG_W4_STAMP(12);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // k-steps 2 H, 2 H + 1 of the tile in buffer B
+  auto ld_half = [&](auto btag, auto htag, bf16x8 (&af)[2][4], bf16x8 (&wf)[2][4]) __attribute__((always_inline)) {
+    constexpr int O = decltype(btag)::value * 65536, H = decltype(htag)::value;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      constexpr int dummy = 0; (void)dummy;
+      const int x = (2 * H + s2) << 5;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) af[s2][j] = *(const bf16x8*)(lds + ((int)(fa - lds) ^ x) + O + j * 4096);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf[s2][i] = *(const bf16x8*)(lds + ((int)(fw - lds) ^ x) + O + i * 4096);
+    }
+  };
+  // (the chunk halves are read as the SAME vector type as the hi fragments: through HIP's uint4 the compiler put an s_waitcnt vmcnt(0)
+  // — a drain of the LDS-DMA stream — in front of these reads in every pair, and narrowed the second read to ds_read_b96 + two v_mov)
+  typedef int mx_i32x4 __attribute__((ext_vector_type(4)));
+  [[maybe_unused]] auto ld_mx = [&](auto ttag, MxFrag (&af)[4], MxFrag (&wf)[4]) __attribute__((always_inline)) {
+    constexpr int X = decltype(ttag)::value << 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const mx_i32x4 q0 = __builtin_bit_cast(mx_i32x4, *(const bf16x8*)(lds + ((int)(ma - lds) ^ X) + j * 4096));
+      const mx_i32x4 q1 = __builtin_bit_cast(mx_i32x4, *(const bf16x8*)(lds + ((int)(ma - lds) ^ X ^ 16) + j * 4096));
+      af[j].v = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const mx_i32x4 q0 = __builtin_bit_cast(mx_i32x4, *(const bf16x8*)(lds + ((int)(mw - lds) ^ X) + i * 4096));
+      const mx_i32x4 q1 = __builtin_bit_cast(mx_i32x4, *(const bf16x8*)(lds + ((int)(mw - lds) ^ X ^ 16) + i * 4096));
+      wf[i].v = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+  auto mfma_half = [&](const bf16x8 (&wf)[2][4], const bf16x8 (&af)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = H16<HT>::mfma32(wf[s2][i], af[s2][j], acc[i][j]);
+  };
+  [[maybe_unused]] auto mfma_mx = [&](const MxFrag (&wf)[4], const MxFrag (&af)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[i].v, af[j].v, acc[i][j], 2, 2, 0, wf[i].v[6], 0, af[j].v[6]);
+  };
+#define WSEG_W4_SCHED(NREP, NDS, NVM, NMF)                                              \
+  _Pragma("unroll") for (int sg_ = 0; sg_ < (NREP); ++sg_) {                            \
+    if ((NDS) > 0) __builtin_amdgcn_sched_group_barrier(0x100, (NDS), 0);               \
+    if ((NVM) > 0) __builtin_amdgcn_sched_group_barrier(0x020, (NVM), 0);               \
+    __builtin_amdgcn_sched_group_barrier(0x008, (NMF), 0);                              \
+  }
+  // second halves: 16 / PER groups of {PER fragment reads, NMF MFMAs}, then as many of {PER requests, NMF MFMAs}: one request per MFMA
+  // slot — an LDS-DMA issue blocks the wave's in-order issue for ~50-65 cycles, of which one MFMA in flight covers 32; two requests
+  // back to back leave the matrix pipe idle for the second one (cycle stamps: 1 520 against 1 124 cycles per 32-MFMA half)
+#define WSEG_W4_SCHED2(HAS_DS, HAS_VM, PER, NMF)                                        \
+  _Pragma("unroll") for (int sg_ = 0; sg_ < 16 / (PER); ++sg_) {                        \
+    if (HAS_DS) __builtin_amdgcn_sched_group_barrier(0x100, (PER), 0);                  \
+    __builtin_amdgcn_sched_group_barrier(0x008, (NMF), 0);                              \
+  }                                                                                     \
+  _Pragma("unroll") for (int sg_ = 0; sg_ < 16 / (PER); ++sg_) {                        \
+    if (HAS_VM) __builtin_amdgcn_sched_group_barrier(0x020, (PER), 0);                  \
+    __builtin_amdgcn_sched_group_barrier(0x008, (NMF), 0);                              \
+  }
+  constexpr std::integral_constant<int, 0> B0{};
+  constexpr std::integral_constant<int, 1> B1{};
+  constexpr std::true_type YES{};
+  constexpr std::false_type NO{};
+
+  // One plain / hi K tile in buffer B.  NEXT1: K tile g + 1 exists (its first fragments are read in the second half); NEXT2: K tile
+  // g + 2 exists (requested in the second half).  Both are compile-time: the code of a pair never branches.
+  auto tile16 = [&](auto btag, auto next1_tag, auto next2_tag) __attribute__((always_inline)) {
+    constexpr int B = decltype(btag)::value;
+    constexpr bool NEXT1 = decltype(next1_tag)::value, NEXT2 = decltype(next2_tag)::value;
+    const std::integral_constant<int, B ^ 1> other{};
+    WSEG_W4_STAMP(1);
+    ld_half(btag, B1, a1, w1);
+    mfma_half(w0, a0);
+    WSEG_W4_SCHED(16, 1, 0, 1)                     // the 16 reads between the first 16 MFMAs: retired long before the barrier asks
+    WSEG_W4_STAMP(2);
+    mid_barrier();
+    WSEG_W4_STAMP(3);
+    // (source order = the order the scheduler must keep: an LDS-DMA is an LDS store it cannot tell apart from the fragment reads; a
+    // sched_group_barrier pipeline that asks for the opposite order is dropped as a whole and the half runs reads, requests, MFMAs
+    // back to back.  Reads first: they are retired by the time the next half needs them; the requests still have a half + to land)
+    if constexpr (MXM) {                           // the MX tile g + 1 (buffer 1) always exists: K ranges are whole (hi, MX) pairs
+      ld_mx(B0, am0, wx0);
+      if constexpr (NEXT2) issue(B0);
+    } else {
+      if constexpr (NEXT1) ld_half(other, B0, a0, w0);
+      if constexpr (NEXT2) issue(btag);
+    }
+    mfma_half(w1, a1);
+    WSEG_W4_SCHED2(MXM || NEXT1, NEXT2, 1, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    WSEG_W4_STAMP(4);
+  };
+  // the MX tile (buffer 1) of an M6 pair; NEXT1 / NEXT2 as above (the next tile is a hi tile in buffer 0)
+  [[maybe_unused]] auto tile_mx = [&](auto next1_tag, auto next2_tag) __attribute__((always_inline)) {
+    constexpr bool NEXT1 = decltype(next1_tag)::value, NEXT2 = decltype(next2_tag)::value;
+    WSEG_W4_STAMP(5);
+    ld_mx(B1, am1, wx1);
+    mfma_mx(wx0, am0);
+    WSEG_W4_SCHED(8, 2, 0, 1)
+    WSEG_W4_STAMP(6);
+    mid_barrier();
+    WSEG_W4_STAMP(7);
+    if constexpr (NEXT1) ld_half(B0, B0, a0, w0);
+    if constexpr (NEXT2) issue(B1);
+    mfma_mx(wx1, am1);
+    WSEG_W4_SCHED2(NEXT1, NEXT2, 2, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    WSEG_W4_STAMP(8);
+  };
+  auto pair_mid = [&]() __attribute__((always_inline)) {       // both tiles have a tile 1 and 2 ahead of them
+    tile16(B0, YES, YES);
+    if constexpr (MXM) tile_mx(YES, YES); else tile16(B1, YES, YES);
+  };
+  auto pair_end = [&]() __attribute__((always_inline)) {       // the last pair of the workgroup's stream
+    tile16(B0, YES, NO);
+    if constexpr (MXM) tile_mx(NO, NO); else tile16(B1, NO, NO);
+  };
+
+  // prologue: K tiles 0 and 1 requested, tile 0 landed, its first fragments in registers
+  issue(B0);
+  issue(B1);
+  asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+  ld_half(B0, B0, a0, w0);
+
+  for (int idx = loc; idx < count; idx += bpx) {
+    int m0, n0;
+    tile_coords(start + idx, m0, n0);
+    const bool more = idx + bpx < count;
+    rsrc_t nra = ra, nrw = rw;                     // the next output tile
+    if (more) tile_rsrc(idx + bpx, nra, nrw);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // Stretches of straight-line code (one loop body behind a branch makes the register allocator shuffle accumulators between the two
+    // halves of the register file and spill): the pairs whose requests stay inside this output tile; then the pair whose two requests
+    // are K tiles 0 and 1 of the next output tile — or, at the end of the stream, the pair that requests nothing
+#pragma nounroll
+    for (int kt = 2; kt < nk; kt += 2) pair_mid();
+    ra = nra; rw = nrw; kofs = 0;
+#pragma nounroll
+    for (int once = more ? 1 : 0; once > 0; --once) pair_mid();
+#pragma nounroll
+    for (int once = more ? 0 : 1; once > 0; --once) pair_end();
+    // LDS-staged epilogue in the wave's own strip of the staging area (no barrier: the strips are wave-private and no K-tile buffer
+    // is touched; the next tiles keep landing meanwhile)
+#if defined(WSEG_STAMPS) && WSEG_STAMPS == 6
+    if (blockIdx.x == 0 && wave == 0 && lane == 0 && ec < 16) { g_w4_stamps[4 * 512 + 2 * ec] = __builtin_readcyclecounter(); g_w4_stamps[4 * 512 + 2 * ec + 1] = wall_clock64(); }
+    ++ec;
+#endif
+    WSEG_W4_STAMP(9);
+    staged_epilogue32<T, EPI>(acc, (float*)(smem + 2 * BUF), ep, M, m0 + wm * 128, n0 + wn * 128, lane, wave);
+    WSEG_W4_STAMP(10);
+  }
+#undef WSEG_W4_SCHED
+#undef WSEG_W4_SCHED2
+}
+
+#endif      // WSEG_KNOBS
+
 template <int EPI, typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, int m_pad,
                                                             int M, int N, EpiParams ep) {
@@ -1732,6 +2170,23 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
       }
       // (Measured and dropped, r04: the generic kernel as 4 waves x 128x128 wave tiles, one wave per SIMD — a third fewer fragment
       // reads per MFMA, but with nothing to hide its per-K-tile barriers behind: 640 against 1 080 TFLOP/s on the encoder shapes.)
+      // r05 experiment (knob builds): the one-wave-per-SIMD kernel (plain 16-bit operands and M6 rows, an even number of K tiles)
+#ifdef WSEG_KNOBS
+      if constexpr (!IO<T>::split || std::is_same<T, M6>::value) {
+#ifndef WSEG_W4_DEFAULT
+#define WSEG_W4_DEFAULT 0
+#endif
+        static const bool use_w4 = WSEG_KNOB_INT("WSEG_GEMM_W4", WSEG_W4_DEFAULT) != 0;
+        if (use_w4 && !g0.hi_only && (g.K / 64) % 2 == 0 && EPI != EPI_QKV_DEC && EPI != EPI_SCALE) {
+          int grid = ntiles < n_cu ? ntiles : n_cu;
+          grid &= ~7;
+          hipLaunchKernelGGL((gemm_w4_kernel<T, EPI>), dim3(grid), dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K, g.ep, ntm, group_m);
+          if (e1) (void)hipEventRecord(e1, s);
+          WSEG_LAUNCH_CHECK();
+          return WSEG_OK;
+        }
+      }
+#endif
       {
         int grid = ntiles < n_cu ? ntiles : n_cu;
         grid &= ~7;
@@ -1775,7 +2230,11 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
     return WSEG_OK;
   }
   SkinnyPlan sp = plan_skinny(g, IsMx<T>::v);
-  if (sp.splits == 1) {
+  // (block-floating-point cross K / V: the row writer needs the lanes of a row side by side, which the 4-column MFMA-layout epilogue of
+  // the stream kernels does not give — an un-split plan goes through the partial plane + reduction kernel as well)
+  const bool coop_kv = EPI == EPI_KV_CROSS && IO<T>::split && g.ep.kv24 == 2;
+  if (sp.splits == 1 && !(coop_kv && g.splitk_ws && (size_t)sp.m_pad * g.N * sizeof(float) <= g.splitk_ws_bytes)) {
+    if (coop_kv) { set_error("gemm: block-floating-point cross K / V needs the split-K workspace"); return WSEG_ERR_STATE; }
     dim3 grid(g.N / 64, sp.mt, 1);
 #define WSEG_SKINNY(BM_, WM_, WN_)                                                                                      \
   hipLaunchKernelGGL((gemm_h16_kernel<T, BM_, 64, WM_, WN_, EPI, false, 2>), grid, dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, \
@@ -2036,6 +2495,11 @@ extern "C" int wseg_profile_end(double* total_flops, double* total_ms, int64_t* 
   return WSEG_OK;
 }
 
+#if defined(WSEG_STAMPS) && WSEG_STAMPS == 6 && defined(WSEG_KNOBS)
+extern "C" int wseg_debug_w4_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wseg::g_w4_stamps), sizeof(unsigned long long) * (4 * 512 + 32));
+}
+#endif
 #if defined(WSEG_STAMPS) && WSEG_STAMPS == 4
 extern "C" int wseg_debug_pp_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wseg::g_pp_stamps), sizeof(unsigned long long) * 132);

@@ -54,8 +54,10 @@ struct EpiParams {
   int qkv_mode = 0;              // split-precision modes, EPI_QKV_ENC storage of Q / K / V^T (x3_enc_attention_mode): 0 = IEEE half,
                                  // 1 = fp32 (fp32 attention kernel), 2 = half hi + lo planes, the lo plane qkv_plane elements behind
   size_t qkv_plane = 0;
-  int kv24 = 0;                  // split-precision modes, EPI_KV_CROSS: 1 = cross K / V as 24-bit values in two planes per (slot, head)
-                                 // — [t_len][64] top halves (16 bits) then [t_len][64] third bytes — instead of fp32 (x3_cross_kv24)
+  int kv24 = 0;                  // split-precision modes, EPI_KV_CROSS storage of the cross K / V (x3_cross_kv_format): 0 = fp32;
+                                 // 1 = 24-bit values in two planes per (slot, head): [t_len][64] top halves (16 bits) then [t_len][64]
+                                 // third bytes; 2 (default, r05) = block floating point, one block per (position, head) row:
+                                 // [t_len][64] int16 then [t_len] fp32 powers of two, value = int16 * scale (132 bytes per row)
 };
 
 struct GemmArgs {
@@ -106,7 +108,12 @@ int x3_enc_attention_mode();
 // split-precision modes: cross-attention K / V stored as fp32 words rounded to their top 24 bits (sign, exponent, 15 + 1 mantissa
 // bits — the ">= 16 bits" the precision study asks of the cross K; 3 instead of 4 bytes per element of an HBM-bound stream).
 // Default on; WSEG_X3_CKV=f32 keeps fp32.
-bool x3_cross_kv24();
+// Storage format of the cross-attention K / V in the split-precision modes (EpiParams::kv24) and its bytes per (position, head) row.
+// 2 = per-row block floating point (r05): the 200-recording sweep through the CPU oracle with K and V so quantised is 200 / 200 and the
+// first-step logit error stays at the mode's own 1.5e-4 (24-bit: 1.5e-4; plain half: 7.5e-4, 196 / 200; tools/precision_study.py
+// "ckv=bfp16r", profiles/r05_precision_study.json) for 132 instead of 192 bytes per row of an HBM-bound stream.
+int x3_cross_kv_format(int nb);      // 0 = fp32 (more than 4 beams), 1 = 24-bit (knob builds: WSEG_X3_CKV=k24), 2 = bfp16 rows
+static inline size_t cross_kv_row_bytes(int fmt, size_t es) { return fmt == 2 ? 132 : (fmt == 1 ? 192 : 64 * es); }
 // WSEG_F16M6: hi | lo IEEE-half operand rows [M][2K words] -> M6 rows [M][4K bytes] (wseg_common.h), K % 64 == 0
 int launch_x3_to_m6(const void* x3_rows, void* m6_rows, size_t M, int K, bool weight_order, hipStream_t s);
 // the dtype every NON-GEMM kernel runs in: WSEG_F16M6 is WSEG_F16X3 outside the GEMMs

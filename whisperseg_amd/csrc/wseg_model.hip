@@ -164,9 +164,9 @@ void make_plan(const wseg_model* m, int W, int nb, int L, int kv_units, char* ba
   DecPlan& q = p.dec;
   q.W = W;
   const size_t Wc = W, R = Wc * nb, Rp = align_up(R, 256);
-  const size_t ces = (m->x3 && x3_cross_kv24() && nb <= 4) ? 3 : es;      // 24-bit cross K / V (wseg_dec.hip)
-  q.ck = take(Ld * Wc * H * Tk * 64 * ces);
-  q.cv = take(Ld * Wc * H * Tk * 64 * ces);
+  const size_t crow = cross_kv_row_bytes(m->x3 ? x3_cross_kv_format(nb) : 0, es);      // bytes per (position, head) row (wseg_dec.hip)
+  q.ck = take(Ld * Wc * H * Tk * crow);
+  q.cv = take(Ld * Wc * H * Tk * crow);
   q.kv_units = kv_units;
   q.kv_layer_stride = align_up((size_t)kv_units * nb * H * KV_PAGE * 64 * es, 256);
   q.sk = take(Ld * q.kv_layer_stride);
@@ -181,6 +181,9 @@ void make_plan(const wseg_model* m, int W, int nb, int L, int kv_units, char* ba
   q.logits = take(Rp * (size_t)m->vp * 4);
   q.first_logits = take(R * (size_t)m->vp * 4);
   q.splitk_bytes = (size_t)8 * Rp * maxn * 4;   // fp32 partials of the decoder-step GEMMs
+  // ... and of the cross-K/V GEMM of a FEW windows (the stream kernels below the large-tile threshold of ~340 tiles of 128x128: at most
+  // 128 * 340 / (N / 128) rows of N fp32 columns = 22.3 MB whatever N is): its block-floating-point row writer lives in the reduction kernel
+  if (m->x3) q.splitk_bytes = std::max(q.splitk_bytes, (size_t)24 << 20);
   q.splitk = take(q.splitk_bytes);
   q.mask = take(align_up((size_t)c.vocab, 4));
   q.tk_val = take(R * 256 * 4);
@@ -298,7 +301,7 @@ int run_decoder_step(wseg_model* m, DecPlan& p, char* mxa, bool want_logits, hip
   const DecodeState& st = p.st;
   const int R = st.W * st.nb;
   const size_t self_stride = p.kv_layer_stride;
-  const size_t cross_stride = (size_t)st.W * H * Tk * 64 * ((m->x3 && x3_cross_kv24() && st.nb <= 4) ? 3 : m->es);
+  const size_t cross_stride = (size_t)st.W * H * Tk * cross_kv_row_bytes(m->x3 ? x3_cross_kv_format(st.nb) : 0, m->es);
   WSEG_TRY(launch_embed(m->mx ? WSEG_F32 : dt, st, m->mx ? m->dec_tok_f32 : m->dec_tok, m->dec_pos, p.dx, d, s));
   EpiParams e;
   // WSEG_F16M6: LayerNorm outputs (dy) and attention outputs (dattn) are M6 rows already; the FFN hidden (dh) is when its GEMM
@@ -585,8 +588,8 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
   WSEG_TRY(launch_decode_reset(st, s));
 
   const int d = c.d_model, H = c.n_heads, Tk = c.enc_positions;
-  const bool kv24 = m->x3 && x3_cross_kv24() && nb <= 4;
-  const size_t cross_stride = (size_t)S * H * Tk * 64 * (kv24 ? 3 : m->es);
+  const int kv24 = m->x3 ? x3_cross_kv_format(nb) : 0;
+  const size_t cross_stride = (size_t)S * H * Tk * cross_kv_row_bytes(kv24, m->es);
   const size_t feat_stride = (size_t)c.n_mels * c.spec_cols;
   const int npg = st.npg;
 
@@ -624,7 +627,7 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
         EpiParams e;
         e.bias = m->dec[l].ckv_b; e.k = q.ck + l * cross_stride; e.v = q.cv + l * cross_stride;
         e.d_model = d; e.t_len = Tk; e.n_heads = H; e.slot_map = q.adm_slots + off + c0; e.kv24 = kv24;
-        WSEG_TRY(gemm(m, EPI_KV_CROSS, enc_rows, d, m->dec[l].ckv_w, d, nc * Tk, 2 * d, d, e, nullptr, s));
+        WSEG_TRY(gemm(m, EPI_KV_CROSS, enc_rows, d, m->dec[l].ckv_w, d, nc * Tk, 2 * d, d, e, &q, s));
       }
       WSEG_TRY(timing_event(ln, s, &e2));
       ln.ev_enc.push_back(e0); ln.ev_enc.push_back(e1); ln.ev_ckv.push_back(e1); ln.ev_ckv.push_back(e2);
