@@ -803,6 +803,9 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_k24_kernel(DecodeState 
 // each), two beams per v_pk_fma_f32, DPP row sums; an element is one v_cvt_f32_i32 (sign-extended half word), the row's scale
 // multiplies the finished score (K) / the probability (V) — powers of two: exact, the sums are those of the dequantised values.
 // ------------------------------------------------------------------------------------------------
+#ifndef WSEG_BFP_U
+#define WSEG_BFP_U 8
+#endif
 template <typename TO, int NB>
 __global__ __launch_bounds__(256, 3) void dec_cross_attn_bfp_kernel(DecodeState st, const float* __restrict__ q,
                                                                     const unsigned char* __restrict__ ck, const unsigned char* __restrict__ cv,
@@ -810,7 +813,7 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_bfp_kernel(DecodeState 
                                                                     const float* __restrict__ q_bias, float scale) {
   typedef unsigned int raw16 __attribute__((ext_vector_type(4)));
   typedef float f2 __attribute__((ext_vector_type(2)));
-  constexpr int U = 8;
+  constexpr int U = WSEG_BFP_U;
   __shared__ float sc[NB][512];
   __shared__ float red[4][NB][64];
   __shared__ float sinv[NB];
