@@ -831,6 +831,21 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_bfp_kernel(DecodeState 
   constexpr int NP = (NB + 1) / 2;
   f2 qq[8][NP];
   __shared__ float sq[NB][64];                          // thread (j, e) finishes dim e of beam j (reduce1), slices come back from LDS
+  // The first batch of K rows is requested BEFORE the query is assembled (reduce1: a chain of dependent split-K loads) and the first
+  // batch of V rows before the softmax: neither depends on what it overtakes, and the kernel's fixed costs (~170 us of a 464-us launch at
+  // 1 024 slots by a two-point fit against the 24-bit format) are exactly these serial sections.
+  auto ld_rows = [&](const unsigned char* base, int t0, raw16 (&r)[U]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = min(t0 + u * 32 + wave * 8 + rowl, Tk - 1);      // clamped: out-of-range rows are discarded by their consumers
+      r[u] = __builtin_nontemporal_load((const raw16*)(base + (size_t)t * 128 + sub * 16));
+    }
+  };
+#ifndef WSEG_BFP_PREFETCH
+#define WSEG_BFP_PREFETCH 1
+#endif
+  raw16 kq[U];
+  if (WSEG_BFP_PREFETCH) ld_rows(Kb, 0, kq);
   for (int i = tid; i < Tk; i += 256) { sks[i] = __builtin_nontemporal_load(Ks + i); svs[i] = __builtin_nontemporal_load(Vs + i); }
   if (pi.part != nullptr) {
     if (tid < NB * 64) sq[tid >> 6][tid & 63] = reduce1<float>(pi, w * nb + min(tid >> 6, nb - 1), h * 64 + (tid & 63), q_bias) * scale;
@@ -862,12 +877,7 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_bfp_kernel(DecodeState 
     }
   };
   for (int t0 = 0; t0 < Tk; t0 += 32 * U) {
-    raw16 kq[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int t = min(t0 + u * 32 + wave * 8 + rowl, Tk - 1);      // clamped: out-of-range rows are discarded below
-      kq[u] = __builtin_nontemporal_load((const raw16*)(Kb + (size_t)t * 128 + sub * 16));
-    }
+    if (t0 > 0 || !WSEG_BFP_PREFETCH) ld_rows(Kb, t0, kq);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int t = t0 + u * 32 + wave * 8 + rowl;
@@ -897,6 +907,8 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_bfp_kernel(DecodeState 
       if (sub < nb && t < Tk) sc[sub][t] = mine * sks[t];
     }
   }
+  raw16 vq[U];
+  if (WSEG_BFP_PREFETCH) ld_rows(Vb, 0, vq);
   __syncthreads();
   for (int j = wave; j < nb; j += 4) {
     float mx = -3.0e38f;
@@ -915,12 +927,7 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_bfp_kernel(DecodeState 
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[j][e] = (f2){0.f, 0.f};
   for (int t0 = 0; t0 < Tk; t0 += 32 * U) {
-    raw16 vq[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int t = min(t0 + u * 32 + wave * 8 + rowl, Tk - 1);
-      vq[u] = __builtin_nontemporal_load((const raw16*)(Vb + (size_t)t * 128 + sub * 16));
-    }
+    if (t0 > 0 || !WSEG_BFP_PREFETCH) ld_rows(Vb, t0, vq);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int t = t0 + u * 32 + wave * 8 + rowl;

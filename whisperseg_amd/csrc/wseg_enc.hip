@@ -245,6 +245,12 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
       asm volatile("" : "+v"(kfo), "+v"(vfo));
       const char* cKs = (const char*)cK + sub * 4096;
       [[maybe_unused]] const char* cKls = (const char*)sKl[kt & 1] + sub * 4096;
+#ifndef WSEG_EA_PRIO
+#define WSEG_EA_PRIO 1
+#endif
+      // (three workgroups share a CU: a wave that has MFMAs to issue goes first — MI355X_MICROARCH.md, static priority — while its
+      // neighbours' softmax VALU fills the slots between them)
+      if (WSEG_EA_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int hs = 0; hs < 4; ++hs) {
         const bf16x8 kf = *(const bf16x8*)(cKs + (kfo ^ (hs << 5)));
@@ -255,6 +261,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
           s = H16<HT>::mfma32(kfl, qf[hs], s);
         }
       }
+      if (WSEG_EA_PRIO) __builtin_amdgcn_s_setprio(0);
       if (key_base + 32 > T) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -282,6 +289,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
       }
       // O^T[hd][q] += V^T[hd][key] P^T[key][q]; contraction slots of lane-half g2, MFMA mm:
       // keys 16*mm + 4*g2 + {0,1,2,3, 8,9,10,11}  == registers 8*mm .. 8*mm+7 of s.
+      if (WSEG_EA_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int mm = 0; mm < 2; ++mm) {
         union { bf16x8 v; uint32_t u[4]; } pf, pfl;
@@ -309,6 +317,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
           }
         }
       }
+      if (WSEG_EA_PRIO) __builtin_amdgcn_s_setprio(0);
     }
   }
   const int q = q0 + qi;
