@@ -35,7 +35,7 @@ VGPR_CAPS = {
     r"enc_attention_h16_kernel<.*true>": 168,                      # 3 workgroups per CU
     r"enc_attention_h16_kernel<.*false>": 128,                     # 4 workgroups per CU
     r"dec_self_attn_kernel<": 64,                                  # 8 single-wave workgroups per SIMD
-    r"dec_cross_attn_bfp_kernel<": 168,
+    r"dec_cross_attn_bfp_kernel<": 128,                            # 4 workgroups per CU
     r"dec_cross_attn_pk_kernel<": 128,
     r"layernorm_kernel<": 128,
 }

@@ -806,15 +806,23 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_k24_kernel(DecodeState 
 #ifndef WSEG_BFP_U
 #define WSEG_BFP_U 8
 #endif
+// Occupancy: four workgroups per CU (128 registers).  The 4-beam instantiation fits with 5 instead of 8 V rows per lane in flight and the
+// scores as [position][beam] (one 16-byte LDS read per row instead of four addresses); with 8 it needs 168 registers = three per CU.
+#ifndef WSEG_BFP_OCC
+#define WSEG_BFP_OCC 4
+#endif
+#ifndef WSEG_BFP_UV
+#define WSEG_BFP_UV (WSEG_BFP_OCC == 4 ? 5 : 8)
+#endif
 template <typename TO, int NB>
-__global__ __launch_bounds__(256, 3) void dec_cross_attn_bfp_kernel(DecodeState st, const float* __restrict__ q,
+__global__ __launch_bounds__(256, WSEG_BFP_OCC) void dec_cross_attn_bfp_kernel(DecodeState st, const float* __restrict__ q,
                                                                     const unsigned char* __restrict__ ck, const unsigned char* __restrict__ cv,
                                                                     void* __restrict__ out, int H, int Tk, int d, PartialInfo pi,
                                                                     const float* __restrict__ q_bias, float scale) {
   typedef unsigned int raw16 __attribute__((ext_vector_type(4)));
   typedef float f2 __attribute__((ext_vector_type(2)));
   constexpr int U = WSEG_BFP_U;
-  __shared__ float sc[NB][512];
+  __shared__ __attribute__((aligned(16))) float sc[512][NB];      // [position][beam]: one 16-byte read per row in the V pass
   __shared__ float red[4][NB][64];
   __shared__ float sinv[NB];
   __shared__ float sks[512], svs[512];                 // the row scales of this (slot, head): 2 x 2 KB, fetched once with coalesced loads (as
@@ -834,9 +842,11 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_bfp_kernel(DecodeState 
   // The first batch of K rows is requested BEFORE the query is assembled (reduce1: a chain of dependent split-K loads) and the first
   // batch of V rows before the softmax: neither depends on what it overtakes, and the kernel's fixed costs (~170 us of a 464-us launch at
   // 1 024 slots by a two-point fit against the 24-bit format) are exactly these serial sections.
-  auto ld_rows = [&](const unsigned char* base, int t0, raw16 (&r)[U]) __attribute__((always_inline)) {
+  constexpr int UV = NB == 4 ? WSEG_BFP_UV : U;      // rows per lane in flight in the V pass (the 4-beam accumulators leave room for 6 at 128 registers)
+  auto ld_rows = [&](const unsigned char* base, int t0, auto& r) __attribute__((always_inline)) {
+    constexpr int UU = sizeof(r) / sizeof(r[0]);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < UU; ++u) {
       const int t = min(t0 + u * 32 + wave * 8 + rowl, Tk - 1);      // clamped: out-of-range rows are discarded by their consumers
       r[u] = __builtin_nontemporal_load((const raw16*)(base + (size_t)t * 128 + sub * 16));
     }
@@ -904,18 +914,18 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_bfp_kernel(DecodeState 
       float mine = a[0];
 #pragma unroll
       for (int j = 1; j < NB; ++j) mine = sub == j ? a[j] : mine;
-      if (sub < nb && t < Tk) sc[sub][t] = mine * sks[t];
+      if (sub < nb && t < Tk) sc[t][sub] = mine * sks[t];
     }
   }
-  raw16 vq[U];
+  raw16 vq[UV];
   if (WSEG_BFP_PREFETCH) ld_rows(Vb, 0, vq);
   __syncthreads();
   for (int j = wave; j < nb; j += 4) {
     float mx = -3.0e38f;
-    for (int t = lane; t < Tk; t += 64) mx = fmaxf(mx, sc[j][t]);
+    for (int t = lane; t < Tk; t += 64) mx = fmaxf(mx, sc[t][j]);
     mx = wave_max(mx);
     float sum = 0.f;
-    for (int t = lane; t < Tk; t += 64) { const float p = expf(sc[j][t] - mx); sc[j][t] = p * svs[t]; sum += p; }      // (V's row scale rides on the probability)
+    for (int t = lane; t < Tk; t += 64) { const float p = expf(sc[t][j] - mx); sc[t][j] = p * svs[t]; sum += p; }      // (V's row scale rides on the probability)
     sum = wave_sum(sum);
     if (lane == 0) sinv[j] = 1.0f / sum;
   }
@@ -926,18 +936,22 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_bfp_kernel(DecodeState 
   for (int j = 0; j < NB; ++j)
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[j][e] = (f2){0.f, 0.f};
-  for (int t0 = 0; t0 < Tk; t0 += 32 * U) {
+  for (int t0 = 0; t0 < Tk; t0 += 32 * UV) {
     if (t0 > 0 || !WSEG_BFP_PREFETCH) ld_rows(Vb, t0, vq);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < UV; ++u) {
       const int t = t0 + u * 32 + wave * 8 + rowl;
       const bool ok = t < Tk;
       const int tc = ok ? t : Tk - 1;
       float vf[8];
       unpack(vq[u], vf);
+      float pr[NB];
+      if constexpr (NB == 4) { const float4 t4 = *(const float4*)&sc[tc][0]; pr[0] = t4.x; pr[1] = t4.y; pr[2] = t4.z; pr[3] = t4.w; }
+      else if constexpr (NB == 2) { const float2 t2 = *(const float2*)&sc[tc][0]; pr[0] = t2.x; pr[1] = t2.y; }
+      else pr[0] = sc[tc][0];
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        const float p = (ok && j < nb) ? sc[j][tc] : 0.f;
+        const float p = (ok && j < nb) ? pr[j] : 0.f;
         const f2 pp = {p, p};
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[j][e] = __builtin_elementwise_fma(pp, (f2){vf[2 * e], vf[2 * e + 1]}, acc[j][e]);
