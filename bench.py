@@ -101,9 +101,10 @@ def end_to_end_bound(model, dtype, beams, gen, W, enc_frac=1.0, dec_frac=1.0, cr
     """Ceiling of `end_to_end_frac` (algorithmic flops per second / dense MFMA peak) for this workload: the step is a chain of
     dependent kernels, so their times ADD — matrix-core kernels at enc_frac / dec_frac of the dense peak (the split-precision
     modes issue THREE MFMAs per algorithmic product), HBM-bound kernels at their bandwidth:
-      cross-attention  Tk x 64 x (K + V) per (window, head, layer, step): 2 B per element in the 16-bit modes, 132 / 64 B in the split
-                       modes (int16 + one fp32 scale per row: block floating point, r05; r03-r04: 3 B), 4 B in f32 — shared by the
-                       beams of a window, streamed once per decode step;
+      cross-attention  Tk x 64 x (K + V) per (window, head, layer, step): 2 B per element in the 16-bit modes, 132 / 64 B in f16m6
+                       (int16 + one fp32 scale per row: block floating point, r05), 3 B in bf16x3 / f16x3 (24-bit), 4 B in f32 —
+                       shared by the beams of a window, streamed once per decode step and once for the forced prompt positions
+                       (the prompt pass of the split modes; the other modes step through the prompt);
       self-attention   2 x t x 64 elements per (row, head, layer) at step t (fp32 rows in the f32 / split modes);
       logits           fp32 [rows][vocab] written by the LM head and read twice by the top-k kernels;
       decoder weights  once per step, shared by the W windows in flight.
@@ -114,12 +115,13 @@ def end_to_end_bound(model, dtype, beams, gen, W, enc_frac=1.0, dec_frac=1.0, cr
     enc_f, ckv_f, dec_f = flops_per_window(model, beams, gen)
     x3 = dtype.endswith("x3") or dtype == "f16m6"      # fp32 storage outside the GEMMs, block-floating-point cross K / V
     mult = mfma_issue_multiplier(dtype)
-    kv_b = 132 / 64 if x3 else (4 if dtype == "f32" else 2)       # cross K / V bytes per element
+    kv_b = 132 / 64 if dtype == "f16m6" else (3 if x3 else (4 if dtype == "f32" else 2))       # cross K / V bytes per element
     sa_b = 4 if (x3 or dtype == "f32") else 2                     # self-attention cache bytes per element
     w_b = 4 if (x3 or dtype == "f32") else 2                      # weight bytes per logical element (hi + lo pairs: 4)
     steps = P + gen - 1
     heads = d // 64
-    cross = steps * L * heads * T * 64 * 2 * kv_b
+    cross_streams = gen + 1 if (x3 and beams <= 4) else steps      # prompt pass: positions 0 .. P - 2 share one pass over K / V
+    cross = cross_streams * L * heads * T * 64 * 2 * kv_b
     selfa = sum(2 * (t + 1) * 64 * sa_b for t in range(steps)) * beams * heads * L
     logits = gen * beams * V * 4 * 3
     dec_w = steps * (L * (4 * d * d + 2 * d * d + 2 * d * f) + d * V) * w_b / max(W, 1)

@@ -24,8 +24,8 @@ from conftest import ROOT
 
 # kernel (regex on the demangled name) -> (max scratch bytes per lane, reason)
 ALLOW_SCRATCH = {
-    # (r04 needed one entry: dec_cross_attn_k24_kernel<*, 4> spilled a 64-bit pointer outside its loops; the kernel now exists in knob
-    # builds only — the product streams block-floating-point K / V through dec_cross_attn_bfp_kernel, no scratch)
+    # (r04 needed one entry: dec_cross_attn_k24_kernel<*, 4> spilled a 64-bit pointer outside its loops; with its scores laid out
+    # [position][beam] (one 16-byte LDS read per row) it needs 114 registers and no scratch)
 }
 # kernel regex -> VGPR ceiling (waves per SIMD the launch geometry counts on: MI355X_MICROARCH.md register-file table)
 VGPR_CAPS = {
@@ -36,6 +36,8 @@ VGPR_CAPS = {
     r"enc_attention_h16_kernel<.*false>": 128,                     # 4 workgroups per CU
     r"dec_self_attn_kernel<": 64,                                  # 8 single-wave workgroups per SIMD
     r"dec_cross_attn_bfp_kernel<": 128,                            # 4 workgroups per CU
+    r"dec_cross_attn_k24_kernel<": 128,
+    r"prompt_self_attn_kernel<": 64,
     r"dec_cross_attn_pk_kernel<": 128,
     r"layernorm_kernel<": 128,
 }

@@ -355,3 +355,26 @@ def test_paged_kv_workspace_too_small_is_an_error(gpu_lib):
     lens = torch.empty((2,), dtype=torch.int32, device="cuda:0")
     rc = eng.lib.wseg_generate(eng.handle, x.data_ptr(), 2, C.byref(gp), ws.data_ptr(), ws.numel(), toks.data_ptr(), lens.data_ptr(), None)
     assert rc == -3 and b"workspace too small" in eng.lib.wseg_last_error()
+
+
+@pytest.mark.parametrize("dtype", ["f16m6", "f16x3", "bf16x3"])
+@pytest.mark.parametrize("nb", [1, 2, 4])
+def test_prompt_pass_equals_stepping_through_the_prompt(gpu_lib, dtype, nb, monkeypatch):
+    """Split-precision modes run the forced prompt positions 0 .. P - 2 of every admission as ONE pass over the admitted windows
+    (rows = windows x positions; the windows' cross-attention K / V are streamed once for them) and start the slots at position
+    P - 1.  Same tokens as stepping through the prompt (test knob WSEG_NO_PROMPT_PASS), P - 1 fewer steps when all windows start
+    together, and the same under refills (admissions of a few windows, every one with its own prompt pass)."""
+    eng = tiny_engine(dtype)
+    x = tiny_feats(23)
+    res = {}
+    for mode in ("pass", "step"):
+        if mode == "step":
+            monkeypatch.setenv("WSEG_NO_PROMPT_PASS", "1")
+        for slots, refill in ((23, 0), (5, 1), (1, 0)):
+            t, l = gen(eng, x, nb, n_slots=slots, refill_min=refill)
+            res[mode, slots] = (t, l, eng.last_stats()["n_steps"])
+    for slots in (23, 5, 1):
+        assert torch.equal(res["pass", slots][0], res["step", 23][0]) and torch.equal(res["pass", slots][1], res["step", 23][1]), slots
+        assert torch.equal(res["step", slots][0], res["step", 23][0])
+    assert res["pass", 23][2] == res["step", 23][2] - (len(TM.PROMPT) - 1)
+    assert res["pass", 1][2] <= res["step", 1][2] - 23 * (len(TM.PROMPT) - 1) + 8

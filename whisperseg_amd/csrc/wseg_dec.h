@@ -43,8 +43,17 @@ struct DecodeState {
 
 // all slots idle (start of a wseg_generate call)
 int launch_decode_reset(const DecodeState& st, hipStream_t s);
-// slots[i] starts decoding window wins[i] at position 0 (device arrays of n entries)
-int launch_decode_admit(const DecodeState& st, const int* slots, const int* wins, int n, hipStream_t s);
+// slots[i] starts decoding window wins[i] at position pf_np (device arrays of n entries); pf_np > 0: the prompt positions before it
+// were run by the prompt pass (launch_prompt_*), every beam's ancestry of them points at beam 0's cache rows
+int launch_decode_admit(const DecodeState& st, const int* slots, const int* wins, int n, int pf_np, hipStream_t s);
+// Prompt pass (split-precision modes): the first np <= 4 forced prompt positions of n admitted windows as ONE pass of n * np rows
+// (row i * np + pp) instead of np decode steps of every slot — the cross-attention K / V of a window are streamed once for them.
+// x[row][:] = tok_emb[prompt[pp]][:] + pos_emb[pp][:]
+int launch_prompt_embed(int dtype, const DecodeState& st, int rows, int np, const void* tok_emb, const void* pos_emb, void* x, int d, hipStream_t s);
+// causal self-attention among the np positions of a window; K / V -> beam 0's rows of the first page of slots[i].  q | k | v: split-K
+// partials (qkv_part) or fp32 rows [rows][3 d] WITHOUT bias (qkv); out: the o-proj GEMM's operand rows.
+int launch_prompt_self_attn(int dtype, const DecodeState& st, const float* qkv, const PartialInfo* qkv_part, const void* qkv_bias, void* kc, void* vc,
+                            const int* slots, int n, int np, void* out, int H, int d, float scale, hipStream_t s);
 // page-table updates: kv_pt[pairs[2 i]] = pairs[2 i + 1] for i < n (device array of 2 n ints, written by the scheduler)
 int launch_kv_assign(int* kv_pt, const int* pairs, int n, hipStream_t s);
 // preemption: slots[i] stops decoding and produces no output (its window is re-queued by the scheduler)
@@ -59,8 +68,11 @@ int launch_dec_self_attn(int dtype, const DecodeState& st, const void* q, void* 
                          int H, int d, const PartialInfo* qkv_part, const void* qkv_bias, float scale, hipStream_t s);
 // cross-attention: the nb beams of a window share K/V [W][H][Tk][64]
 // q_part != nullptr: the query arrives as split-K partials [z][m_pad][d] (+ q_bias, scaled by `scale`)
+// kv_slot != nullptr (prompt pass, block-floating-point K / V only): "window" w of st is admitted window w with st.nb = np query
+// rows, its K / V are those of slot kv_slot[w]
 int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const void* ck, const void* cv, void* out,
-                          int H, int Tk, int d, const PartialInfo* q_part, const void* q_bias, float scale, hipStream_t s);
+                          int H, int Tk, int d, const PartialInfo* q_part, const void* q_bias, float scale, hipStream_t s,
+                          const int* kv_slot = nullptr);
 // WSEG_F16M6: M6 rows (24-bit K / V kernel, <= 4 beams) or hi | lo rows that the caller converts (5..8 beams)?
 bool dec_cross_attn_writes_mx(int dtype, int nb);
 // log-softmax + suppress + running score -> top-2nb per row (beam) / argmax of the processed logits (greedy)

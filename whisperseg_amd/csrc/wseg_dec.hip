@@ -27,8 +27,9 @@ __global__ void decode_reset_kernel(DecodeState st) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < st.W * st.nb; i += gridDim.x * 256) st.tokens_in[i] = st.prompt[0];
 }
 
-// One workgroup per admitted slot: fresh sequences / scores / ancestry, position 0, not done.
-__global__ __launch_bounds__(256) void decode_admit_kernel(DecodeState st, const int* __restrict__ slots, const int* __restrict__ wins) {
+// One workgroup per admitted slot: fresh sequences / scores / ancestry, not done; position pf_np (the prompt positions before it were
+// run by the admission pass, run_prompt_pass: their K / V are beam 0's cache rows for every beam).
+__global__ __launch_bounds__(256) void decode_admit_kernel(DecodeState st, const int* __restrict__ slots, const int* __restrict__ wins, int pf_np) {
   const int w = slots[blockIdx.x];
   const int nb = st.nb, L = st.L;
   for (int i = threadIdx.x; i < nb * L; i += 256) {
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void decode_admit_kernel(DecodeState st, const
     const int v = p < st.P ? st.prompt[p] : st.pad;
     st.run_seq[(size_t)w * nb * L + i] = v;
     st.fin_seq[(size_t)w * nb * L + i] = v;
-    st.anc[(size_t)w * nb * L + i] = (unsigned char)j;
+    st.anc[(size_t)w * nb * L + i] = (unsigned char)(p < pf_np ? 0 : j);
   }
   if (threadIdx.x < nb) {
     const int j = threadIdx.x, i = w * nb + j;
@@ -44,13 +45,13 @@ __global__ __launch_bounds__(256) void decode_admit_kernel(DecodeState st, const
     st.fin_score[i] = -1.0e9f;
     st.fin_flag[i] = 0;
     st.fin_len[i] = 0;
-    st.tokens_in[i] = st.prompt[0];
+    st.tokens_in[i] = st.prompt[pf_np];
   }
   if (threadIdx.x == 0) {
     const int win = wins[blockIdx.x];
     int cap = st.max_length;
     if (st.win_max_length) cap = max(st.P + 1, min(cap, st.win_max_length[win]));
-    st.unsat[w] = 1; st.pos[w] = 0; st.win[w] = win; st.wmax[w] = cap; st.done[w] = 0;
+    st.unsat[w] = 1; st.pos[w] = pf_np; st.win[w] = win; st.wmax[w] = cap; st.done[w] = 0;
   }
 }
 
@@ -83,6 +84,17 @@ __global__ __launch_bounds__(256) void embed_kernel(DecodeState st, const void* 
   const int tok = st.tokens_in[r], pos = st.pos[r / st.nb];
   for (int c = threadIdx.x; c < d; c += 256)
     x[(size_t)r * d + c] = Op<T>::ld1(tok_emb, (size_t)tok, d, c) + El<PT>::ld(pos_emb + (size_t)pos * d + c);
+}
+
+// Prompt pass: row i * np + pp = admitted window i at prompt position pp.
+template <typename T>
+__global__ __launch_bounds__(256) void prompt_embed_kernel(DecodeState st, int np, const void* __restrict__ tok_emb,
+                                                           const typename IO<T>::P* __restrict__ pos_emb, float* __restrict__ x, int d) {
+  typedef typename IO<T>::P PT;
+  const int r = blockIdx.x, pp = r % np;
+  const int tok = st.prompt[pp];
+  for (int c = threadIdx.x; c < d; c += 256)
+    x[(size_t)r * d + c] = Op<T>::ld1(tok_emb, (size_t)tok, d, c) + El<PT>::ld(pos_emb + (size_t)pp * d + c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -298,6 +310,62 @@ __global__ __launch_bounds__(64, 8) void dec_self_attn_kernel(DecodeState st, co
     op_st8<TO>(out, (size_t)r, d, h * 64 + sub * 8, o8);
   }
   WSEG_STAMP(1, 7);
+}
+
+// Prompt pass (split-precision modes: fp32 cache rows): causal self-attention over the first np <= 4 prompt positions of the windows
+// admitted together, one wave per (window, head), lane e = dim e.  Row i * np + pp of q | k | v (split-K partials, or the fp32 rows of
+// an un-split GEMM without bias) is window i at position pp; K / V go to beam 0's rows of the slot's first page — the admission
+// kernel points every beam's ancestry of these positions there (the forced prompt is the same for all beams).
+template <typename TO>
+__global__ __launch_bounds__(64) void prompt_self_attn_kernel(const float* __restrict__ qkv, PartialInfo pi, const float* __restrict__ bias,
+                                                               float* __restrict__ kc, float* __restrict__ vc, const int* __restrict__ kv_pt, int npg,
+                                                               const int* __restrict__ slots, int np, int nb, int H, int d,
+                                                               void* __restrict__ out, float scale) {
+  __shared__ float so[4][64];
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x / H, h = blockIdx.x - i * H;
+  const int unit = kv_pt[(size_t)slots[i] * npg];
+  float q[4], k[4], v[4];
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp) {
+    q[pp] = k[pp] = v[pp] = 0.f;
+    if (pp < np) {
+      const int row = i * np + pp, col = h * 64 + lane;
+      if (pi.part != nullptr) {
+        q[pp] = reduce1<float>(pi, row, col, bias);
+        k[pp] = reduce1<float>(pi, row, d + col, bias);
+        v[pp] = reduce1<float>(pi, row, 2 * d + col, bias);
+      } else {
+        const float* b = qkv + (size_t)row * 3 * d + col;
+        q[pp] = b[0] + bias[col]; k[pp] = b[d] + bias[d + col]; v[pp] = b[2 * d] + bias[2 * d + col];
+      }
+      q[pp] *= scale;
+      const size_t at = ((((size_t)unit * nb) * H + h) * KV_PAGE + pp) * 64 + lane;
+      kc[at] = k[pp];
+      vc[at] = v[pp];
+    }
+  }
+  static_assert(KV_PAGE >= 4, "the prompt pass writes into the first page");
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp) {
+    if (pp < np) {
+      float sc[4], mx = -3.0e38f;
+#pragma unroll
+      for (int t = 0; t <= pp; ++t) { sc[t] = wave_sum(q[pp] * k[t]); mx = fmaxf(mx, sc[t]); }
+      float sum = 0.f, o = 0.f;
+#pragma unroll
+      for (int t = 0; t <= pp; ++t) { const float pr = expf(sc[t] - mx); sum += pr; o = fmaf(pr, v[t], o); }
+      so[pp][lane] = o / sum;
+    }
+  }
+  __syncthreads();
+  if (lane < np * 8) {      // lane (pp, e8): 8 consecutive columns of one row — whole quads of lanes share a 32-column block (M6 rows)
+    const int pp = lane >> 3, e0 = (lane & 7) * 8;
+    float o8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] = so[pp][e0 + e];
+    op_st8<TO>(out, (size_t)(i * np + pp), d, h * 64 + e0, o8);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -623,7 +691,6 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
   WSEG_STAMP(2, 7);
 }
 
-#ifdef WSEG_KNOBS      // the 24-bit format of r03-r04: knob builds only (WSEG_X3_CKV=k24, same-box A/B against the block-floating-point rows)
 // ------------------------------------------------------------------------------------------------
 // Split-precision modes: cross-attention over 24-bit K / V (EpiParams::kv24: per (slot, head) a [Tk][64] plane of the fp32
 // words' top halves, then a [Tk][64] plane of their third bytes; 192 instead of 256 bytes per row pair of an HBM-bound stream).
@@ -631,15 +698,15 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
 // (16 + 8 bytes each), one v_perm_b32 per element to rebuild the fp32 word, two beams per v_pk_fma_f32, DPP row sums.
 // ------------------------------------------------------------------------------------------------
 template <typename TO, int NB>
-__global__ __launch_bounds__(256, 3) void dec_cross_attn_k24_kernel(DecodeState st, const float* __restrict__ q,
+__global__ __launch_bounds__(256, 4) void dec_cross_attn_k24_kernel(DecodeState st, const float* __restrict__ q,
                                                                     const unsigned char* __restrict__ ck, const unsigned char* __restrict__ cv,
                                                                     void* __restrict__ out, int H, int Tk, int d, PartialInfo pi,
-                                                                    const float* __restrict__ q_bias, float scale) {
+                                                                    const float* __restrict__ q_bias, float scale, const int* __restrict__ kv_slot) {
   typedef unsigned int raw16 __attribute__((ext_vector_type(4)));
   typedef unsigned int raw8 __attribute__((ext_vector_type(2)));
   typedef float f2 __attribute__((ext_vector_type(2)));
   constexpr int U = 8;
-  __shared__ float sc[NB][512];
+  __shared__ __attribute__((aligned(16))) float sc[512][NB];      // [position][beam]: one read per row in the V pass
   __shared__ float red[4][NB][64];
   __shared__ float sinv[NB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -649,8 +716,9 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_k24_kernel(DecodeState 
   WSEG_STAMP(3, 1);
   const int nb = st.nb;
   const int sub = lane & 7, rowl = lane >> 3;
-  const unsigned char* Kb = ck + ((size_t)w * H + h) * Tk * 192;
-  const unsigned char* Vb = cv + ((size_t)w * H + h) * Tk * 192;
+  const int ws = kv_slot ? kv_slot[w] : w;              // prompt pass: query rows of admitted window w, K / V of its slot
+  const unsigned char* Kb = ck + ((size_t)ws * H + h) * Tk * 192;
+  const unsigned char* Vb = cv + ((size_t)ws * H + h) * Tk * 192;
   const unsigned char* Kl = Kb + (size_t)Tk * 128;
   const unsigned char* Vl = Vb + (size_t)Tk * 128;
   constexpr int NP = (NB + 1) / 2;
@@ -724,7 +792,7 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_k24_kernel(DecodeState 
       float mine = a[0];
 #pragma unroll
       for (int j = 1; j < NB; ++j) mine = sub == j ? a[j] : mine;
-      if (sub < nb && t < Tk) sc[sub][t] = mine;
+      if (sub < nb && t < Tk) sc[t][sub] = mine;
     }
   }
   WSEG_STAMP(3, 3);                                 // scores
@@ -732,10 +800,10 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_k24_kernel(DecodeState 
   WSEG_STAMP(3, 4);
   for (int j = wave; j < nb; j += 4) {
     float mx = -3.0e38f;
-    for (int t = lane; t < Tk; t += 64) mx = fmaxf(mx, sc[j][t]);
+    for (int t = lane; t < Tk; t += 64) mx = fmaxf(mx, sc[t][j]);
     mx = wave_max(mx);
     float sum = 0.f;
-    for (int t = lane; t < Tk; t += 64) { const float p = expf(sc[j][t] - mx); sc[j][t] = p; sum += p; }
+    for (int t = lane; t < Tk; t += 64) { const float p = expf(sc[t][j] - mx); sc[t][j] = p; sum += p; }
     sum = wave_sum(sum);
     if (lane == 0) sinv[j] = 1.0f / sum;
   }
@@ -763,9 +831,13 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_k24_kernel(DecodeState 
       const int tc = ok ? t : Tk - 1;
       float vf[8];
       unpack(vh[u], vl[u], vf);
+      float pr[NB];
+      if constexpr (NB == 4) { const float4 t4 = *(const float4*)&sc[tc][0]; pr[0] = t4.x; pr[1] = t4.y; pr[2] = t4.z; pr[3] = t4.w; }
+      else if constexpr (NB == 2) { const float2 t2 = *(const float2*)&sc[tc][0]; pr[0] = t2.x; pr[1] = t2.y; }
+      else pr[0] = sc[tc][0];
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        const float p = (ok && j < nb) ? sc[j][tc] : 0.f;
+        const float p = (ok && j < nb) ? pr[j] : 0.f;
         const f2 pp = {p, p};
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[j][e] = __builtin_elementwise_fma(pp, (f2){vf[2 * e], vf[2 * e + 1]}, acc[j][e]);
@@ -794,8 +866,6 @@ __global__ __launch_bounds__(256, 3) void dec_cross_attn_k24_kernel(DecodeState 
   WSEG_STAMP(3, 7);
 }
 
-#endif      // WSEG_KNOBS
-
 // ------------------------------------------------------------------------------------------------
 // Split-precision modes, r05: cross-attention over block-floating-point K / V (EpiParams::kv24 == 2: per (slot, head) a [Tk][64] plane
 // of int16 followed by [Tk] fp32 powers of two, value = int16 * scale of its row; 132 instead of the 24-bit format's 192 bytes per
@@ -818,7 +888,7 @@ template <typename TO, int NB>
 __global__ __launch_bounds__(256, WSEG_BFP_OCC) void dec_cross_attn_bfp_kernel(DecodeState st, const float* __restrict__ q,
                                                                     const unsigned char* __restrict__ ck, const unsigned char* __restrict__ cv,
                                                                     void* __restrict__ out, int H, int Tk, int d, PartialInfo pi,
-                                                                    const float* __restrict__ q_bias, float scale) {
+                                                                    const float* __restrict__ q_bias, float scale, const int* __restrict__ kv_slot) {
   typedef unsigned int raw16 __attribute__((ext_vector_type(4)));
   typedef float f2 __attribute__((ext_vector_type(2)));
   constexpr int U = WSEG_BFP_U;
@@ -832,8 +902,9 @@ __global__ __launch_bounds__(256, WSEG_BFP_OCC) void dec_cross_attn_bfp_kernel(D
   if (st.done[w]) return;                              // idle slot: its 66 KB of K / V are not streamed
   const int nb = st.nb;
   const int sub = lane & 7, rowl = lane >> 3;
-  const unsigned char* Kb = ck + ((size_t)w * H + h) * Tk * 132;
-  const unsigned char* Vb = cv + ((size_t)w * H + h) * Tk * 132;
+  const int ws = kv_slot ? kv_slot[w] : w;              // prompt pass: query rows of admitted window w, K / V of its slot
+  const unsigned char* Kb = ck + ((size_t)ws * H + h) * Tk * 132;
+  const unsigned char* Vb = cv + ((size_t)ws * H + h) * Tk * 132;
   const float* Ks = (const float*)(Kb + (size_t)Tk * 128);
   const float* Vs = (const float*)(Vb + (size_t)Tk * 128);
   constexpr int NP = (NB + 1) / 2;
@@ -1330,9 +1401,10 @@ int launch_decode_reset(const DecodeState& st, hipStream_t s) {
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
-int launch_decode_admit(const DecodeState& st, const int* slots, const int* wins, int n, hipStream_t s) {
+int launch_decode_admit(const DecodeState& st, const int* slots, const int* wins, int n, int pf_np, hipStream_t s) {
   if (n <= 0) return WSEG_OK;
-  hipLaunchKernelGGL(decode_admit_kernel, dim3(n), dim3(256), 0, s, st, slots, wins);
+  if (pf_np < 0 || pf_np >= st.P) { set_error("admission: %d prompt positions prefilled of %d", pf_np, st.P); return WSEG_ERR_INVALID; }
+  hipLaunchKernelGGL(decode_admit_kernel, dim3(n), dim3(256), 0, s, st, slots, wins, pf_np);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
@@ -1365,6 +1437,31 @@ int launch_embed(int dtype, const DecodeState& st, const void* tok_emb, const vo
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
+int launch_prompt_embed(int dtype, const DecodeState& st, int rows, int np, const void* tok_emb, const void* pos_emb, void* x, int d, hipStream_t s) {
+#define WSEG_EMB(T_) hipLaunchKernelGGL((prompt_embed_kernel<T_>), dim3(rows), dim3(256), 0, s, st, np, tok_emb, (const typename IO<T_>::P*)pos_emb, (float*)x, d)
+  if (dtype == WSEG_BF16X3) WSEG_EMB(X3<bf16_t>);
+  else if (dtype == WSEG_F16X3) WSEG_EMB(X3<f16_t>);
+  else if (dtype == WSEG_F32) WSEG_EMB(float);
+  else { set_error("prompt pass: dtype %d", dtype); return WSEG_ERR_INVALID; }
+#undef WSEG_EMB
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
+int launch_prompt_self_attn(int dtype, const DecodeState& st, const float* qkv, const PartialInfo* qkv_part, const void* qkv_bias, void* kc, void* vc,
+                            const int* slots, int n, int np, void* out, int H, int d, float scale, hipStream_t s) {
+  if (np < 1 || np > 4 || np > KV_PAGE) { set_error("prompt pass: %d positions", np); return WSEG_ERR_INVALID; }
+  if (!st.kv_pt) { set_error("prompt pass: page table missing"); return WSEG_ERR_STATE; }
+  PartialInfo pi;
+  if (qkv_part) pi = *qkv_part;
+#define WSEG_PSA(TO_) hipLaunchKernelGGL((prompt_self_attn_kernel<TO_>), dim3(n * H), dim3(64), 0, s, qkv, pi, (const float*)qkv_bias, (float*)kc, (float*)vc, st.kv_pt, st.npg, slots, np, st.nb, H, d, out, scale)
+  if (dtype == WSEG_BF16X3) WSEG_PSA(X3<bf16_t>);
+  else if (dtype == WSEG_F16X3) WSEG_PSA(X3<f16_t>);
+  else if (dtype == WSEG_F16M6) WSEG_PSA(M6);
+  else { set_error("prompt pass: dtype %d", dtype); return WSEG_ERR_INVALID; }
+#undef WSEG_PSA
+  WSEG_LAUNCH_CHECK();
+  return WSEG_OK;
+}
 int launch_dec_self_attn(int dtype, const DecodeState& st, const void* q, void* kc, void* vc, void* out, int H, int d,
                          const PartialInfo* qkv_part, const void* qkv_bias, float scale, hipStream_t s) {
   if (st.L > 512) { set_error("self-attention: max_length %d > 512", st.L); return WSEG_ERR_INVALID; }
@@ -1394,24 +1491,29 @@ static void launch_cross_t(const DecodeState& st, const void* q, const void* ck,
   else WSEG_CA(8);
 #undef WSEG_CA
 }
-int x3_cross_kv_format(int nb) {      // wseg_kernels.h; knob builds: WSEG_X3_CKV = f32 | k24 (attribution / A-B)
-  static const int v = WSEG_KNOB_IS("WSEG_X3_CKV", "f32") ? 0 : (WSEG_KNOB_IS("WSEG_X3_CKV", "k24") ? 1 : 2);
-  return nb <= 4 ? v : 0;
+// wseg_kernels.h.  The three-MFMA modes keep the 24-bit rows of r03-r04: their GEMMs are exact to ~6e-6 of a logit on the parity
+// sweep's model and the 24-bit rows add 2e-5, the block-floating-point rows 6e-5 — enough to flip the sweep's narrowest time-token
+// margin (1e-5 .. 1e-4) in f16x3.  The mixed mode's own fp6 cross terms cost 8e-5: it takes the 31 % smaller rows (1.3e-4 in all).
+// Knob builds: WSEG_X3_CKV = f32 | k24 | bfp for every split mode (attribution / A-B).
+int x3_cross_kv_format(int dtype, int nb) {
+  static const int forced = WSEG_KNOB_IS("WSEG_X3_CKV", "f32") ? 0 : (WSEG_KNOB_IS("WSEG_X3_CKV", "k24") ? 1 : (WSEG_KNOB_IS("WSEG_X3_CKV", "bfp") ? 2 : -1));
+  if (nb > 4) return 0;
+  return forced >= 0 ? forced : (dtype == WSEG_F16M6 ? 2 : 1);
 }
 // WSEG_F16M6: does the cross-attention write its output (the co-proj GEMM's operand) as M6 rows?  The 24-bit K / V kernel does (it
 // exists for up to 4 beams); 5..8 beams run the general fp32-K/V kernel, which writes hi | lo rows that the caller converts.
-bool dec_cross_attn_writes_mx(int dtype, int nb) { return dtype == WSEG_F16M6 && x3_cross_kv_format(nb) != 0; }
+bool dec_cross_attn_writes_mx(int dtype, int nb) { return dtype == WSEG_F16M6 && x3_cross_kv_format(dtype, nb) != 0; }
 
 int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const void* ck, const void* cv, void* out, int H, int Tk, int d,
-                          const PartialInfo* q_part, const void* q_bias, float scale, hipStream_t s) {
+                          const PartialInfo* q_part, const void* q_bias, float scale, hipStream_t s, const int* kv_slot) {
   if (Tk > 512) { set_error("cross-attention: %d encoder positions > 512", Tk); return WSEG_ERR_INVALID; }
   PartialInfo pi;
   if (q_part) pi = *q_part;
   const bool m6 = dtype == WSEG_F16M6;      // M6-row output from the 24-bit K / V kernel only (dec_cross_attn_writes_mx)
-  const int kvf = (dtype == WSEG_BF16X3 || dtype == WSEG_F16X3 || m6) ? x3_cross_kv_format(st.nb) : 0;
+  const int kvf = (dtype == WSEG_BF16X3 || dtype == WSEG_F16X3 || m6) ? x3_cross_kv_format(dtype, st.nb) : 0;
   if (kvf == 2) {
     dim3 grid(st.W * H), block(256);
-#define WSEG_BFP(TO_, NB_) hipLaunchKernelGGL((dec_cross_attn_bfp_kernel<TO_, NB_>), grid, block, 0, s, st, (const float*)q, (const unsigned char*)ck, (const unsigned char*)cv, out, H, Tk, d, pi, (const float*)q_bias, scale)
+#define WSEG_BFP(TO_, NB_) hipLaunchKernelGGL((dec_cross_attn_bfp_kernel<TO_, NB_>), grid, block, 0, s, st, (const float*)q, (const unsigned char*)ck, (const unsigned char*)cv, out, H, Tk, d, pi, (const float*)q_bias, scale, kv_slot)
     if (dtype == WSEG_BF16X3) { if (st.nb <= 1) WSEG_BFP(X3<bf16_t>, 1); else if (st.nb <= 2) WSEG_BFP(X3<bf16_t>, 2); else WSEG_BFP(X3<bf16_t>, 4); }
     else if (m6) { if (st.nb <= 1) WSEG_BFP(M6, 1); else if (st.nb <= 2) WSEG_BFP(M6, 2); else WSEG_BFP(M6, 4); }
     else { if (st.nb <= 1) WSEG_BFP(X3<f16_t>, 1); else if (st.nb <= 2) WSEG_BFP(X3<f16_t>, 2); else WSEG_BFP(X3<f16_t>, 4); }
@@ -1419,10 +1521,9 @@ int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const
     WSEG_LAUNCH_CHECK();
     return WSEG_OK;
   }
-#ifdef WSEG_KNOBS
   if (kvf == 1) {
     dim3 grid(st.W * H), block(256);
-#define WSEG_K24(TO_, NB_) hipLaunchKernelGGL((dec_cross_attn_k24_kernel<TO_, NB_>), grid, block, 0, s, st, (const float*)q, (const unsigned char*)ck, (const unsigned char*)cv, out, H, Tk, d, pi, (const float*)q_bias, scale)
+#define WSEG_K24(TO_, NB_) hipLaunchKernelGGL((dec_cross_attn_k24_kernel<TO_, NB_>), grid, block, 0, s, st, (const float*)q, (const unsigned char*)ck, (const unsigned char*)cv, out, H, Tk, d, pi, (const float*)q_bias, scale, kv_slot)
     if (dtype == WSEG_BF16X3) { if (st.nb <= 1) WSEG_K24(X3<bf16_t>, 1); else if (st.nb <= 2) WSEG_K24(X3<bf16_t>, 2); else WSEG_K24(X3<bf16_t>, 4); }
     else if (m6) { if (st.nb <= 1) WSEG_K24(M6, 1); else if (st.nb <= 2) WSEG_K24(M6, 2); else WSEG_K24(M6, 4); }
     else { if (st.nb <= 1) WSEG_K24(X3<f16_t>, 1); else if (st.nb <= 2) WSEG_K24(X3<f16_t>, 2); else WSEG_K24(X3<f16_t>, 4); }
@@ -1430,7 +1531,7 @@ int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const
     WSEG_LAUNCH_CHECK();
     return WSEG_OK;
   }
-#endif
+  if (kv_slot) { set_error("cross-attention: the slot map exists for the 24-bit and block-floating-point K / V kernels only"); return WSEG_ERR_INVALID; }
   static const bool deep = getenv("WSEG_CROSS_NO_PK") == nullptr;         // tuning knob: fp32-FMA kernel
   if ((dtype == WSEG_BF16 || dtype == WSEG_F16) && deep && Tk <= 512 && st.nb <= 4) {
     dim3 grid(st.W * H), block(256);

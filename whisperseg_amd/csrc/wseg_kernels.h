@@ -112,7 +112,7 @@ int x3_enc_attention_mode();
 // 2 = per-row block floating point (r05): the 200-recording sweep through the CPU oracle with K and V so quantised is 200 / 200 and the
 // first-step logit error stays at the mode's own 1.5e-4 (24-bit: 1.5e-4; plain half: 7.5e-4, 196 / 200; tools/precision_study.py
 // "ckv=bfp16r", profiles/r05_precision_study.json) for 132 instead of 192 bytes per row of an HBM-bound stream.
-int x3_cross_kv_format(int nb);      // 0 = fp32 (more than 4 beams), 1 = 24-bit (knob builds: WSEG_X3_CKV=k24), 2 = bfp16 rows
+int x3_cross_kv_format(int dtype, int nb);      // 0 = fp32 (more than 4 beams), 1 = 24-bit (bf16x3 / f16x3), 2 = bfp16 rows (f16m6)
 static inline size_t cross_kv_row_bytes(int fmt, size_t es) { return fmt == 2 ? 132 : (fmt == 1 ? 192 : 64 * es); }
 // WSEG_F16M6: hi | lo IEEE-half operand rows [M][2K words] -> M6 rows [M][4K bytes] (wseg_common.h), K % 64 == 0
 int launch_x3_to_m6(const void* x3_rows, void* m6_rows, size_t M, int K, bool weight_order, hipStream_t s);

@@ -25,6 +25,7 @@ struct DecLayer {
 
 struct DecPlan {   // decoder-side buffers (W window slots)
   int W = 0;
+  int row_cap = 0;                           // rows the activation buffers hold (W * beams rounded up to 256)
   char *ck, *cv, *sk, *sv, *dx, *dy, *dq, *dattn, *dh, *logits, *first_logits, *splitk, *mask;
   int kv_units = 0;                          // pool units of the paged self-attention K / V (wseg_kernels.h)
   size_t kv_layer_stride = 0;                // bytes between the pools of consecutive layers (K and V alike)
@@ -32,6 +33,7 @@ struct DecPlan {   // decoder-side buffers (W window slots)
   int* kv_pairs = nullptr;                   // scratch of the page-table update kernel [2 * W]
   char *tk_val, *tk_idx, *tk_stat;
   int *adm_slots, *adm_wins, *ret_slots;     // device lists written by the scheduler (admission / retirement)
+  int* zeros = nullptr;                      // [W] zeros: the "idle" flags of the prompt pass's view of the admitted windows
   int* seed_dev;                             // sampling seed (2 words), rewritten per call: the step graph stays valid
   size_t splitk_bytes;
   DecodeState st;
@@ -155,7 +157,7 @@ void make_plan(const wseg_model* m, int W, int nb, int L, int kv_units, char* ba
       if (!gemm_out_is_mx(dtp, n * c.spec_cols, (int)d, m->kp1)) big = std::max(big, mp * 3 * d);
       if (!gemm_out_is_mx(dtp, n * c.enc_positions, (int)ffn, (int)d)) big = std::max(big, mp * ffn);
     }
-    if (!gemm_out_is_mx(dtp, R0, (int)ffn, (int)d)) big = std::max(big, Rp0 * ffn);
+    big = std::max(big, Rp0 * ffn);      // decode step / prompt pass of any row count up to R0 whose FFN hidden arrives as hi | lo rows
     if (!dec_cross_attn_writes_mx(dtp, nb)) big = std::max(big, Rp0 * d);      // 5..8 beams: cross-attention output as hi | lo rows
     p.mxa = take(big * 4);
     p.mxe = take(Mp * d * 4);
@@ -164,7 +166,7 @@ void make_plan(const wseg_model* m, int W, int nb, int L, int kv_units, char* ba
   DecPlan& q = p.dec;
   q.W = W;
   const size_t Wc = W, R = Wc * nb, Rp = align_up(R, 256);
-  const size_t crow = cross_kv_row_bytes(m->x3 ? x3_cross_kv_format(nb) : 0, es);      // bytes per (position, head) row (wseg_dec.hip)
+  const size_t crow = cross_kv_row_bytes(m->x3 ? x3_cross_kv_format(c.dtype, nb) : 0, es);      // bytes per (position, head) row (wseg_dec.hip)
   q.ck = take(Ld * Wc * H * Tk * crow);
   q.cv = take(Ld * Wc * H * Tk * crow);
   q.kv_units = kv_units;
@@ -173,6 +175,7 @@ void make_plan(const wseg_model* m, int W, int nb, int L, int kv_units, char* ba
   q.sv = take(Ld * q.kv_layer_stride);
   q.kv_pt = (int*)take(Wc * kv_pages(L) * 4);
   q.kv_pairs = (int*)take(2 * Wc * 4);
+  q.row_cap = (int)Rp;
   q.dx = take(Rp * d * 4);                         // decoder residual stream, fp32
   q.dy = take(Rp * d * es);
   q.dq = take(Rp * d * es);
@@ -192,6 +195,7 @@ void make_plan(const wseg_model* m, int W, int nb, int L, int kv_units, char* ba
   q.adm_slots = (int*)take(Wc * 4);
   q.adm_wins = (int*)take(Wc * 4);
   q.ret_slots = (int*)take(Wc * 4);
+  q.zeros = (int*)take(Wc * 4);
   q.seed_dev = (int*)take(8);
   DecodeState& st = q.st;
   st.W = (int)Wc; st.nb = nb; st.L = L; st.V = c.vocab; st.ldv = m->vp;
@@ -294,15 +298,28 @@ int run_encoder(wseg_model* m, const float* feats, int W, Plan& p, void* enc_out
   return WSEG_OK;
 }
 
-// One decoder step for all R rows at position *st.pos.  want_logits: run final LN + LM head.
-int run_decoder_step(wseg_model* m, DecPlan& p, char* mxa, bool want_logits, hipStream_t s) {
+// The forced prompt positions 0 .. np - 1 of n windows admitted together (device list `slots`), as one pass of n * np rows through the
+// decoder layers instead of np steps of every slot: the decoder weights and the windows' cross-attention K / V are read once for them
+// (split-precision modes, up to 4 beams; the admission kernel then starts the slots at position np).
+struct PromptPass { const int* slots; int n, np; };
+
+// One decoder step for all R rows at position *st.pos (want_logits: final LN + LM head), or the prompt pass `pp` of newly admitted windows
+// (row i * np + j = window i at position j; no logits: the next token is forced).
+int run_decoder_step(wseg_model* m, DecPlan& p, char* mxa, bool want_logits, hipStream_t s, const PromptPass* pp = nullptr) {
   const wseg_model_config& c = m->cfg;
   const int dt = m->sdt, gdt = c.dtype, d = c.d_model, H = c.n_heads, ffn = c.ffn, Tk = c.enc_positions;
-  const DecodeState& st = p.st;
-  const int R = st.W * st.nb;
   const size_t self_stride = p.kv_layer_stride;
-  const size_t cross_stride = (size_t)st.W * H * Tk * cross_kv_row_bytes(m->x3 ? x3_cross_kv_format(st.nb) : 0, m->es);
-  WSEG_TRY(launch_embed(m->mx ? WSEG_F32 : dt, st, m->mx ? m->dec_tok_f32 : m->dec_tok, m->dec_pos, p.dx, d, s));
+  const size_t cross_stride = (size_t)p.st.W * H * Tk * cross_kv_row_bytes(m->x3 ? x3_cross_kv_format(gdt, p.st.nb) : 0, m->es);
+  DecodeState view = p.st;      // the prompt pass seen by the cross-attention kernel: n "slots" of np "beams", none idle
+  if (pp) { view.W = pp->n; view.nb = pp->np; view.done = p.zeros; }
+  const DecodeState& st = pp ? view : p.st;
+  const int R = st.W * st.nb;
+  if (pp) {
+    if (!m->x3 || x3_cross_kv_format(gdt, p.st.nb) == 0 || R > p.row_cap) { set_error("prompt pass: unsupported mode / row count %d", R); return WSEG_ERR_STATE; }
+    WSEG_TRY(launch_prompt_embed(m->mx ? WSEG_F32 : dt, p.st, R, pp->np, m->mx ? m->dec_tok_f32 : m->dec_tok, m->dec_pos, p.dx, d, s));
+  } else {
+    WSEG_TRY(launch_embed(m->mx ? WSEG_F32 : dt, st, m->mx ? m->dec_tok_f32 : m->dec_tok, m->dec_pos, p.dx, d, s));
+  }
   EpiParams e;
   // WSEG_F16M6: LayerNorm outputs (dy) and attention outputs (dattn) are M6 rows already; the FFN hidden (dh) is when its GEMM
   // ran on a large-tile kernel (a_mx: the operand needs no conversion)
@@ -326,7 +343,15 @@ int run_decoder_step(wseg_model* m, DecPlan& p, char* mxa, bool want_logits, hip
       g.splitk_ws = (float*)p.splitk; g.splitk_ws_bytes = p.splitk_bytes;
       PartialInfo pi; bool ok = false;
       WSEG_TRY(launch_gemm_partial(gdt, g, &pi, &ok, s));
-      if (ok) {
+      if (pp) {
+        if (!ok) {      // many windows admitted at once: q | k | v as fp32 rows of an un-split GEMM (bias added by the attention kernel)
+          e = EpiParams();
+          e.out_f32 = (float*)p.logits; e.ldc = 3 * d;
+          WSEG_TRY(gemm(m, EPI_F32, a_op, d, L.qkv_w, d, R, 3 * d, d, e, &p, s));
+        }
+        WSEG_TRY(launch_prompt_self_attn(gdt, p.st, (const float*)p.logits, ok ? &pi : nullptr, L.qkv_b, p.sk + l * self_stride, p.sv + l * self_stride,
+                                         pp->slots, pp->n, pp->np, p.dattn, H, d, 0.125f, s));
+      } else if (ok) {
         WSEG_TRY(launch_dec_self_attn(gdt, st, nullptr, p.sk + l * self_stride, p.sv + l * self_stride, p.dattn, H, d, &pi, L.qkv_b, 0.125f, s));
       } else {
         e = EpiParams();
@@ -345,12 +370,14 @@ int run_decoder_step(wseg_model* m, DecPlan& p, char* mxa, bool want_logits, hip
       PartialInfo pi; bool ok = false;
       WSEG_TRY(launch_gemm_partial(gdt, g, &pi, &ok, s));
       if (ok) {
-        WSEG_TRY(launch_dec_cross_attn(gdt, st, nullptr, p.ck + l * cross_stride, p.cv + l * cross_stride, p.dattn, H, Tk, d, &pi, L.cq_b, 0.125f, s));
+        WSEG_TRY(launch_dec_cross_attn(gdt, st, nullptr, p.ck + l * cross_stride, p.cv + l * cross_stride, p.dattn, H, Tk, d, &pi, L.cq_b, 0.125f, s,
+                                       pp ? pp->slots : nullptr));
       } else {
         e = EpiParams();
         e.bias = L.cq_b; e.out = p.dq; e.ldc = d; e.scale = 0.125f;
         WSEG_TRY(gemm(m, EPI_SCALE, a_op, d, L.cq_w, d, R, d, d, e, &p, s));
-        WSEG_TRY(launch_dec_cross_attn(gdt, st, p.dq, p.ck + l * cross_stride, p.cv + l * cross_stride, p.dattn, H, Tk, d, nullptr, nullptr, 0.125f, s));
+        WSEG_TRY(launch_dec_cross_attn(gdt, st, p.dq, p.ck + l * cross_stride, p.cv + l * cross_stride, p.dattn, H, Tk, d, nullptr, nullptr, 0.125f, s,
+                                       pp ? pp->slots : nullptr));
       }
     }
     WSEG_TRY(gemm_resid_ln(p.dattn, d, L.co_w, L.co_b, L.ln3_g, L.ln3_b, dec_cross_attn_writes_mx(gdt, st.nb)));      // x += cross Wo ; y = LN3(x)
@@ -361,7 +388,7 @@ int run_decoder_step(wseg_model* m, DecPlan& p, char* mxa, bool want_logits, hip
     WSEG_TRY(gemm_resid_ln(p.dh, ffn, L.fc2_w, L.fc2_b, last ? m->dec_ln_g : m->dec[l + 1].ln1_g,
                            last ? m->dec_ln_b : m->dec[l + 1].ln1_b, dh_mx));
   }
-  if (want_logits) {
+  if (want_logits && !pp) {
     e = EpiParams();
     e.out_f32 = (float*)p.logits; e.ldc = m->vp;
     WSEG_TRY(gemm(m, EPI_F32, p.dy, d, m->dec_tok, d, R, m->vp, d, e, nullptr, s));
@@ -586,15 +613,21 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
   WSEG_TRY(launch_build_suppress_mask((unsigned char*)q.mask, c.vocab, gp->suppress_tokens, gp->n_suppress,
                                       gp->begin_suppress_tokens, gp->n_begin_suppress, s));
   WSEG_TRY(launch_decode_reset(st, s));
+  WSEG_HIP_CHECK(hipMemsetAsync(q.zeros, 0, (size_t)S * sizeof(int), s));
 
   const int d = c.d_model, H = c.n_heads, Tk = c.enc_positions;
-  const int kv24 = m->x3 ? x3_cross_kv_format(nb) : 0;
+  const int kv24 = m->x3 ? x3_cross_kv_format(c.dtype, nb) : 0;
+  // prompt pass: the first NPF forced positions of every admission run as one pass (run_decoder_step, PromptPass) and the slots start
+  // at position NPF.  Split-precision modes up to 4 beams (24-bit / block-floating-point cross K / V); the f32 and plain 16-bit modes step through the prompt.
+  const bool prompt_pass = getenv("WSEG_NO_PROMPT_PASS") == nullptr;      // test knob (read per call): step through the prompt instead
+  const int NPF = (prompt_pass && m->x3 && kv24 != 0) ? std::min(P - 1, 4) : 0;
   const size_t cross_stride = (size_t)S * H * Tk * cross_kv_row_bytes(kv24, m->es);
   const size_t feat_stride = (size_t)c.n_mels * c.spec_cols;
   const int npg = st.npg;
 
   // host view of the slots
-  std::vector<int> slot_win(S, -1), slot_from(S, 0);   // window in the slot (-1 = free), first step whose status counts for it
+  std::vector<int> slot_win(S, -1), slot_from(S, 0);   // window in the slot (-1 = free), first step whose status counts for it (at which
+                                                       // the slot is at position NPF)
   std::vector<std::vector<int>> slot_units(S);         // pool units the slot holds, in page order
   std::vector<int> free_slots, free_units, tmp_a, tmp_b;
   for (int i = S - 1; i >= 0; --i) free_slots.push_back(i);   // popped from the back: lowest slot first
@@ -651,7 +684,28 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
       WSEG_TRY(encode_run(tmp_b[i], j - i, i));
       i = j;
     }
-    WSEG_TRY(launch_decode_admit(st, q.adm_slots, q.adm_wins, n, s));
+    WSEG_TRY(launch_decode_admit(st, q.adm_slots, q.adm_wins, n, NPF, s));
+    if (NPF > 0) {
+      // the first page of every admitted slot now (the refill rule left a pool unit for each), then the prompt pass in chunks that fit
+      // the decode step's row buffers
+      tmp_b.clear();
+      for (int i = 0; i < n; ++i) {
+        const int sl = tmp_a[i];
+        if (free_units.empty()) { set_error("admission without a pool unit per window"); return WSEG_ERR_STATE; }
+        const int u = free_units.back(); free_units.pop_back();
+        slot_units[sl].push_back(u);
+        ++units_in_use;
+        tmp_b.push_back(sl * npg); tmp_b.push_back(u);
+      }
+      if (units_in_use > stats.kv_units_peak) stats.kv_units_peak = units_in_use;
+      WSEG_TRY(h2d_list(ln, tmp_b.data(), (int)tmp_b.size(), q.kv_pairs, s));
+      WSEG_TRY(launch_kv_assign(q.kv_pt, q.kv_pairs, n, s));
+      const int chunk = q.row_cap / NPF;
+      for (int c0 = 0; c0 < n; c0 += chunk) {
+        const PromptPass pp = {q.adm_slots + c0, std::min(chunk, n - c0), NPF};
+        WSEG_TRY(run_decoder_step(m, q, p.mxa, false, s, &pp));
+      }
+    }
     in_flight += n;
     stats.n_admissions += 1;
     return WSEG_OK;
@@ -678,7 +732,7 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
     tmp_a.clear();
     for (int sl = 0; sl < S; ++sl) {
       if (slot_win[sl] < 0) continue;
-      const int pos = t - slot_from[sl];
+      const int pos = t - slot_from[sl] + NPF;
       if (pos >= L || pos % KV_PAGE) continue;
       while (free_units.empty()) {
         int victim = -1;                                // youngest slot that holds pages (never the requester)
@@ -728,7 +782,7 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
   auto launch_step = [&]() -> int {
     // the first generated step of a call whose windows all start together is launched eagerly with the logits snapshot
     // (wseg_debug_first_logits); every other step replays the graph
-    const bool snap = t == P - 1 && snap_ok && stats.n_preemptions == 0;
+    const bool snap = t == P - 1 - NPF && snap_ok && stats.n_preemptions == 0;
     if (snap) m->first_logits_valid = true;
     if (snap || !use_graph) return enqueue_step(snap, s);
     if (!ln.step_graph || ln.step_graph_key != key) {
@@ -806,8 +860,8 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
       break;
     }
     if (drained) {                // nothing left to admit later: stop launching once every window in flight must have ended
-      bool may_run = false;       // (a window admitted before step f feeds its last position, L - 2, at step f + L - 2)
-      for (int sl = 0; sl < S && !may_run; ++sl) may_run = slot_win[sl] >= 0 && t < slot_from[sl] + L - 1;
+      bool may_run = false;       // (a window admitted before step f feeds its last position, L - 2, at step f + L - 2 - NPF)
+      for (int sl = 0; sl < S && !may_run; ++sl) may_run = slot_win[sl] >= 0 && t < slot_from[sl] + L - 1 - NPF;
       if (!may_run) break;
     }
     WSEG_TRY(assign_pages());
