@@ -588,6 +588,9 @@ __global__ __launch_bounds__(WM * WN * 64, (BM <= 128 && BN <= 64 && WM * WN == 
 // ------------------------------------------------------------------------------------------------
 // (NIT / I0: the accumulator array holds NIT column tiles of which I0 .. I0 + 3 are written — the 128x128 wave tiles of gemm_w4_kernel
 // go out as two 64-column halves)
+#ifndef WSEG_EPI_M6_LDS
+#define WSEG_EPI_M6_LDS 1      // (0: the register-only row writer + scalar GELU of r04, for same-box A/B builds)
+#endif
 template <typename T, int EPI, int MI, int NI, int NIT = NI, int I0 = 0>
 __device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NIT][MI], float* stage, const EpiParams& ep, int M, int mb,
                                                 int nb, int lane, int wave) {
@@ -658,6 +661,13 @@ __device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NIT][MI], flo
         int mm = m;
         if (ep.slot_map) { const int b = m / ep.t_len; mm = (b == kv_b0 ? kv_s0 : kv_s1) * ep.t_len + (m - b * ep.t_len); }
         if (m < M) epi_apply8<EPI, T>(ep2, mm, nc, v);
+      } else if constexpr (WSEG_EPI_M6_LDS && IsMx<T>::v && (EPI == EPI_GELU || EPI == EPI_STORE)) {
+        // M6 rows: the quad's word exchange goes through the strip slots the quad has just read (8 floats per lane = its 128 bytes)
+        if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) { const gelu_f2 y = gelu_erf_fast2((gelu_f2){v[e], v[e + 1]}); v[e] = y[0]; v[e + 1] = y[1]; }
+        }
+        op_st8_m6_lds(ep.out, (size_t)m, ep.ldc, nc, v, (unsigned char*)(strip + rw * LDT + (cc & ~31)), m < M);
       } else {
         if (m < M) epi_apply8<EPI, T>(ep2, m, nc, v);
       }
@@ -914,6 +924,15 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   const int count = q + (xcd < r ? 1 : 0);
   if (loc >= count) return;
+#if defined(WSEG_PP_STAGGER) && WSEG_PP_STAGGER > 0
+  // experiment (variant builds): the workgroups of XCD x start x * WSEG_PP_STAGGER shader cycles late, so that the tile boundaries of
+  // the eight XCDs — the HBM burst of every CU's epilogue — do not coincide (long tile sequences only: the delay is paid once).
+  // r05: 8 000 / 15 000 cycles per XCD measured +0.4 % on the 1 024-window step (profiles/r05_epilogue_ab.txt): not the lever.
+  if (!SPLITK && (count + bpx - 1) / bpx >= 16) {
+    const long long t0 = clock64(), wait = (long long)xcd * WSEG_PP_STAGGER;
+    while (clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
   // split-K: copy z of the tile grid owns K tiles [k_first(z), k_first(z + 1))
   auto tile_z = [&](int swz) { return SPLITK ? swz / ntmn : 0; };
   auto k_first = [&](int z) { return SPLITK ? (MXM ? 2 * (z * (nk / 2) / S) : z * nk / S) : 0; };      // M6 rows: whole (hi, MX) tile pairs
