@@ -2112,6 +2112,7 @@ template <typename T> static GemmArgs kernel_view(const GemmArgs& g0) {
 }
 
 template <typename T> static int launch_pp_splitk(const GemmArgs& g, int S, hipStream_t s);
+template <typename T> static int pp_splitk_plan(const GemmArgs& g);
 
 static bool skinny_split_writes_mx(int N) {
   static const bool off = WSEG_KNOB_SET("WSEG_NO_MX_REDUCE");      // A/B knob (variant builds)
@@ -2327,6 +2328,18 @@ template <typename T>
 static int gemm_partial_t(const GemmArgs& g0, PartialInfo* info, bool* ok, hipStream_t s) {
   const GemmArgs g = kernel_view<T>(g0);
   if (big_tile_path(g) || !g.splitk_ws || g.K % 64 || g.N % 64) return WSEG_OK;
+#ifndef WSEG_PARTIAL_PP
+#define WSEG_PARTIAL_PP 1
+#endif
+  if (WSEG_PARTIAL_PP) {      // thousands of rows, too few 256x256 tiles for the chip (the decode step's cross-attention query): the split-K copies
+    const int S = pp_splitk_plan<T>(g);      // of the ping-pong kernel leave the same fp32 planes [z][M][N] as the stream family
+    if (S) {
+      WSEG_TRY_(launch_pp_splitk<T>(g, S, s));
+      info->part = g.splitk_ws; info->splits = S; info->m_pad = g.M; info->n = g.N;
+      *ok = true;
+      return WSEG_OK;
+    }
+  }
   SkinnyPlan sp = plan_skinny(g, IsMx<T>::v);
   if ((size_t)sp.splits * sp.m_pad * g.N * sizeof(float) > g.splitk_ws_bytes) return WSEG_OK;
   WSEG_TRY_(launch_skinny_partial<T>(g, sp, s));
