@@ -64,6 +64,8 @@ template <> struct H16<bf16_t> {
   static __device__ __forceinline__ float lo(uint32_t w) { return __uint_as_float(w << 16); }
   static __device__ __forceinline__ float hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
   static __device__ __forceinline__ float one(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+  static __device__ __forceinline__ float sub_lo(float s, uint32_t w) { return s - lo(w); }
+  static __device__ __forceinline__ float sub_hi(float s, uint32_t w) { return s - hi(w); }
   // gfx950's v_cvt_pk_bf16_f32 (the integer emulation is ~7 VALU per element, which showed up as microseconds per
   // 256x256 GEMM tile epilogue)
   static __device__ __forceinline__ uint32_t pack(float l, float h) {
@@ -79,6 +81,10 @@ template <> struct H16<f16_t> {
   static __device__ __forceinline__ float lo(uint32_t w) { return (float)__builtin_bit_cast(hw_f16x2, w)[0]; }
   static __device__ __forceinline__ float hi(uint32_t w) { return (float)__builtin_bit_cast(hw_f16x2, w)[1]; }
   static __device__ __forceinline__ float one(f16_t v) { return (float)__builtin_bit_cast(_Float16, v.bits); }
+  // s - (float)half as ONE v_fma_mix_f32 (the half operand converted inside the instruction; fma(h, -1, s) rounds once, like the
+  // subtraction: bit-identical) instead of v_cvt_f32_f16 + v_sub_f32 — the lo part of every hi + lo split
+  static __device__ __forceinline__ float sub_lo(float s, uint32_t w) { return __builtin_fmaf(lo(w), -1.0f, s); }
+  static __device__ __forceinline__ float sub_hi(float s, uint32_t w) { return __builtin_fmaf(hi(w), -1.0f, s); }
   // round to nearest even, IEEE overflow to infinity — as torch.float16 does.  The one tensor HF protects from that in
   // half precision is the residual stream (the clamp in modeling_whisper.py's encoder layer), which is fp32 here.
   static __device__ __forceinline__ uint32_t pack(float l, float h) {
@@ -182,13 +188,13 @@ __host__ __device__ __forceinline__ int x3_col(int c) { return ((c >> 5) << 6) |
 
 // 8 consecutive logical columns (c % 8 == 0) <-> the two 16-byte pieces of a split row
 template <typename HT> __device__ __forceinline__ void split8(const float v[8], uint4& hi, uint4& lo) {
-  float s[8], h[8], r[8];
+  float s[8], r[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = H16<HT>::sat(v[e]);
   hi = pack8<HT>(s);
-  unpack8<HT>(hi, h);
+  const uint32_t hw[4] = {hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-  for (int e = 0; e < 8; ++e) r[e] = s[e] - h[e];
+  for (int e = 0; e < 4; ++e) { r[2 * e] = H16<HT>::sub_lo(s[2 * e], hw[e]); r[2 * e + 1] = H16<HT>::sub_hi(s[2 * e + 1], hw[e]); }
   lo = pack8<HT>(r);
 }
 // Operand stores / loads.  base: start of the operand matrix, ld: LOGICAL row length, c: logical column.
@@ -284,13 +290,13 @@ __device__ __forceinline__ void op_st8_m6(void* base, size_t row, int ld, int c,
 // maximum of the rounded values IS the rounded maximum — bit-identical scales).  85 instead of 135 VALU instructions per 8 columns: the
 // GELU epilogue of the encoder's fc1 GEMM is VALU-bound (all 8 waves of the workgroup write their tile at once, matrix pipe idle).
 __device__ __forceinline__ void op_st8_m6_lds(void* base, size_t row, int ld, int c, const float v[8], unsigned char* quad, bool store) {
-  float s[8], h[8], r[8];
+  float s[8], r[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = H16<f16_t>::sat(v[e]);
   const uint4 hi = pack8<f16_t>(s);
-  unpack8<f16_t>(hi, h);
+  const uint32_t hw4[4] = {hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-  for (int e = 0; e < 8; ++e) r[e] = s[e] - h[e];
+  for (int e = 0; e < 4; ++e) { r[2 * e] = H16<f16_t>::sub_lo(s[2 * e], hw4[e]); r[2 * e + 1] = H16<f16_t>::sub_hi(s[2 * e + 1], hw4[e]); }
   const uint4 lo = pack8<f16_t>(r);
   float ms = fabsf(s[0]), mr = fabsf(r[0]);
 #pragma unroll

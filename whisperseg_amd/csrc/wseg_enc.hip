@@ -271,7 +271,8 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
       }
       float mx = s[0];
 #pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      for (int r = 1; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);      // v_max3_f32
+      mx = fmaxf(mx, s[15]);
       mx = fmaxf(mx, lane_xor<32>(mx));
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __expf(m_run - m_new);
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
         if constexpr (SPLIT) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            pfl.u[j] = H16<HT>::pack(s[8 * mm + 2 * j] - H16<HT>::lo(pf.u[j]), s[8 * mm + 2 * j + 1] - H16<HT>::hi(pf.u[j]));
+            pfl.u[j] = H16<HT>::pack(H16<HT>::sub_lo(s[8 * mm + 2 * j], pf.u[j]), H16<HT>::sub_hi(s[8 * mm + 2 * j + 1], pf.u[j]));
         }
         // V^T row hd = ht*32 + qi, 8-byte granule (sub*8 + 4 mm + g2 [+ 2]) ^ ((hd >> 1) & 15)  ==  ht*4096 + (vfrag ^ (c << 3)) bytes
         const unsigned va = vfo ^ ((sub * 8 + 4 * mm) << 3), vb = vfo ^ ((sub * 8 + 4 * mm + 2) << 3);
