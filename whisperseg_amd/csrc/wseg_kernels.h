@@ -56,7 +56,7 @@ struct EpiParams {
   size_t qkv_plane = 0;
   int kv24 = 0;                  // split-precision modes, EPI_KV_CROSS storage of the cross K / V (x3_cross_kv_format): 0 = fp32;
                                  // 1 = 24-bit values in two planes per (slot, head): [t_len][64] top halves (16 bits) then [t_len][64]
-                                 // third bytes; 2 (default, r05) = block floating point, one block per (position, head) row:
+                                 // third bytes (bf16x3 / f16x3); 2 (f16m6, r05) = block floating point, one block per (position, head) row:
                                  // [t_len][64] int16 then [t_len] fp32 powers of two, value = int16 * scale (132 bytes per row)
 };
 
@@ -105,13 +105,13 @@ int launch_enc_attention(int dtype, const void* q, const void* k, const void* vt
 // split-precision modes: arithmetic of the encoder self-attention -> EpiParams::qkv_mode.  2 (default): split precision (half
 // hi + lo operands, three MFMAs per product); 0: plain IEEE half (WSEG_X3_ENC_ATTN=f16); 1: fp32 matrix cores (=f32).
 int x3_enc_attention_mode();
-// split-precision modes: cross-attention K / V stored as fp32 words rounded to their top 24 bits (sign, exponent, 15 + 1 mantissa
-// bits — the ">= 16 bits" the precision study asks of the cross K; 3 instead of 4 bytes per element of an HBM-bound stream).
-// Default on; WSEG_X3_CKV=f32 keeps fp32.
 // Storage format of the cross-attention K / V in the split-precision modes (EpiParams::kv24) and its bytes per (position, head) row.
+// 1 = fp32 words rounded to their top 24 bits (sign, exponent, 15 + 1 mantissa bits — the ">= 16 bits" the precision study asks of the
+// cross K; 3 instead of 4 bytes per element of an HBM-bound stream): bf16x3 / f16x3.
 // 2 = per-row block floating point (r05): the 200-recording sweep through the CPU oracle with K and V so quantised is 200 / 200 and the
-// first-step logit error stays at the mode's own 1.5e-4 (24-bit: 1.5e-4; plain half: 7.5e-4, 196 / 200; tools/precision_study.py
-// "ckv=bfp16r", profiles/r05_precision_study.json) for 132 instead of 192 bytes per row of an HBM-bound stream.
+// first-step logit error stays at the mixed mode's own 1.5e-4 (24-bit: 1.5e-4; plain half: 7.5e-4, 196 / 200; tools/precision_study.py
+// "ckv=bfp16r", profiles/r05_precision_study.json) for 132 instead of 192 bytes per row of an HBM-bound stream: f16m6 (wseg_dec.hip,
+// x3_cross_kv_format, says why the three-MFMA modes do not take it).
 int x3_cross_kv_format(int dtype, int nb);      // 0 = fp32 (more than 4 beams), 1 = 24-bit (bf16x3 / f16x3), 2 = bfp16 rows (f16m6)
 static inline size_t cross_kv_row_bytes(int fmt, size_t es) { return fmt == 2 ? 132 : (fmt == 1 ? 192 : 64 * es); }
 // WSEG_F16M6: hi | lo IEEE-half operand rows [M][2K words] -> M6 rows [M][4K bytes] (wseg_common.h), K % 64 == 0
