@@ -2370,7 +2370,7 @@ template <typename T> static int pp_splitk_plan(const GemmArgs& g) {
   // 128x64 stream kernel from 512 rows up (decode step at 128 / 256 / 384 slots: 9.9 -> 9.3, 15.2 -> 14.5, 18.4 -> 17.7 ms; at 64
   // slots the stream kernel wins, 6.2 against 6.7 ms)
   static const int min_rows_env = WSEG_KNOB_INT("WSEG_PP_SPLITK_MIN_ROWS", 0);
-  const int min_rows = min_rows_env ? min_rows_env : (IO<T>::split ? 512 : 2048);
+  const int min_rows = min_rows_env ? min_rows_env : (IO<T>::split ? 448 : 2048);      // (r05: 480 rows = the 120 windows of a one-hour recording, 9.39 -> 8.99 ms per step; at 384 rows the stream kernel wins, 7.32 against 7.77)
   static const int min_kt = WSEG_KNOB_INT("WSEG_PP_SPLITK_MIN_KT", 40);
   if (g.M < min_rows || g.N % 256 || g.K % 64 || g.K / 64 < min_kt || !g.splitk_ws) return 0;
   const int nt = cdiv(g.M, 256) * (g.N / 256), nk = g.K / 64, n_cu = device_cu_count();
