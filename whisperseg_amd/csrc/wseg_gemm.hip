@@ -2249,6 +2249,21 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
     WSEG_LAUNCH_CHECK();
     return WSEG_OK;
   }
+#ifndef WSEG_MX_PP_SPLITK
+#define WSEG_MX_PP_SPLITK 1
+#endif
+  // WSEG_F16M6, M6-row outputs below the large-tile threshold but with hundreds of rows (decoder fc1 at 112-270 slots; r05): split-K copies
+  // of the 256x256 kernel + the M6-writing 8-column reduction, instead of the 128x64 stream kernel (whose 4-column epilogue writes hi | lo
+  // rows that a conversion launch turns into M6 rows): 57.5 + 11.8 us -> see profiles/r05_epilogue_ab.txt.  gemm_out_is_mx predicts it.
+  if constexpr (IsMx<T>::v && (EPI == EPI_STORE || EPI == EPI_GELU)) {
+    const int S = WSEG_MX_PP_SPLITK ? pp_splitk_plan<T>(g) : 0;
+    if (S) {
+      WSEG_TRY_(launch_pp_splitk<T>(g, S, s));
+      hipLaunchKernelGGL((splitk_reduce8_kernel<EPI, T>), dim3(cdiv(g.M * (g.N / 8), 256)), dim3(256), 0, s, g.splitk_ws, S, g.M, g.M, g.N, g.ep);
+      WSEG_LAUNCH_CHECK();
+      return WSEG_OK;
+    }
+  }
   SkinnyPlan sp = plan_skinny(g, IsMx<T>::v);
   // (block-floating-point cross K / V: the row writer needs the lanes of a row side by side, which the 4-column MFMA-layout epilogue of
   // the stream kernels does not give — an un-split plan goes through the partial plane + reduction kernel as well)
@@ -2448,8 +2463,9 @@ bool gemm_out_is_mx(int dtype, int M, int N, int K, size_t splitk_ws_bytes) {
   g.M = M; g.N = N; g.K = 2 * K;
   if (big_tile_path(g)) return true;
   if (!splitk_ws_bytes || g.K % 128 || N % 64) return false;
-  g.splitk_ws = (float*)(uintptr_t)16;      // any non-null value: plan_skinny only asks whether a workspace exists and how large it is
+  g.splitk_ws = (float*)(uintptr_t)16;      // any non-null value: the plans only ask whether a workspace exists and how large it is
   g.splitk_ws_bytes = splitk_ws_bytes;
+  if (WSEG_MX_PP_SPLITK && pp_splitk_plan<M6>(g)) return true;
   return plan_skinny(g, true).splits > 1 && skinny_split_writes_mx(N);
 }
 
