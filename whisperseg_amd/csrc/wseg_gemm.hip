@@ -2389,8 +2389,14 @@ template <typename T> static int pp_splitk_plan(const GemmArgs& g) {
   static const int min_kt = WSEG_KNOB_INT("WSEG_PP_SPLITK_MIN_KT", 40);
   if (g.M < min_rows || g.N % 256 || g.K % 64 || g.K / 64 < min_kt || !g.splitk_ws) return 0;
   const int nt = cdiv(g.M, 256) * (g.N / 256), nk = g.K / 64, n_cu = device_cu_count();
+  static const int max_s = WSEG_KNOB_INT("WSEG_PP_SPLITK_MAX_S", 64), min_kt_per = WSEG_KNOB_INT("WSEG_PP_SPLITK_KT_PER", 4);
   int S = n_cu / nt;
-  while (S >= 2 && ((nt * S) % 8 || nk / S < 4 || (size_t)S * g.M * g.N * sizeof(float) > g.splitk_ws_bytes)) --S;
+  if (S > max_s) S = max_s;
+  while (S >= 2 && ((nt * S) % 8 || nk / S < min_kt_per || (size_t)S * g.M * g.N * sizeof(float) > g.splitk_ws_bytes)) --S;
+  // fewer than 96 workgroups of 5 K tiles each (d x d projections at 448-511 rows) lose to the stream family: 120 windows 8.9-9.1 -> 8.6 ms per
+  // decode step, 112 windows 8.73 -> 8.13 (profiles/r05_epilogue_ab.txt)
+  static const int min_wgs = WSEG_KNOB_INT("WSEG_PP_SPLITK_MIN_WGS", 96);
+  if (nt * S < min_wgs) return 0;
   return S >= 2 ? S : 0;
 }
 
