@@ -378,3 +378,24 @@ def test_prompt_pass_equals_stepping_through_the_prompt(gpu_lib, dtype, nb, monk
         assert torch.equal(res["step", slots][0], res["step", 23][0])
     assert res["pass", 23][2] == res["step", 23][2] - (len(TM.PROMPT) - 1)
     assert res["pass", 1][2] <= res["step", 1][2] - 23 * (len(TM.PROMPT) - 1) + 8
+
+
+@pytest.mark.parametrize("plen", [1, 2, 6, 8])
+def test_prompt_pass_with_other_prompt_lengths(gpu_lib, plen, monkeypatch):
+    """The C-ABI takes prompts of 1..8 tokens: the pass covers min(P - 1, 4) positions (none for P = 1), the rest of a longer prompt is
+    stepped through; same tokens as stepping through all of it."""
+    eng = tiny_engine("f16m6")
+    x = tiny_feats(7)
+    prompt = (TM.PROMPT + [TM.PROMPT[1], TM.PROMPT[2]] * 3)[:plen]
+
+    def run():
+        t, l = eng.generate(x, prompt, TM.EOT, TM.EOT, max_length=40, num_beams=4, suppress_tokens=TM.SUPPRESS,
+                            begin_suppress_tokens=TM.BEGIN_SUPPRESS, n_slots=3, refill_min=1)
+        return t.cpu(), l.cpu(), eng.last_stats()["n_steps"]
+
+    t1, l1, s1 = run()
+    monkeypatch.setenv("WSEG_NO_PROMPT_PASS", "1")
+    t2, l2, s2 = run()
+    assert torch.equal(t1, t2) and torch.equal(l1, l2)
+    assert s1 <= s2 if plen > 1 else s1 == s2
+    assert (t1[:, :plen] == torch.tensor(prompt)).all()
