@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
   // lane groups {0-3,12-15,20-27}, ... and needs 16 distinct (row & 1, slot) pairs per group — XOR (key & 7), right for
   // 16-row fragments, was 2-way conflicted here (SQ_LDS_BANK_CONFLICT 44 % of LDS cycles)
   __shared__ __attribute__((aligned(16))) HT sK[2][64 * 64];   // double-buffered: filled by LDS-DMA, no registers in between
-  __shared__ __attribute__((aligned(16))) HT sV[64 * 64];   // [hd][64 keys], 8-B granules XOR ((hd >> 1) & 15)
+  __shared__ __attribute__((aligned(16))) HT sV[64 * 64];   // [hd][64 keys], 8-B granules XOR (hd & 15) (WSEG_EA_VSWZ)
   __shared__ __attribute__((aligned(16))) HT sKl[SPLIT ? 2 : 1][SPLIT ? 64 * 64 : 8];      // lo planes (SPLIT)
   __shared__ __attribute__((aligned(16))) HT sVl[SPLIT ? 64 * 64 : 8];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -174,7 +174,11 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
   const int n_tiles = (T + 63) / 64;
   // per-lane byte offsets of the MFMA fragment reads (see the key-block loop)
   const unsigned kfrag = (unsigned)(qi * 128 + ((g2 ^ ((qi >> 1) & 7)) << 4));
-  const unsigned vfrag = (unsigned)(qi * 128 + ((g2 ^ ((qi >> 1) & 15)) << 3));
+#ifndef WSEG_EA_VSWZ
+#define WSEG_EA_VSWZ 1      // 1 (r05): V^T granules XOR (hd & 15), rows in natural order at the write — SQ_LDS_BANK_CONFLICT 2.1e7 -> 0 per launch (36 % of
+                            // the LDS cycles; 0 = XOR ((hd >> 1) & 15) of r02-r04, whose 16-lane ds_read_b64 groups hit every bank pair twice)
+#endif
+  const unsigned vfrag = (unsigned)(qi * 128 + ((g2 ^ (WSEG_EA_VSWZ ? (qi & 15) : ((qi >> 1) & 15))) << 3));
   // K tile and V^T tile (each 8 KiB = 512 16-byte chunks, 2 per thread; rows are padded to Tp, so a tile is always readable).
   // The NEXT tile is requested while the current one is multiplied: K by LDS-DMA straight into the other sK buffer (the
   // swizzle is applied on the source side: LDS slot c holds global slot (c & 7) ^ ((row >> 1) & 7) of its row), V^T into 8
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
   uint4 v0, v1, v0l, v1l;
   // V^T row of this thread's two chunks: rows 4j + {0, 2, 1, 3} for consecutive 8-lane groups, so that the two rows sharing a
   // 16-lane ds_write_b64 group have swizzles of different parity (rows 2k and 2k + 1 share theirs and collided 2-way)
-  const int vrow = ((tid >> 3) & ~3) | (((tid >> 3) & 1) << 1) | (((tid >> 3) >> 1) & 1);
+  const int vrow = WSEG_EA_VSWZ ? (tid >> 3) : (((tid >> 3) & ~3) | (((tid >> 3) & 1) << 1) | (((tid >> 3) >> 1) & 1));
   auto fetch = [&](int kt) {
     const HT* ksrc = Kb + (size_t)(kt * 64) * 64;
     HT* kdst = sK[kt & 1];
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
       const int r0 = vrow, sl = tid & 7;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int row = r0 + i * 32, sw = (row >> 1) & 15;
+        const int row = r0 + i * 32, sw = WSEG_EA_VSWZ ? (row & 15) : ((row >> 1) & 15);
         const uint4 vv = i == 0 ? v0 : v1;
         *(uint2*)(sV + row * 64 + (((2 * sl) ^ sw) << 2)) = make_uint2(vv.x, vv.y);
         *(uint2*)(sV + row * 64 + (((2 * sl + 1) ^ sw) << 2)) = make_uint2(vv.z, vv.w);
@@ -228,6 +232,108 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
     }
     __syncthreads();
     if (kt + 1 < n_tiles) fetch(kt + 1);                  // the other sK buffer was last read two barriers ago
+#ifndef WSEG_EA_PRIO
+#define WSEG_EA_PRIO 1
+#endif
+#ifndef WSEG_EA_JOINT
+#define WSEG_EA_JOINT 1
+#endif
+#if WSEG_EA_JOINT
+    // Both 32-key halves of the tile together (r05): two independent score accumulators (the 12 MFMAs of one half are a dependent chain on ONE
+    // accumulator: alternating halves lets the matrix pipe run back to back), one running maximum / rescale per 64 keys instead of per 32:
+    // 1 171 -> 1 127 us per 256-window launch together with the conflict-free V^T image (profiles/r05_encattn_ab.txt).  Measured and dropped:
+    // the second half's probabilities computed between the first half's P V MFMAs (1 350 us: VALU inside a wave's MFMA stretch stalls both), the
+    // exponent arguments / row sums on v_pk_fma_f32 / v_pk_add_f32 (1 143 us).
+    {
+      const int key_base = kt * 64;
+      f32x16 s0, s1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+      unsigned kfo = kfrag, vfo = vfrag;
+      asm volatile("" : "+v"(kfo), "+v"(vfo));
+      const char* cKs = (const char*)cK;
+      [[maybe_unused]] const char* cKls = (const char*)sKl[kt & 1];
+      if (WSEG_EA_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int hs = 0; hs < 4; ++hs) {
+        const bf16x8 kf0 = *(const bf16x8*)(cKs + (kfo ^ (hs << 5)));
+        const bf16x8 kf1 = *(const bf16x8*)(cKs + 4096 + (kfo ^ (hs << 5)));
+        s0 = H16<HT>::mfma32(kf0, qf[hs], s0);
+        s1 = H16<HT>::mfma32(kf1, qf[hs], s1);
+        if constexpr (SPLIT) {
+          const bf16x8 kfl0 = *(const bf16x8*)(cKls + (kfo ^ (hs << 5)));
+          const bf16x8 kfl1 = *(const bf16x8*)(cKls + 4096 + (kfo ^ (hs << 5)));
+          s0 = H16<HT>::mfma32(kf0, qfl[hs], s0);
+          s1 = H16<HT>::mfma32(kf1, qfl[hs], s1);
+          s0 = H16<HT>::mfma32(kfl0, qf[hs], s0);
+          s1 = H16<HT>::mfma32(kfl1, qf[hs], s1);
+        }
+      }
+      if (WSEG_EA_PRIO) __builtin_amdgcn_s_setprio(0);
+      if (key_base + 64 > T) {      // the ragged tile of a (window, head)
+        asm volatile("");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key_base + (r & 3) + 8 * (r >> 2) + 4 * g2;
+          if (key >= T) s0[r] = -1.0e30f;
+          if (key + 32 >= T) s1[r] = -1.0e30f;
+        }
+      }
+      float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s0[r]), s1[r]);      // v_max3_f32
+      mx = fmaxf(mx, lane_xor<32>(mx));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __expf(m_run - m_new);
+      float ps = 0.f;
+      const float m_l2 = -m_new * 1.4426950408889634f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], 1.4426950408889634f, m_l2));
+        s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], 1.4426950408889634f, m_l2));
+        ps += s0[r] + s1[r];
+      }
+      m_run = m_new;
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      }
+      if (WSEG_EA_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const f32x16& sv = sub == 0 ? s0 : s1;
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+          union { bf16x8 v; uint32_t u[4]; } pf, pfl;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) pf.u[jj] = H16<HT>::pack(sv[8 * mm + 2 * jj], sv[8 * mm + 2 * jj + 1]);
+          if constexpr (SPLIT) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+              pfl.u[jj] = H16<HT>::pack(H16<HT>::sub_lo(sv[8 * mm + 2 * jj], pf.u[jj]), H16<HT>::sub_hi(sv[8 * mm + 2 * jj + 1], pf.u[jj]));
+          }
+          const unsigned va = vfo ^ ((sub * 8 + 4 * mm) << 3), vb = vfo ^ ((sub * 8 + 4 * mm + 2) << 3);
+#pragma unroll
+          for (int ht = 0; ht < 2; ++ht) {
+            union { bf16x8 v; uint2 u[2]; } vf, vfl;
+            vf.u[0] = *(const uint2*)((const char*)sV + ht * 4096 + va);
+            vf.u[1] = *(const uint2*)((const char*)sV + ht * 4096 + vb);
+            if (ht == 0) o0 = H16<HT>::mfma32(vf.v, pf.v, o0);
+            else o1 = H16<HT>::mfma32(vf.v, pf.v, o1);
+            if constexpr (SPLIT) {
+              vfl.u[0] = *(const uint2*)((const char*)sVl + ht * 4096 + va);
+              vfl.u[1] = *(const uint2*)((const char*)sVl + ht * 4096 + vb);
+              if (ht == 0) { o0 = H16<HT>::mfma32(vf.v, pfl.v, o0); o0 = H16<HT>::mfma32(vfl.v, pf.v, o0); }
+              else { o1 = H16<HT>::mfma32(vf.v, pfl.v, o1); o1 = H16<HT>::mfma32(vfl.v, pf.v, o1); }
+            }
+          }
+        }
+      }
+      if (WSEG_EA_PRIO) __builtin_amdgcn_s_setprio(0);
+      ps += lane_xor<32>(ps);
+      l_run = l_run * alpha + ps;
+    }
+#else
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       const int key_base = kt * 64 + sub * 32;
@@ -245,9 +351,6 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
       asm volatile("" : "+v"(kfo), "+v"(vfo));
       const char* cKs = (const char*)cK + sub * 4096;
       [[maybe_unused]] const char* cKls = (const char*)sKl[kt & 1] + sub * 4096;
-#ifndef WSEG_EA_PRIO
-#define WSEG_EA_PRIO 1
-#endif
       // (three workgroups share a CU: a wave that has MFMAs to issue goes first — MI355X_MICROARCH.md, static priority — while its
       // neighbours' softmax VALU fills the slots between them)
       if (WSEG_EA_PRIO) __builtin_amdgcn_s_setprio(1);
@@ -262,7 +365,8 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
         }
       }
       if (WSEG_EA_PRIO) __builtin_amdgcn_s_setprio(0);
-      if (key_base + 32 > T) {
+      if (key_base + 32 > T) {      // the one ragged key block of a (window, head): a real branch — if-converted, its 16 key indices, compares and
+        asm volatile("");           // selects (55 VALU instructions) ran in every key block (r05, from the loop's instruction histogram)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = key_base + (r & 3) + 8 * (r >> 2) + 4 * g2;
@@ -320,6 +424,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
       }
       if (WSEG_EA_PRIO) __builtin_amdgcn_s_setprio(0);
     }
+#endif
   }
   const int q = q0 + qi;
   if constexpr (IsMx<TO>::v) {
