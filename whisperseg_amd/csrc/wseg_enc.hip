@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
   // lane groups {0-3,12-15,20-27}, ... and needs 16 distinct (row & 1, slot) pairs per group — XOR (key & 7), right for
   // 16-row fragments, was 2-way conflicted here (SQ_LDS_BANK_CONFLICT 44 % of LDS cycles)
   __shared__ __attribute__((aligned(16))) HT sK[2][64 * 64];   // double-buffered: filled by LDS-DMA, no registers in between
-  __shared__ __attribute__((aligned(16))) HT sV[64 * 64];   // [hd][64 keys], 8-B granules XOR (hd & 15) (WSEG_EA_VSWZ)
+  __shared__ __attribute__((aligned(16))) HT sV[64 * 64];   // [hd][64 keys] in 16-byte operand-order slots (WSEG_EA_VSWZ)
   __shared__ __attribute__((aligned(16))) HT sKl[SPLIT ? 2 : 1][SPLIT ? 64 * 64 : 8];      // lo planes (SPLIT)
   __shared__ __attribute__((aligned(16))) HT sVl[SPLIT ? 64 * 64 : 8];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -175,8 +175,11 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
   // per-lane byte offsets of the MFMA fragment reads (see the key-block loop)
   const unsigned kfrag = (unsigned)(qi * 128 + ((g2 ^ ((qi >> 1) & 7)) << 4));
 #ifndef WSEG_EA_VSWZ
-#define WSEG_EA_VSWZ 1      // 1 (r05): V^T granules XOR (hd & 15), rows in natural order at the write — SQ_LDS_BANK_CONFLICT 2.1e7 -> 0 per launch (36 % of
-                            // the LDS cycles; 0 = XOR ((hd >> 1) & 15) of r02-r04, whose 16-lane ds_read_b64 groups hit every bank pair twice)
+// LDS image of the V^T tile (r05; profiles/r05_encattn_ab.txt).  2: 16-byte slots in MFMA operand order, XOR ((hd >> 1) & 7) like the K tile — a
+// fragment is one ds_read_b128, no bank conflicts (1 169 -> 1 111 us per 256-window launch).  1: 8-byte granules XOR (hd & 15): conflict-free
+// (SQ_LDS_BANK_CONFLICT 2.1e7 -> 0 per launch) but two ds_read_b64 per fragment, which the compiler pairs across fragments (ds_read2_b64) and
+// re-sorts with ~50 v_mov per tile.  0: XOR ((hd >> 1) & 15), r02-r04: every 16-lane read group hit each bank pair twice.
+#define WSEG_EA_VSWZ 2
 #endif
   const unsigned vfrag = (unsigned)(qi * 128 + ((g2 ^ (WSEG_EA_VSWZ ? (qi & 15) : ((qi >> 1) & 15))) << 3));
   // K tile and V^T tile (each 8 KiB = 512 16-byte chunks, 2 per thread; rows are padded to Tp, so a tile is always readable).
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
   uint4 v0, v1, v0l, v1l;
   // V^T row of this thread's two chunks: rows 4j + {0, 2, 1, 3} for consecutive 8-lane groups, so that the two rows sharing a
   // 16-lane ds_write_b64 group have swizzles of different parity (rows 2k and 2k + 1 share theirs and collided 2-way)
-  const int vrow = WSEG_EA_VSWZ ? (tid >> 3) : (((tid >> 3) & ~3) | (((tid >> 3) & 1) << 1) | (((tid >> 3) >> 1) & 1));
+  const int vrow = WSEG_EA_VSWZ == 1 ? (tid >> 3) : (((tid >> 3) & ~3) | (((tid >> 3) & 1) << 1) | (((tid >> 3) >> 1) & 1));
   auto fetch = [&](int kt) {
     const HT* ksrc = Kb + (size_t)(kt * 64) * 64;
     HT* kdst = sK[kt & 1];
@@ -219,8 +222,24 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
       const int r0 = vrow, sl = tid & 7;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int row = r0 + i * 32, sw = WSEG_EA_VSWZ ? (row & 15) : ((row >> 1) & 15);
+        const int row = r0 + i * 32;
         const uint4 vv = i == 0 ? v0 : v1;
+#if WSEG_EA_VSWZ == 2
+        // 16-byte slots in MFMA operand order: slot 2 G + g2 of a row holds the 8 keys lane half g2 contracts for the 16-key group G —
+        // keys 16 G + 4 g2 + {0..3} | 16 G + 8 + 4 g2 + {0..3} — so a V^T fragment is ONE ds_read_b128 (it was two ds_read_b64 whose
+        // pairwise merging into ds_read2_b64 cost ~50 v_mov per tile to re-sort the halves); slots XOR ((row >> 1) & 7) like the K tile
+        const int sw = (row >> 1) & 7, G = sl >> 1, hf = sl & 1;
+        char* vrow_p = (char*)sV + row * 128 + hf * 8;
+        *(uint2*)(vrow_p + (((2 * G) ^ sw) << 4)) = make_uint2(vv.x, vv.y);
+        *(uint2*)(vrow_p + (((2 * G + 1) ^ sw) << 4)) = make_uint2(vv.z, vv.w);
+        if constexpr (SPLIT) {
+          const uint4 vl = i == 0 ? v0l : v1l;
+          char* vrowl_p = (char*)sVl + row * 128 + hf * 8;
+          *(uint2*)(vrowl_p + (((2 * G) ^ sw) << 4)) = make_uint2(vl.x, vl.y);
+          *(uint2*)(vrowl_p + (((2 * G + 1) ^ sw) << 4)) = make_uint2(vl.z, vl.w);
+        }
+#else
+        const int sw = WSEG_EA_VSWZ ? (row & 15) : ((row >> 1) & 15);
         *(uint2*)(sV + row * 64 + (((2 * sl) ^ sw) << 2)) = make_uint2(vv.x, vv.y);
         *(uint2*)(sV + row * 64 + (((2 * sl + 1) ^ sw) << 2)) = make_uint2(vv.z, vv.w);
         if constexpr (SPLIT) {
@@ -228,6 +247,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
           *(uint2*)(sVl + row * 64 + (((2 * sl) ^ sw) << 2)) = make_uint2(vl.x, vl.y);
           *(uint2*)(sVl + row * 64 + (((2 * sl + 1) ^ sw) << 2)) = make_uint2(vl.z, vl.w);
         }
+#endif
       }
     }
     __syncthreads();
@@ -238,6 +258,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
 #ifndef WSEG_EA_JOINT
 #define WSEG_EA_JOINT 1
 #endif
+    static_assert(WSEG_EA_JOINT == 1 || WSEG_EA_VSWZ != 2, "the operand-order V^T image is read by the joint key-half path only");
 #if WSEG_EA_JOINT
     // Both 32-key halves of the tile together (r05): two independent score accumulators (the 12 MFMAs of one half are a dependent chain on ONE
     // accumulator: alternating halves lets the matrix pipe run back to back), one running maximum / rescale per 64 keys instead of per 32:
@@ -287,12 +308,16 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
       const float alpha = __expf(m_run - m_new);
       float ps = 0.f;
       const float m_l2 = -m_new * 1.4426950408889634f;
+#if defined(WSEG_EA_TIMING) && WSEG_EA_TIMING == 1      // timing experiment (wrong results): no exponentials
+      ps = s0[0] + s1[5] + m_l2;
+#else
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], 1.4426950408889634f, m_l2));
         s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], 1.4426950408889634f, m_l2));
         ps += s0[r] + s1[r];
       }
+#endif
       m_run = m_new;
       if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
 #pragma unroll
@@ -312,17 +337,25 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
             for (int jj = 0; jj < 4; ++jj)
               pfl.u[jj] = H16<HT>::pack(H16<HT>::sub_lo(sv[8 * mm + 2 * jj], pf.u[jj]), H16<HT>::sub_hi(sv[8 * mm + 2 * jj + 1], pf.u[jj]));
           }
-          const unsigned va = vfo ^ ((sub * 8 + 4 * mm) << 3), vb = vfo ^ ((sub * 8 + 4 * mm + 2) << 3);
+          [[maybe_unused]] const unsigned va = vfo ^ ((sub * 8 + 4 * mm) << 3), vb = vfo ^ ((sub * 8 + 4 * mm + 2) << 3);
 #pragma unroll
           for (int ht = 0; ht < 2; ++ht) {
             union { bf16x8 v; uint2 u[2]; } vf, vfl;
+#if WSEG_EA_VSWZ == 2
+            vf.v = *(const bf16x8*)((const char*)sV + ht * 4096 + (kfo ^ ((sub * 2 + mm) << 5)));      // the K fragment's address form: group G = 2 sub + mm
+#else
             vf.u[0] = *(const uint2*)((const char*)sV + ht * 4096 + va);
             vf.u[1] = *(const uint2*)((const char*)sV + ht * 4096 + vb);
+#endif
             if (ht == 0) o0 = H16<HT>::mfma32(vf.v, pf.v, o0);
             else o1 = H16<HT>::mfma32(vf.v, pf.v, o1);
             if constexpr (SPLIT) {
+#if WSEG_EA_VSWZ == 2
+              vfl.v = *(const bf16x8*)((const char*)sVl + ht * 4096 + (kfo ^ ((sub * 2 + mm) << 5)));
+#else
               vfl.u[0] = *(const uint2*)((const char*)sVl + ht * 4096 + va);
               vfl.u[1] = *(const uint2*)((const char*)sVl + ht * 4096 + vb);
+#endif
               if (ht == 0) { o0 = H16<HT>::mfma32(vf.v, pfl.v, o0); o0 = H16<HT>::mfma32(vfl.v, pf.v, o0); }
               else { o1 = H16<HT>::mfma32(vf.v, pfl.v, o1); o1 = H16<HT>::mfma32(vfl.v, pf.v, o1); }
             }
