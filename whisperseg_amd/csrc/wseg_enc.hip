@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
     // accumulator: alternating halves lets the matrix pipe run back to back), one running maximum / rescale per 64 keys instead of per 32:
     // 1 171 -> 1 127 us per 256-window launch together with the conflict-free V^T image (profiles/r05_encattn_ab.txt).  Measured and dropped:
     // the second half's probabilities computed between the first half's P V MFMAs (1 350 us: VALU inside a wave's MFMA stretch stalls both), the
-    // exponent arguments / row sums on v_pk_fma_f32 / v_pk_add_f32 (1 143 us).
+    // exponent arguments / row sums on v_pk_fma_f32 / v_pk_add_f32 (1 143 us; the row sums alone on v_pk_add_f32: +1 %).
     {
       const int key_base = kt * 64;
       f32x16 s0, s1;
