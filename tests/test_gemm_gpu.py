@@ -139,7 +139,10 @@ def test_hi_only_gemm_is_the_half_product(gpu_lib, M, N, K):
 M6_SHAPES = [sh for sh in X3_SHAPES if sh[2] % 64 == 0] + [(128000, 1280, 1280), (25000, 2560, 5120), (4096, 1280, 5120), (4096, 5120, 1280),
                                                             # the 256x256 kernel's K loop is peeled into leading edge / middle / trailing edge (hi, MX) tile
                                                             # pairs: one pair (first and last at once), two, five
-                                                            (66000, 1280, 64), (8192, 2560, 128), (66000, 1280, 320)]
+                                                            (66000, 1280, 64), (8192, 2560, 128), (66000, 1280, 320),
+                                                            # r05: M6-row outputs below the large-tile threshold through split-K copies of the 256x256 kernel + the
+                                                            # M6-writing reduction (decoder fc1 at 112-270 slots); 480 rows: the >= 96-workgroup rule
+                                                            (1024, 5120, 1280), (480, 5120, 1280), (480, 1280, 1280), (900, 1280, 5120)]
 
 
 @pytest.mark.parametrize("M,N,K", M6_SHAPES)
