@@ -195,6 +195,9 @@ def test_two_layer_1024_windows_4096_rows(gpu_lib, two_layer):
         assert torch.equal(t2.cpu(), t) and torch.equal(l2.cpu(), l.cpu())
         small_t = torch.cat([gen(engines[dt], x[lo:lo + 256], 4, 8, n_slots=256)[0].cpu() for lo in range(0, 1024, 256)])
         assert torch.equal(small_t, t), dt        # the same tokens at 256 and at 1024 slots
+        # ... and at 512 slots (2 048 rows: r05 plans — fc1 on one 62 %-full round of 256x256 tiles, q|k|v as two split-K copies)
+        mid_t = torch.cat([gen(engines[dt], x[lo:lo + 512], 4, 8, n_slots=512)[0].cpu() for lo in range(0, 1024, 512)])
+        assert torch.equal(mid_t, t), dt
 
 
 @pytest.fixture(scope="module")

@@ -2154,7 +2154,11 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
     // (split / mixed modes: a K tile pair costs twice the bf16 K tile while the 128x128 kernel's fixed costs do not shrink — since the
     // r04 K-loop work the 256x256 kernel wins down to 3/5 of a last round: decoder fc1 at 4 096 rows, 320 tiles, 152 against 161 us)
     const bool ragged256 = quant_rule && rounds256 < 4 && nt256 * 5 < rounds256 * n_cu * (IO<T>::split ? 3 : 4);
-    if (big256 && g.N % 256 == 0 && nt256 >= 192 && !ragged256 && g.K >= 128) {      // (K = 64 words: one K tile, 128x128 kernel)
+    // (r05: 160 tiles for the GELU epilogue in the split / mixed modes — decoder fc1 at 2 048 rows, one round on 62 % of the CUs: 512 slots 21.3 ->
+    // 20.3 ms per decode step; NOT for the q|k|v epilogue: 180 tiles at 3 072 rows lose to two rounds of 128x128 tiles, 28.0 -> 29.0 ms)
+    static const int min_tiles256 = WSEG_KNOB_INT("WSEG_BIG256_MIN_TILES", 0);
+    const long need256 = min_tiles256 ? min_tiles256 : ((IO<T>::split && EPI == EPI_GELU) ? 160 : 192);
+    if (big256 && g.N % 256 == 0 && nt256 >= need256 && !ragged256 && g.K >= 128) {      // (K = 64 words: one K tile, 128x128 kernel)
       const int ntm = cdiv(g.M, 256), ntiles = ntm * (g.N / 256);
       constexpr bool pingpong = true;      // (r05: the generic / persistent kernels' 256x256 instantiations — knob-only paths that spilled 200-330 bytes per lane — are gone)
       // WSEG_F16M6, M6-row outputs, between one and two rounds of 256x256 tiles (decoder fc1 at 4 096 rows: 320 tiles on 256 CUs — the
@@ -2342,10 +2346,14 @@ static int launch_any(int dtype, const GemmArgs& g, hipStream_t s) {
 template <typename T>
 static int gemm_partial_t(const GemmArgs& g0, PartialInfo* info, bool* ok, hipStream_t s) {
   const GemmArgs g = kernel_view<T>(g0);
-  if (big_tile_path(g) || !g.splitk_ws || g.K % 64 || g.N % 64) return WSEG_OK;
 #ifndef WSEG_PARTIAL_PP
 #define WSEG_PARTIAL_PP 1
 #endif
+  static const bool partial_big = !WSEG_KNOB_SET("WSEG_NO_PARTIAL_BIG");
+  // (r05: also ABOVE the large-tile threshold when the 256x256 tiles fill at most half the chip — decoder q|k|v at 2 048 rows, 120 tiles: two split-K
+  // copies + the reduction inside the attention kernel instead of the 128x128 kernel with its own epilogue)
+  if (!g.splitk_ws || g.K % 64 || g.N % 64) return WSEG_OK;
+  if (big_tile_path(g) && !(WSEG_PARTIAL_PP && partial_big && pp_splitk_plan<T>(g) >= 2)) return WSEG_OK;
   if (WSEG_PARTIAL_PP) {      // thousands of rows, too few 256x256 tiles for the chip (the decode step's cross-attention query): the split-K copies
     const int S = pp_splitk_plan<T>(g);      // of the ping-pong kernel leave the same fp32 planes [z][M][N] as the stream family
     if (S) {
