@@ -376,14 +376,23 @@ def test_prompt_pass_equals_stepping_through_the_prompt(gpu_lib, dtype, nb, monk
     for slots in (23, 5, 1):
         assert torch.equal(res["pass", slots][0], res["step", 23][0]) and torch.equal(res["pass", slots][1], res["step", 23][1]), slots
         assert torch.equal(res["step", slots][0], res["step", 23][0])
-    assert res["pass", 23][2] == res["step", 23][2] - (len(TM.PROMPT) - 1)
-    assert res["pass", 1][2] <= res["step", 1][2] - 23 * (len(TM.PROMPT) - 1) + 8
+    # the pass also runs the first generated step (one row per window: the beams are still copies): P fewer steps
+    assert res["pass", 23][2] == res["step", 23][2] - len(TM.PROMPT)
+    assert res["pass", 1][2] <= res["step", 1][2] - 23 * len(TM.PROMPT) + 8
+    # ... and without that merge (test knob): P - 1 fewer, same tokens
+    monkeypatch.delenv("WSEG_NO_PROMPT_PASS")
+    monkeypatch.setenv("WSEG_NO_FIRST_STEP_MERGE", "1")
+    for slots, refill in ((23, 0), (5, 1)):
+        t, l = gen(eng, x, nb, n_slots=slots, refill_min=refill)
+        assert torch.equal(t, res["step", 23][0]) and torch.equal(l, res["step", 23][1]), slots
+        if slots == 23:
+            assert eng.last_stats()["n_steps"] == res["step", 23][2] - (len(TM.PROMPT) - 1)
 
 
 @pytest.mark.parametrize("plen", [1, 2, 6, 8])
 def test_prompt_pass_with_other_prompt_lengths(gpu_lib, plen, monkeypatch):
-    """The C-ABI takes prompts of 1..8 tokens: the pass covers min(P - 1, 4) positions (none for P = 1), the rest of a longer prompt is
-    stepped through; same tokens as stepping through all of it."""
+    """The C-ABI takes prompts of 1..8 tokens: P <= 4: the pass covers the whole prompt and the first generated step; longer prompts: the
+    first 4 positions, the rest is stepped through; same tokens as stepping through all of it."""
     eng = tiny_engine("f16m6")
     x = tiny_feats(7)
     prompt = (TM.PROMPT + [TM.PROMPT[1], TM.PROMPT[2]] * 3)[:plen]
@@ -397,5 +406,5 @@ def test_prompt_pass_with_other_prompt_lengths(gpu_lib, plen, monkeypatch):
     monkeypatch.setenv("WSEG_NO_PROMPT_PASS", "1")
     t2, l2, s2 = run()
     assert torch.equal(t1, t2) and torch.equal(l1, l2)
-    assert s1 <= s2 if plen > 1 else s1 == s2
+    assert s1 < s2 if plen <= 4 else s1 <= s2      # P <= 4: the pass also runs the first generated step
     assert (t1[:, :plen] == torch.tensor(prompt)).all()

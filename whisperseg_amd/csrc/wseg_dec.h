@@ -45,7 +45,9 @@ struct DecodeState {
 int launch_decode_reset(const DecodeState& st, hipStream_t s);
 // slots[i] starts decoding window wins[i] at position pf_np (device arrays of n entries); pf_np > 0: the prompt positions before it
 // were run by the prompt pass (launch_prompt_*), every beam's ancestry of them points at beam 0's cache rows
-int launch_decode_admit(const DecodeState& st, const int* slots, const int* wins, int n, int pf_np, hipStream_t s);
+// pos0 <= pf_np: the position the slot's state is left at (pf_np == P, pos0 == P - 1: the prompt pass also runs position P - 1 and the
+// admission finishes the first generated step itself — launch_row_topk / launch_beam_step on the admitted list)
+int launch_decode_admit(const DecodeState& st, const int* slots, const int* wins, int n, int pf_np, int pos0, hipStream_t s);
 // Prompt pass (split-precision modes): the first np <= 4 forced prompt positions of n admitted windows as ONE pass of n * np rows
 // (row i * np + pp) instead of np decode steps of every slot — the cross-attention K / V of a window are streamed once for them.
 // x[row][:] = tok_emb[prompt[pp]][:] + pos_emb[pp][:]
@@ -77,9 +79,12 @@ int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const
 bool dec_cross_attn_writes_mx(int dtype, int nb);
 // log-softmax + suppress + running score -> top-2nb per row (beam) / argmax of the processed logits (greedy)
 // scratch: part_val/part_idx [R][16][16], part_stat [R][16][2]
-int launch_row_topk(const DecodeState& st, const float* logits, float* part_val, int* part_idx, float* part_stat, hipStream_t s);
-int launch_beam_step(const DecodeState& st, hipStream_t s);
-int launch_greedy_step(const DecodeState& st, hipStream_t s);
+// list != nullptr: only the n_list slots named there (device array), logits row i = the ONE row of window list[i] (first generated step of
+// newly admitted windows: their beams are copies)
+int launch_row_topk(const DecodeState& st, const float* logits, float* part_val, int* part_idx, float* part_stat, hipStream_t s,
+                    const int* list = nullptr, int n_list = 0);
+int launch_beam_step(const DecodeState& st, hipStream_t s, const int* list = nullptr, int n_list = 0);
+int launch_greedy_step(const DecodeState& st, hipStream_t s, const int* list = nullptr, int n_list = 0);
 // retire: best sequence of slots[i] -> out_tokens[win[slots[i]]][:], out_lengths[win[slots[i]]]
 int launch_finalize(const DecodeState& st, const int* slots, int n, int* out_tokens, int* out_lengths, hipStream_t s);
 

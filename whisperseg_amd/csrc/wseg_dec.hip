@@ -29,7 +29,7 @@ __global__ void decode_reset_kernel(DecodeState st) {
 
 // One workgroup per admitted slot: fresh sequences / scores / ancestry, not done; position pf_np (the prompt positions before it were
 // run by the admission pass, run_prompt_pass: their K / V are beam 0's cache rows for every beam).
-__global__ __launch_bounds__(256) void decode_admit_kernel(DecodeState st, const int* __restrict__ slots, const int* __restrict__ wins, int pf_np) {
+__global__ __launch_bounds__(256) void decode_admit_kernel(DecodeState st, const int* __restrict__ slots, const int* __restrict__ wins, int pf_np, int pos0) {
   const int w = slots[blockIdx.x];
   const int nb = st.nb, L = st.L;
   for (int i = threadIdx.x; i < nb * L; i += 256) {
@@ -45,13 +45,13 @@ __global__ __launch_bounds__(256) void decode_admit_kernel(DecodeState st, const
     st.fin_score[i] = -1.0e9f;
     st.fin_flag[i] = 0;
     st.fin_len[i] = 0;
-    st.tokens_in[i] = st.prompt[pf_np];
+    st.tokens_in[i] = st.prompt[pos0];
   }
   if (threadIdx.x == 0) {
     const int win = wins[blockIdx.x];
     int cap = st.max_length;
     if (st.win_max_length) cap = max(st.P + 1, min(cap, st.win_max_length[win]));
-    st.unsat[w] = 1; st.pos[w] = pf_np; st.win[w] = win; st.wmax[w] = cap; st.done[w] = 0;
+    st.unsat[w] = 1; st.pos[w] = pos0; st.win[w] = win; st.wmax[w] = cap; st.done[w] = 0;
   }
 }
 
@@ -1059,21 +1059,25 @@ __device__ __forceinline__ bool better(float av, int ai, float bv, int bi) { ret
 // log_softmax is a per-row shift, so ranking raw logits == ranking log-probs; the shift is applied to the
 // few surviving candidates in stage 2.
 template <int KC>
+// list != nullptr (the first generated step of newly admitted windows, run by the admission): grid.y = n_list * nb, state row r = the row of
+// beam j of slot list[i], logits row i (one row per window: its beams are copies at that step)
 __global__ __launch_bounds__(256) void row_topk_partial_kernel(DecodeState st, const float* __restrict__ logits, int nseg,
                                                                float* __restrict__ part_val, int* __restrict__ part_idx,
-                                                               float* __restrict__ part_stat) {
+                                                               float* __restrict__ part_stat, const int* __restrict__ list) {
   __shared__ float s_red[4];
   __shared__ float s_thr[4];
   __shared__ float s_bv[4];
   __shared__ int s_bi[4];
   __shared__ int s_bt[4];
   __shared__ int s_winner;
-  const int seg = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int r = blockIdx.y, xr = r;
+  if (list) { xr = r / st.nb; r = list[xr] * st.nb + (r - xr * st.nb); }
   if (st.done[r / st.nb]) return;
   const int V = st.V;
   const int per = (V + nseg - 1) / nseg;
   const int lo = seg * per, hi = min(V, lo + per);
-  const float* x = logits + (size_t)r * st.ldv;
+  const float* x = logits + (size_t)xr * st.ldv;
   const int cur_len = st.pos[r / st.nb] + 1;
   const unsigned char bits = 1 | ((cur_len == st.P) ? 2 : 0);
   // the slice as [lo, a4) scalar head, [a4, b4) 16-byte groups (rows are 16-byte aligned: ldv % 4 == 0), [b4, hi) tail:
@@ -1176,8 +1180,11 @@ __global__ __launch_bounds__(256) void row_topk_partial_kernel(DecodeState st, c
 // log_softmax(x) (+ -inf for suppressed ids) + running beam score — HF generation/utils.py:3374-3395.
 template <int KC>
 __global__ __launch_bounds__(64) void row_topk_merge_kernel(DecodeState st, int nseg, const float* __restrict__ part_val,
-                                                            const int* __restrict__ part_idx, const float* __restrict__ part_stat) {
-  const int r = blockIdx.x, lane = threadIdx.x;
+                                                            const int* __restrict__ part_idx, const float* __restrict__ part_stat,
+                                                            const int* __restrict__ list) {
+  const int lane = threadIdx.x;
+  int r = blockIdx.x;
+  if (list) { const int i = r / st.nb; r = list[i] * st.nb + (r - i * st.nb); }
   if (st.done[r / st.nb]) return;
   const bool greedy = st.nb == 1;
   const int Kc = greedy ? st.top_k : 2 * st.nb;          // greedy: 1 candidate; sampling: top_k raw logits
@@ -1223,7 +1230,7 @@ __global__ __launch_bounds__(64) void row_topk_merge_kernel(DecodeState st, int 
 // ------------------------------------------------------------------------------------------------
 // Beam bookkeeping: one 64-lane workgroup per window (lane 0 decides, all lanes move sequences).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void beam_step_kernel(DecodeState st) {
+__global__ __launch_bounds__(64) void beam_step_kernel(DecodeState st, const int* __restrict__ list) {
   __shared__ float c_val[MAX_CAND];
   __shared__ int c_beam[MAX_CAND], c_tok[MAX_CAND], c_hit[MAX_CAND];
   __shared__ float run_val[MAX_CAND], fin_cand[MAX_CAND];
@@ -1231,7 +1238,7 @@ __global__ __launch_bounds__(64) void beam_step_kernel(DecodeState st) {
   __shared__ float n_run_score[MAX_BEAMS], n_fin_score[MAX_BEAMS];
   __shared__ int n_fin_flag[MAX_BEAMS], n_fin_len[MAX_BEAMS];
   __shared__ int head[MAX_BEAMS];
-  const int w = blockIdx.x, lane = threadIdx.x;
+  const int w = list ? list[blockIdx.x] : blockIdx.x, lane = threadIdx.x;
   if (st.done[w]) return;               // idle slot
   const int nb = st.nb, Kc = 2 * nb, L = st.L, P = st.P;
   const int pos = st.pos[w];
@@ -1337,8 +1344,9 @@ __global__ __launch_bounds__(64) void beam_step_kernel(DecodeState st) {
   }
 }
 
-__global__ void greedy_step_kernel(DecodeState st) {
-  const int w = blockIdx.x * 64 + threadIdx.x;
+__global__ void greedy_step_kernel(DecodeState st, const int* __restrict__ list, int n_list) {
+  int w = blockIdx.x * 64 + threadIdx.x;
+  if (list) { if (w >= n_list) return; w = list[w]; }
   if (w >= st.W || st.done[w]) return;
   const int L = st.L;
   const int pos = st.pos[w];
@@ -1401,10 +1409,10 @@ int launch_decode_reset(const DecodeState& st, hipStream_t s) {
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
-int launch_decode_admit(const DecodeState& st, const int* slots, const int* wins, int n, int pf_np, hipStream_t s) {
+int launch_decode_admit(const DecodeState& st, const int* slots, const int* wins, int n, int pf_np, int pos0, hipStream_t s) {
   if (n <= 0) return WSEG_OK;
-  if (pf_np < 0 || pf_np >= st.P) { set_error("admission: %d prompt positions prefilled of %d", pf_np, st.P); return WSEG_ERR_INVALID; }
-  hipLaunchKernelGGL(decode_admit_kernel, dim3(n), dim3(256), 0, s, st, slots, wins, pf_np);
+  if (pf_np < 0 || pf_np > st.P || pos0 < 0 || pos0 >= st.P || pos0 > pf_np) { set_error("admission: %d prompt positions prefilled of %d, start %d", pf_np, st.P, pos0); return WSEG_ERR_INVALID; }
+  hipLaunchKernelGGL(decode_admit_kernel, dim3(n), dim3(256), 0, s, st, slots, wins, pf_np, pos0);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
@@ -1552,27 +1560,31 @@ int row_topk_segments(int R) {
   return nseg < 1 ? 1 : (nseg > 16 ? 16 : nseg);
 }
 template <int KC>
-static void launch_topk_t(const DecodeState& st, const float* logits, float* pv, int* pi, float* ps, hipStream_t s) {
-  const int R = st.W * st.nb, nseg = row_topk_segments(R);
-  hipLaunchKernelGGL((row_topk_partial_kernel<KC>), dim3(nseg, R), dim3(256), 0, s, st, logits, nseg, pv, pi, ps);
-  hipLaunchKernelGGL((row_topk_merge_kernel<KC>), dim3(R), dim3(64), 0, s, st, nseg, pv, pi, ps);
+static void launch_topk_t(const DecodeState& st, const float* logits, float* pv, int* pi, float* ps, hipStream_t s, const int* list, int n_list) {
+  const int R = (list ? n_list : st.W) * st.nb, nseg = row_topk_segments(R);
+  hipLaunchKernelGGL((row_topk_partial_kernel<KC>), dim3(nseg, R), dim3(256), 0, s, st, logits, nseg, pv, pi, ps, list);
+  hipLaunchKernelGGL((row_topk_merge_kernel<KC>), dim3(R), dim3(64), 0, s, st, nseg, pv, pi, ps, list);
 }
-int launch_row_topk(const DecodeState& st, const float* logits, float* part_val, int* part_idx, float* part_stat, hipStream_t s) {
+int launch_row_topk(const DecodeState& st, const float* logits, float* part_val, int* part_idx, float* part_stat, hipStream_t s,
+                    const int* list, int n_list) {
+  if (list && n_list <= 0) return WSEG_OK;
   const int Kc = st.nb == 1 ? st.top_k : 2 * st.nb;
-  if (Kc == 1) launch_topk_t<1>(st, logits, part_val, part_idx, part_stat, s);
-  else if (Kc <= 4) launch_topk_t<4>(st, logits, part_val, part_idx, part_stat, s);
-  else if (Kc <= 8) launch_topk_t<8>(st, logits, part_val, part_idx, part_stat, s);
-  else launch_topk_t<16>(st, logits, part_val, part_idx, part_stat, s);
+  if (Kc == 1) launch_topk_t<1>(st, logits, part_val, part_idx, part_stat, s, list, n_list);
+  else if (Kc <= 4) launch_topk_t<4>(st, logits, part_val, part_idx, part_stat, s, list, n_list);
+  else if (Kc <= 8) launch_topk_t<8>(st, logits, part_val, part_idx, part_stat, s, list, n_list);
+  else launch_topk_t<16>(st, logits, part_val, part_idx, part_stat, s, list, n_list);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
-int launch_beam_step(const DecodeState& st, hipStream_t s) {
-  hipLaunchKernelGGL(beam_step_kernel, dim3(st.W), dim3(64), 0, s, st);
+int launch_beam_step(const DecodeState& st, hipStream_t s, const int* list, int n_list) {
+  if (list && n_list <= 0) return WSEG_OK;
+  hipLaunchKernelGGL(beam_step_kernel, dim3(list ? n_list : st.W), dim3(64), 0, s, st, list);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }
-int launch_greedy_step(const DecodeState& st, hipStream_t s) {
-  hipLaunchKernelGGL(greedy_step_kernel, dim3(cdiv(st.W, 64)), dim3(64), 0, s, st);
+int launch_greedy_step(const DecodeState& st, hipStream_t s, const int* list, int n_list) {
+  if (list && n_list <= 0) return WSEG_OK;
+  hipLaunchKernelGGL(greedy_step_kernel, dim3(cdiv(list ? n_list : st.W, 64)), dim3(64), 0, s, st, list, n_list);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
 }

@@ -301,7 +301,7 @@ int run_encoder(wseg_model* m, const float* feats, int W, Plan& p, void* enc_out
 // The forced prompt positions 0 .. np - 1 of n windows admitted together (device list `slots`), as one pass of n * np rows through the
 // decoder layers instead of np steps of every slot: the decoder weights and the windows' cross-attention K / V are read once for them
 // (split-precision modes, up to 4 beams; the admission kernel then starts the slots at position np).
-struct PromptPass { const int* slots; int n, np; };
+struct PromptPass { const int* slots; int n, np; bool logits; };      // logits: + the LM head on the LAST position's rows -> p.logits [n][vp]
 
 // One decoder step for all R rows at position *st.pos (want_logits: final LN + LM head), or the prompt pass `pp` of newly admitted windows
 // (row i * np + j = window i at position j; no logits: the next token is forced).
@@ -392,6 +392,11 @@ int run_decoder_step(wseg_model* m, DecPlan& p, char* mxa, bool want_logits, hip
     e = EpiParams();
     e.out_f32 = (float*)p.logits; e.ldc = m->vp;
     WSEG_TRY(gemm(m, EPI_F32, p.dy, d, m->dec_tok, d, R, m->vp, d, e, nullptr, s));
+  }
+  if (pp && pp->logits) {      // rows i * np + (np - 1) of the final LayerNorm: row stride np operand rows (es bytes per logical element)
+    e = EpiParams();
+    e.out_f32 = (float*)p.logits; e.ldc = m->vp;
+    WSEG_TRY(gemm(m, EPI_F32, p.dy + (size_t)(pp->np - 1) * d * m->es, pp->np * d, m->dec_tok, d, pp->n, m->vp, d, e, nullptr, s));
   }
   return WSEG_OK;
 }
@@ -620,7 +625,15 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
   // prompt pass: the first NPF forced positions of every admission run as one pass (run_decoder_step, PromptPass) and the slots start
   // at position NPF.  Split-precision modes up to 4 beams (24-bit / block-floating-point cross K / V); the f32 and plain 16-bit modes step through the prompt.
   const bool prompt_pass = getenv("WSEG_NO_PROMPT_PASS") == nullptr;      // test knob (read per call): step through the prompt instead
-  const int NPF = (prompt_pass && m->x3 && kv24 != 0) ? std::min(P - 1, 4) : 0;
+  // ... and when the whole prompt fits the pass (P <= 4) and a step follows anyway (L >= P + 2), the pass also runs position P - 1 — the FIRST
+  // GENERATED step, whose beams are still copies: one row per window through the layers and the LM head instead of a full decode step of every
+  // beam row (which would stream the windows' cross K / V once more) — and the admission finishes that step's bookkeeping for its slots
+  // (candidates from the window's one logits row, beam / greedy step on the admitted list).  NPF: positions the pass covers; POS0: the
+  // position the slot is at when the decode loop first steps it.
+  const bool pass_ok = prompt_pass && m->x3 && kv24 != 0;
+  const bool merged = pass_ok && P <= 4 && L >= P + 2 && getenv("WSEG_NO_FIRST_STEP_MERGE") == nullptr;
+  const int NPF = !pass_ok ? 0 : (merged ? P : std::min(P - 1, 4));
+  const int POS0 = merged ? P : NPF;
   const size_t cross_stride = (size_t)S * H * Tk * cross_kv_row_bytes(kv24, m->es);
   const size_t feat_stride = (size_t)c.n_mels * c.spec_cols;
   const int npg = st.npg;
@@ -637,6 +650,7 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
   int in_flight = 0, t = 0, units_in_use = 0;
   bool hold_admission = false;                         // set by a preemption, cleared by the next retirement
   bool first_admission = true;
+  bool snap_ok = false;                                // did every window of the call start together (first-logits snapshot)?
   m->first_logits_valid = false;
 
   // encoder + cross-K/V of the consecutive windows [w0, w0 + n) into the slots listed at q.adm_slots + off (device)
@@ -684,7 +698,7 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
       WSEG_TRY(encode_run(tmp_b[i], j - i, i));
       i = j;
     }
-    WSEG_TRY(launch_decode_admit(st, q.adm_slots, q.adm_wins, n, NPF, s));
+    WSEG_TRY(launch_decode_admit(st, q.adm_slots, q.adm_wins, n, NPF, merged ? P - 1 : NPF, s));
     if (NPF > 0) {
       // the first page of every admitted slot now (the refill rule left a pool unit for each), then the prompt pass in chunks that fit
       // the decode step's row buffers
@@ -702,8 +716,20 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
       WSEG_TRY(launch_kv_assign(q.kv_pt, q.kv_pairs, n, s));
       const int chunk = q.row_cap / NPF;
       for (int c0 = 0; c0 < n; c0 += chunk) {
-        const PromptPass pp = {q.adm_slots + c0, std::min(chunk, n - c0), NPF};
+        const int nc = std::min(chunk, n - c0);
+        const PromptPass pp = {q.adm_slots + c0, nc, NPF, merged};
         WSEG_TRY(run_decoder_step(m, q, p.mxa, false, s, &pp));
+        if (merged) {
+          if (snap_ok) {      // wseg_debug_first_logits (all windows of the call start together: window i sits in slot i): every beam row of
+            for (int j = 0; j < nb; ++j)      // a window gets the window's row
+              WSEG_HIP_CHECK(hipMemcpy2DAsync(q.first_logits + ((size_t)c0 * nb + j) * m->vp * 4, (size_t)nb * m->vp * 4, q.logits, (size_t)m->vp * 4,
+                                              (size_t)m->vp * 4, (size_t)nc, hipMemcpyDeviceToDevice, s));
+            if (c0 + nc == n) m->first_logits_valid = true;
+          }
+          WSEG_TRY(launch_row_topk(st, (const float*)q.logits, (float*)q.tk_val, (int*)q.tk_idx, (float*)q.tk_stat, s, q.adm_slots + c0, nc));
+          if (nb == 1) WSEG_TRY(launch_greedy_step(st, s, q.adm_slots + c0, nc));
+          else WSEG_TRY(launch_beam_step(st, s, q.adm_slots + c0, nc));
+        }
       }
     }
     in_flight += n;
@@ -732,7 +758,7 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
     tmp_a.clear();
     for (int sl = 0; sl < S; ++sl) {
       if (slot_win[sl] < 0) continue;
-      const int pos = t - slot_from[sl] + NPF;
+      const int pos = t - slot_from[sl] + POS0;
       if (pos >= L || pos % KV_PAGE) continue;
       while (free_units.empty()) {
         int victim = -1;                                // youngest slot that holds pages (never the requester)
@@ -778,11 +804,10 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
     put(&st.P, 4); put(&st.eos, 4); put(&st.pad, 4); put(&st.length_penalty, 4); put(st.prompt, sizeof(st.prompt));
     put(&st.top_k, 4); put(&st.top_p, 4);
   }
-  bool snap_ok = false;                          // did every window of the call start together (first-logits snapshot)?
   auto launch_step = [&]() -> int {
     // the first generated step of a call whose windows all start together is launched eagerly with the logits snapshot
     // (wseg_debug_first_logits); every other step replays the graph
-    const bool snap = t == P - 1 - NPF && snap_ok && stats.n_preemptions == 0;
+    const bool snap = !merged && t == P - 1 - POS0 && snap_ok && stats.n_preemptions == 0;
     if (snap) m->first_logits_valid = true;
     if (snap || !use_graph) return enqueue_step(snap, s);
     if (!ln.step_graph || ln.step_graph_key != key) {
@@ -860,8 +885,8 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
       break;
     }
     if (drained) {                // nothing left to admit later: stop launching once every window in flight must have ended
-      bool may_run = false;       // (a window admitted before step f feeds its last position, L - 2, at step f + L - 2 - NPF)
-      for (int sl = 0; sl < S && !may_run; ++sl) may_run = slot_win[sl] >= 0 && t < slot_from[sl] + L - 1 - NPF;
+      bool may_run = false;       // (a window admitted before step f feeds its last position, L - 2, at step f + L - 2 - POS0)
+      for (int sl = 0; sl < S && !may_run; ++sl) may_run = slot_win[sl] >= 0 && t < slot_from[sl] + L - 1 - POS0;
       if (!may_run) break;
     }
     WSEG_TRY(assign_pages());
