@@ -408,3 +408,25 @@ def test_prompt_pass_with_other_prompt_lengths(gpu_lib, plen, monkeypatch):
     assert torch.equal(t1, t2) and torch.equal(l1, l2)
     assert s1 < s2 if plen <= 4 else s1 <= s2      # P <= 4: the pass also runs the first generated step
     assert (t1[:, :plen] == torch.tensor(prompt)).all()
+
+
+@pytest.mark.parametrize("nb", [1, 4])
+def test_first_step_in_the_pass_with_windows_that_end_there(gpu_lib, nb, monkeypatch):
+    """Per-window caps of P + 1 .. P + 3: some windows are finished by the first generated step, which the admission's pass runs itself
+    (one row per window) — they must retire with exactly that one token, refills included; same tokens as stepping through everything,
+    also when the call's max_length leaves no step after the first (the merge is then off by construction)."""
+    eng = tiny_engine("f16m6")
+    x = tiny_feats(17)
+    P = len(TM.PROMPT)
+    caps = [P + 1 + (i % 3) for i in range(17)]
+    res = {}
+    for mode in ("merged", "step"):
+        if mode == "step":
+            monkeypatch.setenv("WSEG_NO_PROMPT_PASS", "1")
+        for slots in (17, 4):
+            res[mode, slots] = gen(eng, x, nb, 40, window_max_length=caps, n_slots=slots, refill_min=1)
+        res[mode, "short"] = gen(eng, x, nb, P + 1, n_slots=6)      # max_length = P + 1: one generated token per window
+    for key in ((17), (4), ("short")):
+        assert torch.equal(res["merged", key][0], res["step", key][0]) and torch.equal(res["merged", key][1], res["step", key][1]), key
+    assert all(int(v) <= c for v, c in zip(res["merged", 17][1].tolist(), caps))
+    assert (res["merged", "short"][1] == P + 1).all()
