@@ -237,9 +237,7 @@ int wseg_last_timing(const wseg_model* m, float out[4]);
 /* Test / tuning tap: out[M][N] = epilogue(A[M][K] * W[N][K]^T + bias) with the library's GEMM of the given dtype.
  * epi: 0 store, 1 GELU, 2 residual add (resid[M][N] and out are the fp32 residual stream in every dtype).  A must have
  * round_up(M,256) readable rows, N % 128 == 0,
- * K % 64 == 0.  epi | 0x100 (WSEG_F16M6, epi 2): the hi-only experiment — the 256x256 kernel multiplies the IEEE-half hi parts
- * of the M6 rows alone (measured and NOT used by the model: DESIGN.md).  Used by tests/test_gemm_gpu.py (parity vs torch) and
- * tools/gemm_bench.py. */
+ * K % 64 == 0.  Used by tests/test_gemm_gpu.py (parity vs torch / fp64) and tools/gemm_bench.py. */
 int wseg_debug_gemm(int32_t dtype, int32_t epi, int32_t M, int32_t N, int32_t K, const void* A, const void* W,
                     const void* bias, const void* resid, void* out, void* splitk_ws, size_t splitk_ws_bytes, void* stream);
 

@@ -91,51 +91,6 @@ def test_split_precision_gemm_matches_fp64(gpu_lib, M, N, K, epi, dtype):
     assert worst <= tol * scale, (worst, scale)
 
 
-@pytest.mark.parametrize("M,N,K", [(128000, 1280, 1280), (49999, 1024, 640), (4096, 1280, 1280)])
-def test_hi_only_gemm_is_the_half_product(gpu_lib, M, N, K):
-    """WSEG_F16M6 hi-only experiment (GemmArgs::hi_only; wseg_debug_gemm epi | 0x100; NOT used by the model — DESIGN.md §8): the
-    256x256 kernel steps over the MX tiles of the M6 rows and multiplies the IEEE-half hi parts alone.  Against the fp64 product of
-    the operands ROUNDED to IEEE half only fp32 accumulation order is left; on weight rows whose MX blocks are zero the full M6
-    kernel gives the same bits (an MX tile of zero codes adds +0).  Shapes the large-tile kernel does not take (the last one) keep
-    the full M6 product: the flag is a permission."""
-    from whisperseg_amd import _lib
-    from whisperseg_amd.engine import split_operand
-    g = torch.Generator(device="cuda").manual_seed(M + N + K)
-    Mp = (M + 255) // 256 * 256
-    A = torch.rand(Mp, K, device="cuda", generator=g) * 2 - 1
-    W = (torch.rand(N, K, device="cuda", generator=g) * 2 - 1) * K ** -0.5
-    bias = torch.rand(N, device="cuda", generator=g) - 0.5
-    res = torch.rand(Mp, N, device="cuda", generator=g) - 0.5
-    As, Ws = split_operand(A, torch.float16), split_operand(W, torch.float16)
-    Am, Wm = torch.empty_like(As), torch.empty_like(Ws)
-    _lib.check(gpu_lib.wseg_convert_operand(As.data_ptr(), Am.data_ptr(), Mp, K, 0, _lib.stream_ptr()))
-    _lib.check(gpu_lib.wseg_convert_operand(Ws.data_ptr(), Wm.data_ptr(), N, K, 1, _lib.stream_ptr()))
-    Wz = Wm.clone()
-    Wz.view(N, K // 64, 128)[:, :, 64:] = 0                     # the MX half of every 256-byte block
-    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
-
-    def run(epi, Wrows):
-        out = torch.full((Mp, N), float("nan"), device="cuda")
-        _lib.check(gpu_lib.wseg_debug_gemm(5, epi, M, N, K, Am.data_ptr(), Wrows.data_ptr(), bias.data_ptr(), res.data_ptr(), out.data_ptr(),
-                                           ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
-        torch.cuda.synchronize()
-        return out
-    out = run(2 | 0x100, Wm)
-    assert torch.isnan(out[M:]).all() or M == Mp
-    large_tile = M > 4096
-    if large_tile:
-        assert torch.equal(run(2, Wz)[:M].view(torch.int32), out[:M].view(torch.int32))
-    Ah, Wh = (A.half().double(), W.half().double()) if large_tile else (A.double(), W.double())
-    worst = 0.0
-    for lo in range(0, M, 8192):
-        hi = min(M, lo + 8192)
-        ref = Ah[lo:hi] @ Wh.T + bias.double() + res[lo:hi].double()
-        got = out[lo:hi].double()
-        assert torch.isfinite(got).all()
-        worst = max(worst, (got - ref).abs().max().item())
-    assert worst <= (3e-6 if large_tile else 1e-4), worst
-
-
 M6_SHAPES = [sh for sh in X3_SHAPES if sh[2] % 64 == 0] + [(128000, 1280, 1280), (25000, 2560, 5120), (4096, 1280, 5120), (4096, 5120, 1280),
                                                             # the 256x256 kernel's K loop is peeled into leading edge / middle / trailing edge (hi, MX) tile
                                                             # pairs: one pair (first and last at once), two, five

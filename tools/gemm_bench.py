@@ -13,7 +13,6 @@ ap.add_argument("--decoder-only", action="store_true")
 ap.add_argument("--rotate", type=int, default=1, help="cycle through this many weight copies (cold weights, as in a decode step)")
 ap.add_argument("--vs-torch", action="store_true", help="also time torch's F.linear (hipBLASLt) on the same operands: calibration of what the box can do, never a product path")
 ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16x3", "bf16x3", "f16m6"], help="engine mode of the GEMM (split modes: operands from fp32 values; f16m6: M6 rows via wseg_convert_operand)")
-ap.add_argument("--hi-only", action="store_true", help="f16m6: grant the hi-only permission (epi | 0x100): the large-tile kernel multiplies the hi halves alone; the error is then taken against the product of the operands rounded to IEEE half")
 ap.add_argument("--shapes", default="", help="custom list 'M,N,K,epi;M,N,K,epi;...' (epi 0 bias, 1 bias+gelu, 2 bias+residual, 3 the decoder's fused bias+residual+LayerNorm step)")
 a = ap.parse_args()
 lib = _lib.load(require_device=True)
@@ -66,7 +65,7 @@ for name, m, n, k, epi in shapes:
             _lib.check(lib.wseg_debug_gemm_resid_ln(DT, m, n, k, A.data_ptr(), Ws[call[0] % len(Ws)].data_ptr(), bias.data_ptr(), out.data_ptr(),
                                                     gam.data_ptr(), bet.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), st))
             return
-        _lib.check(lib.wseg_debug_gemm(DT, epi | (0x100 if a.hi_only else 0), m, n, k, A.data_ptr(), Ws[call[0] % len(Ws)].data_ptr(), bias.data_ptr(), res.data_ptr(),
+        _lib.check(lib.wseg_debug_gemm(DT, epi, m, n, k, A.data_ptr(), Ws[call[0] % len(Ws)].data_ptr(), bias.data_ptr(), res.data_ptr(),
                                        out.data_ptr(), ws.data_ptr(), ws.numel(), st))
     for _ in range(3):
         run()
@@ -78,8 +77,6 @@ for name, m, n, k, epi in shapes:
     us = e0.elapsed_time(e1) / a.iters * 1e3
     if epi == 3:
         out.copy_(res); run()
-    if a.hi_only:
-        A_ref, W_ref = A_ref.half().float(), W_ref.half().float()
     ref = (A_ref[:m].float() @ W_ref.float().T + bias.float())
     if epi == 1: ref = torch.nn.functional.gelu(ref)
     if epi >= 2: ref = ref + res[:m].float()

@@ -29,6 +29,18 @@ SR = 16000
 STS = 0.01
 TONES = [500.0, 1500.0, 3000.0]
 
+# Fixture-model variants.  "tiny" is the model of rounds 1-5 (tests/golden/tiny_model: weights rounded to bf16, the 200-recording
+# sweep every precision format of r03-r05 was chosen on).  "tiny2" (r06) is the HELD-OUT model: another shape (d 256, 4 heads,
+# 3 + 3 layers, ffn 768), another init seed, another data stream, other tone frequencies / amplitudes / noise floor, and
+# FULL-MANTISSA fp32 weights (a real checkpoint's weights are not representable in 16 bits: with the bf16-rounded weights of "tiny"
+# the lo halves of every weight operand are zero in the IEEE-half modes).
+VARIANTS = {
+    "tiny": dict(d_model=128, heads=2, enc_layers=2, dec_layers=2, ffn=512, tones=TONES, amp=(0.1, 0.3), noise=0.005,
+                 init_seed=0, data_seed=1234, round_bf16=True),
+    "tiny2": dict(d_model=256, heads=4, enc_layers=3, dec_layers=3, ffn=768, tones=[700.0, 2100.0, 4200.0], amp=(0.05, 0.35),
+                  noise=0.008, init_seed=1, data_seed=987654, round_bf16=False),
+}
+
 
 def bytes_to_unicode():
     bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("¡"), ord("¬") + 1)) + list(range(ord("®"), ord("ÿ") + 1))
@@ -57,11 +69,13 @@ def base_vocab():
     return {b2u[b]: i for i, b in enumerate(order)}
 
 
-def hf_config_dict():
+def hf_config_dict(variant="tiny"):
+    v = VARIANTS[variant]
     return dict(
-        model_type="whisper", vocab_size=VOCAB_SIZE, num_mel_bins=80, d_model=128,
-        encoder_layers=2, decoder_layers=2, encoder_attention_heads=2, decoder_attention_heads=2,
-        encoder_ffn_dim=512, decoder_ffn_dim=512, max_source_positions=500, max_target_positions=448,
+        model_type="whisper", vocab_size=VOCAB_SIZE, num_mel_bins=80, d_model=v["d_model"],
+        encoder_layers=v["enc_layers"], decoder_layers=v["dec_layers"], encoder_attention_heads=v["heads"],
+        decoder_attention_heads=v["heads"],
+        encoder_ffn_dim=v["ffn"], decoder_ffn_dim=v["ffn"], max_source_positions=500, max_target_positions=448,
         decoder_start_token_id=SOT, pad_token_id=EOT, eos_token_id=EOT, bos_token_id=EOT,
         activation_function="gelu", scale_embedding=False,
         total_spec_columns=1000, cluster_codebook=CLUSTER_CODEBOOK,
@@ -69,12 +83,12 @@ def hf_config_dict():
     )
 
 
-def write_model_dir(path, state_dict_bf16):
+def write_model_dir(path, state_dict_bf16, variant="tiny"):
     """HF-style directory: config.json, generation_config.json, vocab.json, added_tokens.json, model.safetensors."""
     from safetensors.torch import save_file
     os.makedirs(path, exist_ok=True)
     with open(os.path.join(path, "config.json"), "w") as f:
-        json.dump(hf_config_dict(), f, indent=1)
+        json.dump(hf_config_dict(variant), f, indent=1)
     with open(os.path.join(path, "generation_config.json"), "w") as f:
         json.dump({"max_length": 448, "suppress_tokens": SUPPRESS, "begin_suppress_tokens": BEGIN_SUPPRESS,
                    "pad_token_id": EOT, "eos_token_id": EOT, "decoder_start_token_id": SOT}, f, indent=1)
@@ -85,10 +99,12 @@ def write_model_dir(path, state_dict_bf16):
     save_file({k: v.contiguous() for k, v in state_dict_bf16.items()}, os.path.join(path, "model.safetensors"))
 
 
-def synth_clip(rng, n_samples=160000, max_events=9):
+def synth_clip(rng, n_samples=160000, max_events=9, variant="tiny"):
     """Noise + tone bursts; returns (float32 audio, [(onset_s, offset_s, cluster_id)])."""
+    v = VARIANTS[variant]
+    tones, amp_lo_hi, noise = v["tones"], v["amp"], v["noise"]
     t = np.arange(n_samples) / SR
-    x = 0.005 * rng.standard_normal(n_samples)
+    x = noise * rng.standard_normal(n_samples)
     events = []
     cur = rng.uniform(0.0, 1.5)
     n_ev = rng.integers(0, max_events + 1)
@@ -97,9 +113,9 @@ def synth_clip(rng, n_samples=160000, max_events=9):
         if cur + dur > n_samples / SR - 0.05:
             break
         c = int(rng.integers(0, 3))
-        amp = rng.uniform(0.1, 0.3)
+        amp = rng.uniform(*amp_lo_hi)
         m = (t >= cur) & (t < cur + dur)
-        x[m] += amp * np.sin(2 * np.pi * TONES[c] * t[m])
+        x[m] += amp * np.sin(2 * np.pi * tones[c] * t[m])
         events.append((cur, cur + dur, c))
         cur += dur + rng.uniform(0.12, 1.2)
     return x.astype(np.float32), events

@@ -7,6 +7,7 @@ that beam-search parity (oracle vs HF, HIP engine vs oracle) is exercised on mea
 Weights are rounded to bf16 before saving so that the fp32 oracle and the bf16 engine share them exactly.
 
     python tools/train_tiny.py [--steps 2500]
+    python tools/train_tiny.py --variant tiny2 --out tests/golden/tiny_model2     (r06: the held-out fixture model, fp32 weights)
 """
 import argparse
 import os
@@ -21,10 +22,10 @@ from oracle.frontend import logmel_window  # noqa: E402
 from tools import tiny_model as TM  # noqa: E402
 
 
-def make_batch(rng, bs, max_len=40):
+def make_batch(rng, bs, max_len=40, variant="tiny"):
     feats, dec_in, labels = [], [], []
     for _ in range(bs):
-        x, ev = TM.synth_clip(rng)
+        x, ev = TM.synth_clip(rng, variant=variant)
         f = logmel_window(x, TM.SR, TM.STS)[:, :1000]
         ids = TM.PROMPT + TM.label_tokens(ev)
         d_in = ids[:-1]
@@ -44,21 +45,24 @@ def main():
     ap.add_argument("--steps", type=int, default=2500)
     ap.add_argument("--bs", type=int, default=16)
     ap.add_argument("--out", default="tests/golden/tiny_model")
+    ap.add_argument("--variant", default="tiny", choices=sorted(TM.VARIANTS))
+    ap.add_argument("--threads", type=int, default=8)
     args = ap.parse_args()
+    var = TM.VARIANTS[args.variant]
     from transformers import WhisperConfig, WhisperForConditionalGeneration
-    torch.manual_seed(0)
-    torch.set_num_threads(8)
-    cd = TM.hf_config_dict()
+    torch.manual_seed(var["init_seed"])
+    torch.set_num_threads(args.threads)
+    cd = TM.hf_config_dict(args.variant)
     extra = {k: cd.pop(k) for k in ("total_spec_columns", "cluster_codebook", "default_segmentation_config", "model_type")}
     cfg = WhisperConfig(**cd, suppress_tokens=None, begin_suppress_tokens=None)
     model = WhisperForConditionalGeneration(cfg)
     opt = torch.optim.AdamW(model.parameters(), lr=2e-3, weight_decay=0.01)
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=2e-3, total_steps=args.steps, pct_start=0.1)
-    rng = np.random.default_rng(1234)
+    rng = np.random.default_rng(var["data_seed"])
     model.train()
     t0 = time.time()
     for step in range(args.steps):
-        f, d_in, lab = make_batch(rng, args.bs)
+        f, d_in, lab = make_batch(rng, args.bs, variant=args.variant)
         out = model(input_features=f, decoder_input_ids=d_in, labels=lab)
         out.loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
@@ -66,8 +70,9 @@ def main():
         if step % 50 == 0:
             print(f"step {step} loss {out.loss.item():.4f}  {time.time()-t0:.0f}s", flush=True)
     model.eval()
-    sd = {k: v.detach().to(torch.bfloat16) for k, v in model.state_dict().items() if k != "proj_out.weight"}
-    TM.write_model_dir(args.out, sd)
+    store = torch.bfloat16 if var["round_bf16"] else torch.float32
+    sd = {k: v.detach().to(store) for k, v in model.state_dict().items() if k != "proj_out.weight"}
+    TM.write_model_dir(args.out, sd, args.variant)
     print("saved", args.out)
 
 

@@ -77,6 +77,10 @@ class WsegError(RuntimeError):
     pass
 
 
+class WsegOutOfMemory(WsegError):
+    """The decode workspace could not be allocated on the device (the only error Engine.generate answers with fewer slots)."""
+
+
 def load(require_device=False):
     """dlopen libwseg.so and bind every symbol.  Raises if the library is absent."""
     global _lib

@@ -16,9 +16,12 @@
 #define WSEG_KNOB_SET(name) (getenv(name) != nullptr)
 #define WSEG_KNOB_IS(name, val) (getenv(name) && !strcmp(getenv(name), val))
 #else
-#define WSEG_KNOB_INT(name, dflt) (dflt)
-#define WSEG_KNOB_SET(name) false
-#define WSEG_KNOB_IS(name, val) false
+// (a tool that sets one of these variables against the product library would silently measure the default and label it an ablation:
+// the library says so once per variable on stderr — ADVICE r05)
+namespace wseg { bool knob_compiled_out(const char* name); }      // always false
+#define WSEG_KNOB_INT(name, dflt) (::wseg::knob_compiled_out(name) ? (dflt) : (dflt))
+#define WSEG_KNOB_SET(name) (::wseg::knob_compiled_out(name))
+#define WSEG_KNOB_IS(name, val) (::wseg::knob_compiled_out(name))
 #endif
 
 namespace wseg {
@@ -170,14 +173,6 @@ struct M6 {};
 template <> struct IO<M6> { typedef float P; typedef f16_t H; typedef f16_t A; static constexpr bool split = true; };
 template <typename T> struct IsMx { static constexpr bool v = false; };
 template <> struct IsMx<M6> { static constexpr bool v = true; };
-// Tag M6H: the same M6 rows on both sides and the same outputs, but the GEMM multiplies the hi tiles ONLY (every second K tile is
-// skipped, not even loaded): a plain IEEE-half product of the operands rounded once — half the bytes and 32 / 52 of the matrix-core
-// cycles of M6.  For the GEMMs whose operands tolerate 11 mantissa bits (GemmArgs::hi_only; which ones: DESIGN.md).
-struct M6H {};
-template <> struct IO<M6H> : IO<M6> {};
-template <> struct IsMx<M6H> { static constexpr bool v = true; };
-template <typename T> struct HiOnly { static constexpr bool v = false; };
-template <> struct HiOnly<M6H> { static constexpr bool v = true; };
 typedef int mx_i32x8 __attribute__((ext_vector_type(8)));
 struct MxFrag { mx_i32x8 v; };      // a 32-byte chunk: v[0..5] = 32 e2m3 codes, low byte of v[6] = e8m0 scale (the MFMA reads 6 registers)
 __device__ __forceinline__ f32x4 mfma_mx6(const MxFrag& a, const MxFrag& b, f32x4 c) {

@@ -10,6 +10,12 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+#ifndef WSEG_KNOBS
+bool knob_compiled_out(const char* name) {
+  if (getenv(name)) fprintf(stderr, "libwseg: %s is set, but this library was built without -DWSEG_KNOBS=1: the variable is ignored and the default is in effect\n", name);
+  return false;
+}
+#endif
 }  // namespace wseg
 
 using namespace wseg;

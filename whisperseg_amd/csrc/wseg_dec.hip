@@ -1561,7 +1561,9 @@ int row_topk_segments(int R) {
 }
 template <int KC>
 static void launch_topk_t(const DecodeState& st, const float* logits, float* pv, int* pi, float* ps, hipStream_t s, const int* list, int n_list) {
-  const int R = (list ? n_list : st.W) * st.nb, nseg = row_topk_segments(R);
+  // list mode (the admission's pass): the vocabulary is sliced as in a decode step of the whole slot population, so that the log-sum-exp
+  // of a row is summed in the same order however many windows were admitted together
+  const int R = (list ? n_list : st.W) * st.nb, nseg = row_topk_segments(st.W * st.nb);
   hipLaunchKernelGGL((row_topk_partial_kernel<KC>), dim3(nseg, R), dim3(256), 0, s, st, logits, nseg, pv, pi, ps, list);
   hipLaunchKernelGGL((row_topk_merge_kernel<KC>), dim3(R), dim3(64), 0, s, st, nseg, pv, pi, ps, list);
 }

@@ -887,23 +887,13 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 2 : 1) voi
 // SPLITK (decoder rows, too few 256x256 output tiles for the chip): the tile space is S copies of the m x n tile grid; copy z
 // multiplies K tiles [z nk / S, (z + 1) nk / S) and stores its fp32 partial tile at out_f32 + z M N (EPI_F32, no bias); the
 // caller's reduction kernel (splitk_reduce_resid_ln_kernel) sums the S planes.
-template <typename T, int EPI, bool STAGED_RESID = false, bool SPLITK = false>
+template <typename T, int EPI, bool SPLITK = false>
 __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::H* __restrict__ A, int lda, const typename IO<T>::H* __restrict__ W,
                                                           int ldw, int M, int N, int K, EpiParams ep, int ntm, int GM, int S) {
   typedef typename IO<T>::H HT;
-  constexpr bool HIONLY = HiOnly<T>::v;   // M6H: M6 rows, hi tiles only — the K-tile stream steps over the MX tiles (KS = 2)
-  constexpr int KS = HIONLY ? 2 : 1;
-  constexpr bool MXM = IsMx<T>::v && !HIONLY;      // M6 rows: odd K tiles are MX tiles (16 scaled MFMAs per phase instead of 32 plain ones)
+  constexpr bool MXM = IsMx<T>::v;      // M6 rows: odd K tiles are MX tiles (16 scaled MFMAs per phase instead of 32 plain ones)
   constexpr bool X3M = IO<T>::split && !IsMx<T>::v;      // hi | lo K tiles: 24 instead of 16 MFMAs per phase, (W hi, A hi) (W hi, A lo) (W lo, A hi)
-  // Residual epilogue without LDS and without barriers (EPI_RESID, opt-in: WSEG_PP_DIRECT_RESID=1; the LDS-staged one is the
-  // default): the accumulators of a tile START as its fp32 residual rows (loaded in the MFMA accumulator layout: a lane owns 4
-  // consecutive columns of a row, 16 bytes), the MFMAs add A W^T on top, and the epilogue is bias + 32 direct 16-byte stores
-  // per lane, each followed by the residual load of the NEXT tile into the register quad just stored.  The staged epilogue
-  // costs 21 us per 256x256 tile with the matrix pipe idle; this one measured 27 us: timing-only variants (no loads: -13 us, no
-  // stores: -16 us per tile) show the epilogue is the HBM-bound burst of all CUs hitting their tile boundary together
-  // (1.31 GB of fp32 residual traffic at ~4.6 TB/s), not a per-wave latency chain — kept as an experiment knob.
-  constexpr bool DIRECT = EPI == EPI_RESID && !STAGED_RESID;
-  constexpr bool LATEWAIT = WSEG_PP_LATEWAIT != 0 && !DIRECT;      // see hi_tile, phase B
+  constexpr bool LATEWAIT = WSEG_PP_LATEWAIT != 0;      // see hi_tile, phase B
   constexpr int BM = 256, BN = 256, BK = 64, TM = 128, TN = 64, MI = 8, NI = 4;
   constexpr int HTILE = 128 * BK;                      // elements per half-tile (16 KB)
   constexpr int BUF = 4 * HTILE;                       // elements per K-tile buffer: [A0 | A1 | B0 | B1]
@@ -918,21 +908,12 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   GM &= 0xff;
 #endif
   const int fr = lane & 15, fg = lane >> 4;
-  const int ntn = N / BN, ntmn = ntm * ntn, ntiles = SPLITK ? ntmn * S : ntmn, nk = K / (BK * KS);
+  const int ntn = N / BN, ntmn = ntm * ntn, ntiles = SPLITK ? ntmn * S : ntmn, nk = K / BK;
   const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3, bpx = gridDim.x >> 3;
   const int q = ntiles >> 3, r = ntiles & 7;
   const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   const int count = q + (xcd < r ? 1 : 0);
   if (loc >= count) return;
-#if defined(WSEG_PP_STAGGER) && WSEG_PP_STAGGER > 0
-  // experiment (variant builds): the workgroups of XCD x start x * WSEG_PP_STAGGER shader cycles late, so that the tile boundaries of
-  // the eight XCDs — the HBM burst of every CU's epilogue — do not coincide (long tile sequences only: the delay is paid once).
-  // r05: 8 000 / 15 000 cycles per XCD measured +0.4 % on the 1 024-window step (profiles/r05_epilogue_ab.txt): not the lever.
-  if (!SPLITK && (count + bpx - 1) / bpx >= 16) {
-    const long long t0 = clock64(), wait = (long long)xcd * WSEG_PP_STAGGER;
-    while (clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-  }
-#endif
   // split-K: copy z of the tile grid owns K tiles [k_first(z), k_first(z + 1))
   auto tile_z = [&](int swz) { return SPLITK ? swz / ntmn : 0; };
   auto k_first = [&](int z) { return SPLITK ? (MXM ? 2 * (z * (nk / 2) / S) : z * nk / S) : 0; };      // M6 rows: whole (hi, MX) tile pairs
@@ -981,9 +962,9 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   // strides of their pieces
   const size_t a_piece = (size_t)32 * lda * sizeof(HT);
   const size_t w_half = (size_t)128 * ldw * sizeof(HT), w_piece = (size_t)64 * ldw * sizeof(HT);
-  constexpr size_t K_STEP = (size_t)BK * KS * sizeof(HT);
-  const char* ca_ptr = (const char*)(A + (ca_row + (size_t)(SPLITK ? ca_k0 : 0) * (BK * KS)));
-  const char* cb_ptr = (const char*)(W + (cb_row + (size_t)(SPLITK ? cb_k0 : 0) * (BK * KS)));
+  constexpr size_t K_STEP = (size_t)BK * sizeof(HT);
+  const char* ca_ptr = (const char*)(A + (ca_row + (size_t)(SPLITK ? ca_k0 : 0) * BK));
+  const char* cb_ptr = (const char*)(W + (cb_row + (size_t)(SPLITK ? cb_k0 : 0) * BK));
   // par: LDS buffer of the K tile being issued, when the caller knows it at compile time (M6 rows: a K range is whole (hi, MX) tile
   // pairs, so hi tiles always live in buffer 0 and MX tiles in buffer 1 — the buffer selects and the fragment address arithmetic fold
   // away); -1: the stream index decides
@@ -1003,7 +984,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
         tile_coords(start + ca_idx, tm, tn);
         ca_row = (size_t)tm * lda;
         if constexpr (SPLITK) { const int z = tile_z(start + ca_idx); ca_k0 = k_first(z); ca_nk = k_first(z + 1) - ca_k0; }
-        ca_ptr = (const char*)(A + (ca_row + (size_t)(SPLITK ? ca_k0 : 0) * (BK * KS)));
+        ca_ptr = (const char*)(A + (ca_row + (size_t)(SPLITK ? ca_k0 : 0) * BK));
       }
     }
   };
@@ -1023,7 +1004,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
         tile_coords(start + cb_idx, tm, tn);
         cb_row = (size_t)tn * ldw;
         if constexpr (SPLITK) { const int z = tile_z(start + cb_idx); cb_k0 = k_first(z); cb_nk = k_first(z + 1) - cb_k0; }
-        cb_ptr = (const char*)(W + (cb_row + (size_t)(SPLITK ? cb_k0 : 0) * (BK * KS)));
+        cb_ptr = (const char*)(W + (cb_row + (size_t)(SPLITK ? cb_k0 : 0) * BK));
       }
     }
   };
@@ -1065,35 +1046,14 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
 
   int g = 0;                                           // K tiles consumed so far
   f32x4 acc[NI][MI];
-  constexpr bool direct = DIRECT;
-  // residual rows of the tile at (tm0, tn0) into the accumulators, opaque to the compiler's waitcnt bookkeeping (as C++ loads
-  // it would have to wait for them at the first accumulator use of EVERY K-loop iteration, draining the LDS-DMA prefetch each
-  // time): retired by the explicit vmcnt(0) in front of the tile's first MFMA.  Quadrant order = the order phases 0..3 use them.
-  auto resid_ptr = [&](int tm0, int tn0, int i, int j) {
-    const int m = min(tm0 + wr * TM + j * 16 + fr, M - 1);
-    return (const float*)ep.resid + (size_t)m * ep.ldc + (tn0 + wc * TN + i * 16 + fg * 4);
-  };
-  if constexpr (DIRECT) {
-    int tm0, tn0;
-    tile_coords(start + loc, tm0, tn0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int i = 2 * ((q == 1 || q == 2) ? 1 : 0); i < 2 * ((q == 1 || q == 2) ? 1 : 0) + 2; ++i)
-#pragma unroll
-        for (int j = 4 * (q >> 1); j < 4 * (q >> 1) + 4; ++j)
-          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(acc[i][j]) : "v"(resid_ptr(tm0, tn0, i, j)) : "memory");
-  }
   for (int idx = loc; idx < count; idx += bpx) {
   int m0, n0;
   tile_coords(start + idx, m0, n0);
   const int tz = tile_z(start + idx), nkt = SPLITK ? k_first(tz + 1) - k_first(tz) : nk;
-  if (!(DIRECT && direct)) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
+    for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // One K tile = two phases.  The tile bodies are lambdas so that the M6 instantiation can run a (hi tile, MX tile) PAIR per loop
   // iteration as straight-line code: with both bodies behind a branch inside one loop the register allocator spilled ~60 VGPRs into
   // the loop, and every scratch reload waits (vmcnt is in order) for the whole LDS-DMA prefetch stream: 4x slower than f16x3.
@@ -1102,8 +1062,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   // instruction issue; r04: ~1 % of the GEMM per 8-10 instructions taken out of it)
   auto hi_tile = [&](int kt, auto mid_tag) {
     constexpr bool MID = decltype(mid_tag)::value;
-    // direct epilogue: the K-tile stream never pauses at an output-tile boundary (no staging buffer to protect)
-    const bool first = !MID && !(DIRECT && direct) && kt == 0 && g > 0, final = !MID && !(DIRECT && direct) && kt == nkt - 1;
+    const bool first = !MID && kt == 0 && g > 0, final = !MID && kt == nkt - 1;
     constexpr int PAR = MXM ? 0 : -1;                  // this tile's LDS buffer (M6 rows: hi tiles in buffer 0), -1: g & 1
     constexpr int NPAR = MXM ? 1 : -1;
     const HT* cur = smem + (MXM ? 0 : (g & 1)) * BUF;
@@ -1122,7 +1081,6 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
       afr[j][0] = *(const bf16x8*)(cur + j * 16 * BK + fa0);
       afr[j][1] = *(const bf16x8*)(cur + j * 16 * BK + fa1);
     }
-    if (DIRECT && direct && kt == 0) wait_vmcnt<0>();        // this tile's residual rows have landed in acc
     if (first && g + 1 < KT) issue_b(NPAR);                     // B pair of K tile g+1, held back over the epilogue
     if (MID || g + 1 < KT) issue_a(NPAR);                       // A pair of K tile g+1
     __builtin_amdgcn_sched_barrier(0);
@@ -1154,8 +1112,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   };
   [[maybe_unused]] auto mx_tile = [&](int kt, auto mid_tag) {
     constexpr bool MID = decltype(mid_tag)::value;
-    // direct epilogue: the K-tile stream never pauses at an output-tile boundary (no staging buffer to protect)
-    const bool first = !MID && !(DIRECT && direct) && kt == 0 && g > 0, final = !MID && !(DIRECT && direct) && kt == nkt - 1;
+    const bool first = !MID && kt == 0 && g > 0, final = !MID && kt == nkt - 1;
     const HT* cur = smem + BUF;                        // MX tiles live in buffer 1
       // ---- MX tile (M6 rows): the same two phases, hand-overs and prefetch stream as below; the fragments are 24-byte e2m3
       // groups + a scale byte (ld_mx_frag), a quadrant pair is 16 scaled MFMAs ----
@@ -1218,20 +1175,16 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
     int kt = 0;
     hi_tile(kt, EDGE); ++g; mx_tile(kt + 1, EDGE); ++g;
     kt = 2;
-    if constexpr (!DIRECT) {
 #pragma nounroll
-      for (; kt + 3 < nkt; kt += 2) { hi_tile(kt, MIDDLE); ++g; mx_tile(kt + 1, MIDDLE); ++g; }
-    }
+    for (; kt + 3 < nkt; kt += 2) { hi_tile(kt, MIDDLE); ++g; mx_tile(kt + 1, MIDDLE); ++g; }
 #pragma nounroll
     for (; kt < nkt; kt += 2) { hi_tile(kt, EDGE); ++g; mx_tile(kt + 1, EDGE); ++g; }
   } else {
     int kt = 0;
     hi_tile(kt, EDGE); ++g;
     kt = 1;
-    if constexpr (!DIRECT) {
 #pragma nounroll
-      for (; kt + 2 < nkt; ++kt, ++g) hi_tile(kt, MIDDLE);
-    }
+    for (; kt + 2 < nkt; ++kt, ++g) hi_tile(kt, MIDDLE);
 #pragma nounroll
     for (; kt < nkt; ++kt, ++g) hi_tile(kt, EDGE);
   }
@@ -1241,30 +1194,7 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   // then drops one barrier behind again.  Every wave stages in its own strip of the buffer the last K tile left; nothing
   // is prefetched into that buffer before phase A of the next K tile, which both groups reach only after the barrier
   // below.  (Requesting group 0's residual rows before its idle interval measured no further gain.)
-  if constexpr (DIRECT) {
-    typedef typename IO<T>::P PT;
-    const int nidx = idx + bpx;
-    const bool has_next = nidx < count;
-    int nm0 = 0, nn0 = 0;
-    if (has_next) tile_coords(start + nidx, nm0, nn0);
-    float bv[NI][4];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      if (ep.bias) Vec4<PT>::ld((const PT*)ep.bias + n0 + wc * TN + i * 16 + fg * 4, bv[i]);
-      else bv[i][0] = bv[i][1] = bv[i][2] = bv[i][3] = 0.f;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int i = 2 * ((q == 1 || q == 2) ? 1 : 0); i < 2 * ((q == 1 || q == 2) ? 1 : 0) + 2; ++i)
-#pragma unroll
-        for (int j = 4 * (q >> 1); j < 4 * (q >> 1) + 4; ++j) {
-          const int m = m0 + wr * TM + j * 16 + fr;
-          const f32x4 v = {acc[i][j][0] + bv[i][0], acc[i][j][1] + bv[i][1], acc[i][j][2] + bv[i][2], acc[i][j][3] + bv[i][3]};
-          if (m < M) *(f32x4*)((float*)ep.out + (size_t)m * ep.ldc + (n0 + wc * TN + i * 16 + fg * 4)) = v;
-          if (has_next) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(acc[i][j]) : "v"(resid_ptr(nm0, nn0, i, j)) : "memory");
-        }
-  } else {
+  {
     if (wr == 0) __builtin_amdgcn_s_barrier();
     if constexpr (SPLITK) {
       EpiParams epz = ep;
@@ -1282,405 +1212,6 @@ __global__ __launch_bounds__(512) void gemm_h16_pp_kernel(const typename IO<T>::
   if (wr == 0) __builtin_amdgcn_s_barrier();          // pair group 1's extra barrier
 }
 
-// ================================================================================================
-// EXPERIMENT, knob builds only (python -m whisperseg_amd.build --variant w4 -DWSEG_KNOBS=1; WSEG_GEMM_W4=1): the one-wave-per-SIMD kernel
-// VERDICT r04 asked for.  Built, parity-green, measured with cycle stamps — and slower than the ping-pong kernel above, for a reason
-// the stamps name (profiles/r05_w4_experiments.txt): the product library does not carry it.
-// ================================================================================================
-#ifdef WSEG_KNOBS
-// ------------------------------------------------------------------------------------------------
-// Epilogue of gemm_w4_kernel: the wave tile is 4 x 4 accumulator tiles of 32 x 32 (v_mfma_f32_32x32x16: lane (c = lane & 31, h = lane >> 5)
-// holds, of output row m = c, the columns n = 8 q + 4 h + {0..3}, q = 0..3, in registers 4 q .. 4 q + 3).  One 32-row x 32-column tile
-// at a time goes through the wave's own LDS strip so that 4 lanes cover one 128-byte output row piece with 16-byte accesses and a quad
-// of lanes owns one 32-column block (what the cooperative M6 row writer needs).  As in staged_epilogue: every global load (bias,
-// residual rows, the slot map) is issued before the first store it could queue behind.
-// ------------------------------------------------------------------------------------------------
-template <typename T, int EPI>
-__device__ __forceinline__ void staged_epilogue32(const f32x16 (&acc)[4][4], float* stage, const EpiParams& ep, int M, int mb, int nb, int lane,
-                                                  int wave) {
-  typedef typename IO<T>::P PT;
-  constexpr int LDT = 32 + 4;
-  float* strip = stage + (size_t)wave * 32 * LDT;
-  const int c32 = lane & 31, h = lane >> 5, rr = lane >> 2, cc = (lane & 3) * 8;
-  int kv_b0 = 0, kv_s0 = 0, kv_s1 = 0;
-  EpiParams ep2 = ep;
-  ep2.bias = nullptr;
-  if constexpr (EPI == EPI_KV_CROSS) {      // the (at most two: 128 rows <= t_len) windows this wave tile touches
-    if (ep.slot_map) {
-      const int nwin = (M + ep.t_len - 1) / ep.t_len;
-      kv_b0 = min(mb, M - 1) / ep.t_len;
-      kv_s0 = ep.slot_map[kv_b0];
-      kv_s1 = ep.slot_map[min(kv_b0 + 1, nwin - 1)];
-      ep2.slot_map = nullptr;
-    }
-  }
-  float bv[4][8];                           // the bias of all four column blocks, requested before the first store
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (ep.bias) ld8_h<PT>((const PT*)ep.bias + nb + i * 32 + cc, bv[i]);
-    else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) bv[i][e] = 0.f;
-    }
-  }
-  // fp32 residual rows: a ring of 8 row pieces (16 rows x 32 columns each: two 16-byte loads per lane).  All 8 pieces of column block 0
-  // are requested before the first store; piece t of block i + 1 is requested right after piece t of block i has been stored, 7 stores
-  // ahead of its use, so it never waits for a store it was issued behind (vmcnt retires in order).
-  float4 rres[EPI == EPI_RESID ? 8 : 1][2];
-  auto resid_req = [&](int i, int t) __attribute__((always_inline)) {
-    const float* rp = (const float*)ep.resid + (size_t)min(mb + t * 16 + rr, M - 1) * ep.ldc + nb + i * 32 + cc;
-    rres[t][0] = *(const float4*)rp; rres[t][1] = *(const float4*)(rp + 4);
-  };
-  if constexpr (EPI == EPI_RESID) {
-#pragma unroll
-    for (int t = 0; t < 8; ++t) resid_req(0, t);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {             // 32 columns nb + 32 i ..
-    const int nc = nb + i * 32 + cc;
-    // An UNCONDITIONAL use of the loaded registers (rows beyond M skip the real one): without it a load stays "pending" in the compiler's
-    // scoreboard across the loop back edge and costs an s_waitcnt vmcnt(0) — a drain of the LDS-DMA prefetch stream — in every K-tile
-    // pair of the caller's main loop (the compiler does not see the waits inside asm statements, but it does see asm operands)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) asm volatile("" :: "v"(bv[i][e]));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {           // 32 rows mb + 32 j ..
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *(float4*)(strip + c32 * LDT + 8 * q + 4 * h) = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-      // same-wave LDS RAW / WAR: the ds operations of one wave complete in order
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const int rw = hh * 16 + rr;
-        const float4 a = *(const float4*)(strip + rw * LDT + cc), b = *(const float4*)(strip + rw * LDT + cc + 4);
-        float v[8] = {a.x + bv[i][0], a.y + bv[i][1], a.z + bv[i][2], a.w + bv[i][3], b.x + bv[i][4], b.y + bv[i][5], b.z + bv[i][6], b.w + bv[i][7]};
-        const int m = mb + j * 32 + rw;
-        if constexpr (EPI == EPI_RESID) {
-          const int t = j * 2 + hh;
-          const float4 r0 = rres[t][0], r1 = rres[t][1];
-          asm volatile("" :: "v"(r0.x), "v"(r0.y), "v"(r0.z), "v"(r0.w), "v"(r1.x), "v"(r1.y), "v"(r1.z), "v"(r1.w));
-          if (m < M) {
-            float* o = (float*)ep.out + (size_t)m * ep.ldc + nc;
-            *(float4*)o = make_float4(r0.x + v[0], r0.y + v[1], r0.z + v[2], r0.w + v[3]);
-            *(float4*)(o + 4) = make_float4(r1.x + v[4], r1.y + v[5], r1.z + v[6], r1.w + v[7]);
-          }
-          if (i + 1 < 4) resid_req(i + 1, t);
-        } else if constexpr (EPI == EPI_KV_CROSS) {
-          int mm = m;
-          if (ep.slot_map) { const int bw = m / ep.t_len; mm = (bw == kv_b0 ? kv_s0 : kv_s1) * ep.t_len + (m - bw * ep.t_len); }
-          if (m < M) epi_apply8<EPI, T>(ep2, mm, nc, v);
-        } else {
-          if (m < M) epi_apply8<EPI, T>(ep2, m, nc, v);
-        }
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// One-wave-per-SIMD persistent kernel for the large encoder GEMMs (r05): 256x256 tile, 4 waves = 2 x 2 wave tiles of 128x128 as 4 x 4
-// accumulator tiles of v_mfma_f32_32x32x16 — sixteen 16-register tuples: the 256 accumulator registers of a wave fill the AGPR half of
-// its 512-register file (sixty-four 4-register tuples of the 16x16 instruction made the register allocator shuffle accumulators
-// between the two halves with hundreds of v_accvgpr moves per K tile) —, 128 KB of LDS = two K-tile buffers of [A tile 256 x 64 words
-// | W tile 256 x 64 words] + an 18-KB epilogue staging area of its own (the K-tile stream never pauses at an output-tile boundary).
-// Against the 8-wave ping-pong kernel above: a third fewer fragment bytes per MFMA (32 ds_read_b128 per 64 K words of a 128x128 wave
-// tile instead of 24 per 128x64), half as many waves issuing LDS-DMA, ONE barrier per K tile and no hand-over between row groups:
-// the wave's own instruction stream interleaves fragment reads, LDS-DMA issue and MFMAs (sched_group_barrier).
-//
-// Stream of K tiles g = 0, 1, 2, ... (continuous across the output tiles a workgroup owns), tile g in buffer g & 1.  Per tile:
-//     first half :  32 MFMAs on the fragments of k-steps 0, 1 (in registers)   ||  ds_reads of k-steps 2, 3 of tile g
-//     mid        :  s_waitcnt vmcnt(0) lgkmcnt(0) ; s_barrier    -> every wave has finished READING buffer g & 1 and its pieces of
-//                                                                   tile g + 1 (requested half a tile + ago) have LANDED
-//     second half:  32 MFMAs on k-steps 2, 3   ||  ds_reads of k-steps 0, 1 of tile g + 1 (other buffer)  ||  LDS-DMA of tile g + 2
-//                                                                   into buffer g & 1 (16 pieces of 1 KB per wave)
-// so a tile has a whole half (>= 1024 matrix-pipe cycles) to land before anybody waits for it.
-// M6 rows (WSEG_F16M6): tiles alternate hi (buffer 0: the plain schedule) / MX (buffer 1): an MX tile is two scaled MFMAs
-// (v_mfma_scale_f32_32x32x64_f8f6f4, fp6 e2m3) per accumulator tile — instruction t takes chunk 2 t + (lane >> 5) of both operands'
-// MX blocks: t = 0 pairs activation lo6 with weight hi6, t = 1 activation hi6 with weight lo6 (wseg_common.h) — and its halves are
-// the two instructions: the t = 0 fragments are read during the hi tile's second half, the t = 1 fragments during the MX tile's first
-// half, the next hi tile's first fragments during its second half.  Every half reads 16 fragments; the 512-register file has room
-// for the builtin's 8-register operand tuples: no inline assembly.
-// LDS image: 128-byte rows, logical 16-byte slot s of row r at slot s ^ ((r >> 1) & 7) (conflict-free for 32-row fragments).
-// ------------------------------------------------------------------------------------------------
-// Measurement builds only (python -m whisperseg_amd.build --stamps 6, tools/w4_stamps.py): workgroup 0 records the shader clock of its
-// four waves at the boundaries of the halves of its first K tiles (4 stamps per tile) and around its epilogues.
-#if defined(WSEG_STAMPS) && WSEG_STAMPS == 6
-__device__ unsigned long long g_w4_stamps[4 * 512 + 32];      // + (shader cycles, 100-MHz ticks) at the epilogues of wave 0: the effective clock
-#ifdef WSEG_W4_STAMP_LIGHT      // tile tops and epilogue bounds only (a stamp costs ~130 cycles: six per K tile distort what they measure)
-#define WSEG_W4_STAMP(TAG) do { if ((TAG) == 1 || (TAG) == 5 || (TAG) == 9 || (TAG) == 10) { if (blockIdx.x == 0 && lane == 0 && sc < 512) { \
-    g_w4_stamps[wave * 512 + sc] = (__builtin_readcyclecounter() << 4) | (TAG); } ++sc; } } while (0)
-#else
-#define WSEG_W4_STAMP(TAG) do { if (blockIdx.x == 0 && lane == 0 && sc < 512) { \
-    g_w4_stamps[wave * 512 + sc] = (__builtin_readcyclecounter() << 4) | (TAG); } ++sc; } while (0)
-#endif
-#else
-#define WSEG_W4_STAMP(TAG) do { } while (0)
-#endif
-template <typename T, int EPI>
-__global__ __launch_bounds__(256) void gemm_w4_kernel(const typename IO<T>::H* __restrict__ A, int lda, const typename IO<T>::H* __restrict__ W,
-                                                      int ldw, int M, int N, int K, EpiParams ep, int ntm, int GM) {
-  typedef typename IO<T>::H HT;
-  constexpr bool MXM = IsMx<T>::v;
-  static_assert(!IO<T>::split || MXM, "plain 16-bit operands or M6 rows");
-  constexpr int BM = 256, BN = 256, BK = 64;
-  constexpr int OPER = 256 * BK;                   // elements of one operand tile (32 KB)
-  constexpr int BUF = 2 * OPER;                    // [A tile | W tile]
-  constexpr int LDT = 32 + 4;
-  __shared__ __attribute__((aligned(16))) HT smem[2 * BUF + 4 * 32 * LDT * 2];      // + staging: 4 strips of 32 x 36 floats
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int fr = lane & 31, fh = lane >> 5;
-  [[maybe_unused]] int sc = 0, ec = 0;             // stamp / epilogue counters (measurement builds)
-  const int ntn = N / BN, ntiles = ntm * ntn, nk = K / BK;      // nk is even (launcher)
-  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-  const int q8 = ntiles >> 3, r8 = ntiles & 7;
-  const int start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-  const int count = q8 + (xcd < r8 ? 1 : 0);
-  if (loc >= count) return;
-  auto tile_coords = [&](int swz, int& m0, int& n0) __attribute__((always_inline)) {
-    const int per_group = GM * ntn, grp = swz / per_group, rem = swz - grp * per_group;
-    const int gm = min(GM, ntm - grp * GM);
-    m0 = (grp * GM + rem % gm) * BM;
-    n0 = (rem / gm) * BN;
-  };
-
-  // ---- LDS-DMA stream: a wave streams 64 rows of each operand tile as 8 pieces of 8 rows (1 KB: lane l -> row l >> 3, LDS slot l & 7).
-  // Row r = 8 p + (l >> 3) of the wave's 64 holds logical slot (l & 7) ^ ((r >> 1) & 7) = (l & 7) ^ (4 (p & 1) + (l >> 4)): one lane
-  // offset for the even pieces, one for the odd ones.  The cursor is two uniform byte pointers; NOTHING inside a K-tile pair branches
-  // (a branch splits the basic block the scheduler interleaves MFMAs, fragment reads and LDS-DMA issue in, and the compiler sinks
-  // MFMAs across it): the pairs inside an output tile advance the pointers by one K tile per request, the pair that crosses into the
-  // next output tile takes that tile's pointers, computed once per output tile ----
-  // The requests are MUBUF instructions (buffer_load_dwordx4 ... lds: base in a 4-SGPR buffer descriptor per operand and output tile,
-  // the piece and K offsets in the scalar offset, the lane offset in a 32-bit VGPR): unlike global_load_lds they are VMEM to the
-  // compiler's sched_group_barrier, so they can be PLACED between the MFMAs — as FLAT instructions all 16 of a half were issued in one
-  // burst at its head, ~65 cycles each with the matrix pipe idle (cycle stamps: 2 200 instead of 1 100 cycles per half).
-  const int lrow = lane >> 3, lsl = lane & 7;
-  const int a_lane0 = (lrow * lda + ((lsl ^ (lane >> 4)) << 3)) * (int)sizeof(HT);
-  const int a_lane1 = (lrow * lda + ((lsl ^ (4 + (lane >> 4))) << 3)) * (int)sizeof(HT);
-  const int w_lane0 = (lrow * ldw + ((lsl ^ (lane >> 4)) << 3)) * (int)sizeof(HT);
-  const int w_lane1 = (lrow * ldw + ((lsl ^ (4 + (lane >> 4))) << 3)) * (int)sizeof(HT);
-  auto lane_off = [&](int kept) __attribute__((always_inline)) -> int { int t = kept; asm volatile("" : "+v"(t)); return t; };
-  const int a_piece = 8 * lda * (int)sizeof(HT), w_piece = 8 * ldw * (int)sizeof(HT);
-  constexpr int K_STEP = BK * (int)sizeof(HT);
-  typedef __amdgpu_buffer_rsrc_t rsrc_t;
-  auto tile_rsrc = [&](int seq, rsrc_t& pa, rsrc_t& pw) __attribute__((always_inline)) {
-    int tm, tn;
-    tile_coords(start + seq, tm, tn);
-    pa = __builtin_amdgcn_make_buffer_rsrc((void*)(A + ((size_t)tm + wave * 64) * lda), 0, -1, 0x00020000);
-    pw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + ((size_t)tn + wave * 64) * ldw), 0, -1, 0x00020000);
-  };
-  rsrc_t ra, rw;                                   // descriptors of this wave's 64 rows of the output tile the requests are in
-  int kofs = 0;                                    // ... and the byte offset of the next K tile to request
-  tile_rsrc(loc, ra, rw);
-  typedef __attribute__((address_space(3))) void* lds_vp;
-  auto issue = [&](auto btag) __attribute__((always_inline)) {      // this wave's 16 pieces of the K tile at the cursor into buffer B; the cursor advances
-    constexpr int B = decltype(btag)::value;
-    HT* dA = smem + B * BUF + wave * 4096;
-    HT* dW = dA + OPER;
-    const int al0 = lane_off(a_lane0), al1 = lane_off(a_lane1), wl0 = lane_off(w_lane0), wl1 = lane_off(w_lane1);
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vp)(dA + p * 512), 16, (p & 1) ? al1 : al0, kofs + p * a_piece, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_vp)(dW + p * 512), 16, (p & 1) ? wl1 : wl0, kofs + p * w_piece, 0, 0);
-    }
-    kofs += K_STEP;
-  };
-
-  // ---- fragment addresses (bytes): row t*32 + fr of the wave's 128 rows; hi tiles: k-step ks (16 words) = logical slot 2 ks + fh;
-  // MX tiles: instruction t reads chunk 2 t + fh = logical slots 4 t + 2 fh, + 1.  Buffer 1 is 64 KB up. ----
-  const char* const lds = (const char*)smem;
-  const int swz = (fr >> 1) & 7;
-  const int frag = fr * 128 + ((fh ^ swz) << 4);               // ks = 0; ks: ^ (ks << 5)
-  const int offA = wm * 16384, offW = 32768 + wn * 16384;
-  const char* const fa = lds + offA + frag, * const fw = lds + offW + frag;
-  [[maybe_unused]] const int mfrag = fr * 128 + (((2 * fh) ^ swz) << 4);      // t = 0, first slot; second slot ^ 16; t = 1: ^ 64
-  [[maybe_unused]] const char* const ma = lds + 65536 + offA + mfrag, * const mw = lds + 65536 + offW + mfrag;
-
-  f32x16 acc[4][4];                                // [n tile i][m tile j]
-  bf16x8 a0[2][4], w0[2][4], a1[2][4], w1[2][4];   // fragments of k-steps 0, 1 / 2, 3
-  [[maybe_unused]] MxFrag am0[4], wx0[4], am1[4], wx1[4];      // MX fragments of instruction t = 0 / 1
-
-  auto mid_barrier = [&]() __attribute__((always_inline)) {
-    __builtin_amdgcn_sched_barrier(0);
-#if defined(WSEG_STAMPS) && WSEG_STAMPS == 6 && !defined(WSEG_W4_STAMP_LIGHT)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    WSEG_W4_STAMP(11);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    WSEG_W4_STAMP(12);
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  // k-steps 2 H, 2 H + 1 of the tile in buffer B
-  auto ld_half = [&](auto btag, auto htag, bf16x8 (&af)[2][4], bf16x8 (&wf)[2][4]) __attribute__((always_inline)) {
-    constexpr int O = decltype(btag)::value * 65536, H = decltype(htag)::value;
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      constexpr int dummy = 0; (void)dummy;
-      const int x = (2 * H + s2) << 5;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) af[s2][j] = *(const bf16x8*)(lds + ((int)(fa - lds) ^ x) + O + j * 4096);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wf[s2][i] = *(const bf16x8*)(lds + ((int)(fw - lds) ^ x) + O + i * 4096);
-    }
-  };
-  // (the chunk halves are read as the SAME vector type as the hi fragments: through HIP's uint4 the compiler put an s_waitcnt vmcnt(0)
-  // — a drain of the LDS-DMA stream — in front of these reads in every pair, and narrowed the second read to ds_read_b96 + two v_mov)
-  typedef int mx_i32x4 __attribute__((ext_vector_type(4)));
-  [[maybe_unused]] auto ld_mx = [&](auto ttag, MxFrag (&af)[4], MxFrag (&wf)[4]) __attribute__((always_inline)) {
-    constexpr int X = decltype(ttag)::value << 6;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const mx_i32x4 q0 = __builtin_bit_cast(mx_i32x4, *(const bf16x8*)(lds + ((int)(ma - lds) ^ X) + j * 4096));
-      const mx_i32x4 q1 = __builtin_bit_cast(mx_i32x4, *(const bf16x8*)(lds + ((int)(ma - lds) ^ X ^ 16) + j * 4096));
-      af[j].v = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const mx_i32x4 q0 = __builtin_bit_cast(mx_i32x4, *(const bf16x8*)(lds + ((int)(mw - lds) ^ X) + i * 4096));
-      const mx_i32x4 q1 = __builtin_bit_cast(mx_i32x4, *(const bf16x8*)(lds + ((int)(mw - lds) ^ X ^ 16) + i * 4096));
-      wf[i].v = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7);
-    }
-  };
-  auto mfma_half = [&](const bf16x8 (&wf)[2][4], const bf16x8 (&af)[2][4]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = H16<HT>::mfma32(wf[s2][i], af[s2][j], acc[i][j]);
-  };
-  [[maybe_unused]] auto mfma_mx = [&](const MxFrag (&wf)[4], const MxFrag (&af)[4]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[i].v, af[j].v, acc[i][j], 2, 2, 0, wf[i].v[6], 0, af[j].v[6]);
-  };
-#define WSEG_W4_SCHED(NREP, NDS, NVM, NMF)                                              \
-  _Pragma("unroll") for (int sg_ = 0; sg_ < (NREP); ++sg_) {                            \
-    if ((NDS) > 0) __builtin_amdgcn_sched_group_barrier(0x100, (NDS), 0);               \
-    if ((NVM) > 0) __builtin_amdgcn_sched_group_barrier(0x020, (NVM), 0);               \
-    __builtin_amdgcn_sched_group_barrier(0x008, (NMF), 0);                              \
-  }
-  // second halves: 16 / PER groups of {PER fragment reads, NMF MFMAs}, then as many of {PER requests, NMF MFMAs}: one request per MFMA
-  // slot — an LDS-DMA issue blocks the wave's in-order issue for ~50-65 cycles, of which one MFMA in flight covers 32; two requests
-  // back to back leave the matrix pipe idle for the second one (cycle stamps: 1 520 against 1 124 cycles per 32-MFMA half)
-#define WSEG_W4_SCHED2(HAS_DS, HAS_VM, PER, NMF)                                        \
-  _Pragma("unroll") for (int sg_ = 0; sg_ < 16 / (PER); ++sg_) {                        \
-    if (HAS_DS) __builtin_amdgcn_sched_group_barrier(0x100, (PER), 0);                  \
-    __builtin_amdgcn_sched_group_barrier(0x008, (NMF), 0);                              \
-  }                                                                                     \
-  _Pragma("unroll") for (int sg_ = 0; sg_ < 16 / (PER); ++sg_) {                        \
-    if (HAS_VM) __builtin_amdgcn_sched_group_barrier(0x020, (PER), 0);                  \
-    __builtin_amdgcn_sched_group_barrier(0x008, (NMF), 0);                              \
-  }
-  constexpr std::integral_constant<int, 0> B0{};
-  constexpr std::integral_constant<int, 1> B1{};
-  constexpr std::true_type YES{};
-  constexpr std::false_type NO{};
-
-  // One plain / hi K tile in buffer B.  NEXT1: K tile g + 1 exists (its first fragments are read in the second half); NEXT2: K tile
-  // g + 2 exists (requested in the second half).  Both are compile-time: the code of a pair never branches.
-  auto tile16 = [&](auto btag, auto next1_tag, auto next2_tag) __attribute__((always_inline)) {
-    constexpr int B = decltype(btag)::value;
-    constexpr bool NEXT1 = decltype(next1_tag)::value, NEXT2 = decltype(next2_tag)::value;
-    const std::integral_constant<int, B ^ 1> other{};
-    WSEG_W4_STAMP(1);
-    ld_half(btag, B1, a1, w1);
-    mfma_half(w0, a0);
-    WSEG_W4_SCHED(16, 1, 0, 1)                     // the 16 reads between the first 16 MFMAs: retired long before the barrier asks
-    WSEG_W4_STAMP(2);
-    mid_barrier();
-    WSEG_W4_STAMP(3);
-    // (source order = the order the scheduler must keep: an LDS-DMA is an LDS store it cannot tell apart from the fragment reads; a
-    // sched_group_barrier pipeline that asks for the opposite order is dropped as a whole and the half runs reads, requests, MFMAs
-    // back to back.  Reads first: they are retired by the time the next half needs them; the requests still have a half + to land)
-    if constexpr (MXM) {                           // the MX tile g + 1 (buffer 1) always exists: K ranges are whole (hi, MX) pairs
-      ld_mx(B0, am0, wx0);
-      if constexpr (NEXT2) issue(B0);
-    } else {
-      if constexpr (NEXT1) ld_half(other, B0, a0, w0);
-      if constexpr (NEXT2) issue(btag);
-    }
-    mfma_half(w1, a1);
-    WSEG_W4_SCHED2(MXM || NEXT1, NEXT2, 1, 1)
-    __builtin_amdgcn_sched_barrier(0);
-    WSEG_W4_STAMP(4);
-  };
-  // the MX tile (buffer 1) of an M6 pair; NEXT1 / NEXT2 as above (the next tile is a hi tile in buffer 0)
-  [[maybe_unused]] auto tile_mx = [&](auto next1_tag, auto next2_tag) __attribute__((always_inline)) {
-    constexpr bool NEXT1 = decltype(next1_tag)::value, NEXT2 = decltype(next2_tag)::value;
-    WSEG_W4_STAMP(5);
-    ld_mx(B1, am1, wx1);
-    mfma_mx(wx0, am0);
-    WSEG_W4_SCHED(8, 2, 0, 1)
-    WSEG_W4_STAMP(6);
-    mid_barrier();
-    WSEG_W4_STAMP(7);
-    if constexpr (NEXT1) ld_half(B0, B0, a0, w0);
-    if constexpr (NEXT2) issue(B1);
-    mfma_mx(wx1, am1);
-    WSEG_W4_SCHED2(NEXT1, NEXT2, 2, 1)
-    __builtin_amdgcn_sched_barrier(0);
-    WSEG_W4_STAMP(8);
-  };
-  auto pair_mid = [&]() __attribute__((always_inline)) {       // both tiles have a tile 1 and 2 ahead of them
-    tile16(B0, YES, YES);
-    if constexpr (MXM) tile_mx(YES, YES); else tile16(B1, YES, YES);
-  };
-  auto pair_end = [&]() __attribute__((always_inline)) {       // the last pair of the workgroup's stream
-    tile16(B0, YES, NO);
-    if constexpr (MXM) tile_mx(NO, NO); else tile16(B1, NO, NO);
-  };
-
-  // prologue: K tiles 0 and 1 requested, tile 0 landed, its first fragments in registers
-  issue(B0);
-  issue(B1);
-  asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-  ld_half(B0, B0, a0, w0);
-
-  for (int idx = loc; idx < count; idx += bpx) {
-    int m0, n0;
-    tile_coords(start + idx, m0, n0);
-    const bool more = idx + bpx < count;
-    rsrc_t nra = ra, nrw = rw;                     // the next output tile
-    if (more) tile_rsrc(idx + bpx, nra, nrw);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // Stretches of straight-line code (one loop body behind a branch makes the register allocator shuffle accumulators between the two
-    // halves of the register file and spill): the pairs whose requests stay inside this output tile; then the pair whose two requests
-    // are K tiles 0 and 1 of the next output tile — or, at the end of the stream, the pair that requests nothing
-#pragma nounroll
-    for (int kt = 2; kt < nk; kt += 2) pair_mid();
-    ra = nra; rw = nrw; kofs = 0;
-#pragma nounroll
-    for (int once = more ? 1 : 0; once > 0; --once) pair_mid();
-#pragma nounroll
-    for (int once = more ? 0 : 1; once > 0; --once) pair_end();
-    // LDS-staged epilogue in the wave's own strip of the staging area (no barrier: the strips are wave-private and no K-tile buffer
-    // is touched; the next tiles keep landing meanwhile)
-#if defined(WSEG_STAMPS) && WSEG_STAMPS == 6
-    if (blockIdx.x == 0 && wave == 0 && lane == 0 && ec < 16) { g_w4_stamps[4 * 512 + 2 * ec] = __builtin_readcyclecounter(); g_w4_stamps[4 * 512 + 2 * ec + 1] = wall_clock64(); }
-    ++ec;
-#endif
-    WSEG_W4_STAMP(9);
-    staged_epilogue32<T, EPI>(acc, (float*)(smem + 2 * BUF), ep, M, m0 + wm * 128, n0 + wn * 128, lane, wave);
-    WSEG_W4_STAMP(10);
-  }
-#undef WSEG_W4_SCHED
-#undef WSEG_W4_SCHED2
-}
-
-#endif      // WSEG_KNOBS
 
 template <int EPI, typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, int m_pad,
@@ -1979,7 +1510,12 @@ static int device_cu_count() {
 // applies the epilogue (or the fused residual + LayerNorm).
 struct SkinnyPlan { int bm, bn, mt, m_pad, splits, k_len; };
 
-static SkinnyPlan plan_skinny(const GemmArgs& g, bool pairs = false) {      // pairs: M6 rows — a K range is whole (hi, MX) tile pairs
+// The rows a launch is PLANNED for (GemmArgs::plan_m): kernel family, tile size and split-K ranges follow them, the grid follows g.M.
+static inline int plan_rows(const GemmArgs& g) { return g.plan_m > 0 ? g.plan_m : g.M; }
+static inline GemmArgs plan_view(const GemmArgs& g) { GemmArgs p = g; p.M = plan_rows(g); p.plan_m = 0; return p; }
+
+static SkinnyPlan plan_skinny(const GemmArgs& g0, bool pairs = false) {      // pairs: M6 rows — a K range is whole (hi, MX) tile pairs
+  const GemmArgs g = plan_view(g0);
   SkinnyPlan sp;
   // largest row tile that still yields >= 160 workgroups without splitting K; otherwise 128 rows + split-K
   sp.bm = g.M <= 32 ? 32 : (g.M <= 64 ? 64 : 128);
@@ -2005,6 +1541,8 @@ static SkinnyPlan plan_skinny(const GemmArgs& g, bool pairs = false) {      // p
     }
   }
   sp.k_len = g.K / sp.splits;
+  sp.mt = cdiv(g0.M, sp.bm);      // the grid and the partial planes cover the rows actually launched
+  sp.m_pad = sp.mt * sp.bm;
   return sp;
 }
 
@@ -2101,7 +1639,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_resid_ln_kernel(const float
 // and fc1 (480) are better on large tiles (13.50 vs 13.70 ms).
 static bool big_tile_path(const GemmArgs& g) {
   static const long big_min = WSEG_KNOB_INT("WSEG_BIG_MIN_BLOCKS", 340);   // tuning knob (variant builds)
-  return g.M > 128 && g.N % 128 == 0 && (long)cdiv(g.M, 128) * (g.N / 128) >= big_min;
+  const int pm = plan_rows(g);
+  return pm > 128 && g.N % 128 == 0 && (long)cdiv(pm, 128) * (g.N / 128) >= big_min;
 }
 
 // Split-precision modes: the caller's K / lda / ldw are LOGICAL; the kernels see rows of 2K 16-bit words.
@@ -2148,7 +1687,8 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
     // 256x256 tiles need whole rounds of the chip: with fewer than 4 rounds, a last round that leaves more than a fifth of
     // the CUs idle costs more than the smaller tile's lower arithmetic intensity (decoder fc1 at 4096 rows: 320 tiles =
     // 1.25 rounds, 118 us against 1280 tiles of 128x128 in 2.5 rounds of 512 workgroups).
-    const long nt256 = (long)cdiv(g.M, 256) * (g.N / 256);
+    const int pm = plan_rows(g);
+    const long nt256 = (long)cdiv(pm, 256) * (g.N / 256);
     const long rounds256 = (nt256 + n_cu - 1) / n_cu;
     static const bool quant_rule = !WSEG_KNOB_SET("WSEG_GEMM_NO_QUANT_RULE");   // tuning knob (variant builds)
     // (split / mixed modes: a K tile pair costs twice the bf16 K tile while the 128x128 kernel's fixed costs do not shrink — since the
@@ -2167,16 +1707,16 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
       // reduction writes their M6 rows.
       if constexpr (IsMx<T>::v && (EPI == EPI_STORE || EPI == EPI_GELU)) {
         static const bool tail_split = !WSEG_KNOB_SET("WSEG_NO_TAIL_SPLIT");      // A/B knob (variant builds)
-        const int ntn = g.N / 256, full_cols = n_cu / ntm, pairs = g.K / 128;
+        const int ptm = cdiv(pm, 256);      // planned row tiles: the column split and S must not follow the rows launched
+        const int ntn = g.N / 256, full_cols = n_cu / ptm, pairs = g.K / 128;
         if (tail_split && pingpong && rounds256 == 2 && g.splitk_ws && full_cols >= 1 && full_cols < ntn && g.K >= 256) {
-          const int rem_tiles = (ntn - full_cols) * ntm, n1 = full_cols * 256, n2 = g.N - n1;
+          const int rem_tiles = (ntn - full_cols) * ptm, n1 = full_cols * 256, n2 = g.N - n1;
           int S = n_cu / rem_tiles;
-          while (S >= 2 && ((rem_tiles * S) % 8 || pairs / S < 2 || (size_t)S * g.M * n2 * sizeof(float) > g.splitk_ws_bytes)) --S;
+          while (S >= 2 && ((rem_tiles * S) % 8 || pairs / S < 2 || (size_t)S * pm * n2 * sizeof(float) > g.splitk_ws_bytes)) --S;
           if (S >= 2 && rem_tiles * S * 4 >= n_cu * 3) {
             int grid = ntm * full_cols < n_cu ? ntm * full_cols : n_cu;
-            grid &= ~7;
-            hipLaunchKernelGGL((gemm_h16_pp_kernel<T, EPI, false>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, n1, g.K, g.ep, ntm,
-                               group_m, 1);
+            grid = grid < 8 ? 8 : (grid & ~7);
+            hipLaunchKernelGGL((gemm_h16_pp_kernel<T, EPI>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, n1, g.K, g.ep, ntm, group_m, 1);
             GemmArgs g2 = g;
             g2.W = W + (size_t)n1 * g.ldw;
             g2.N = n2;
@@ -2192,54 +1732,21 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
           }
         }
       }
-      // (Measured and dropped, r04: the generic kernel as 4 waves x 128x128 wave tiles, one wave per SIMD — a third fewer fragment
-      // reads per MFMA, but with nothing to hide its per-K-tile barriers behind: 640 against 1 080 TFLOP/s on the encoder shapes.)
-      // r05 experiment (knob builds): the one-wave-per-SIMD kernel (plain 16-bit operands and M6 rows, an even number of K tiles)
-#ifdef WSEG_KNOBS
-      if constexpr (!IO<T>::split || std::is_same<T, M6>::value) {
-#ifndef WSEG_W4_DEFAULT
-#define WSEG_W4_DEFAULT 0
-#endif
-        static const bool use_w4 = WSEG_KNOB_INT("WSEG_GEMM_W4", WSEG_W4_DEFAULT) != 0;
-        if (use_w4 && !g0.hi_only && (g.K / 64) % 2 == 0 && EPI != EPI_QKV_DEC && EPI != EPI_SCALE) {
-          int grid = ntiles < n_cu ? ntiles : n_cu;
-          grid &= ~7;
-          hipLaunchKernelGGL((gemm_w4_kernel<T, EPI>), dim3(grid), dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K, g.ep, ntm, group_m);
-          if (e1) (void)hipEventRecord(e1, s);
-          WSEG_LAUNCH_CHECK();
-          return WSEG_OK;
-        }
-      }
-#endif
+      // (Measured and dropped: r04, the generic kernel as 4 waves x 128x128 wave tiles, one wave per SIMD — 640 against 1 080 TFLOP/s on the
+      // encoder shapes; r05, the hand-built one-wave-per-SIMD kernel — tools/experiments/r05_gemm_w4_kernel.hip.txt, profiles/r05_w4_experiments.txt;
+      // r03, a register-resident residual epilogue — all CUs reach their epilogue together and its 1.3 GB of fp32 residual traffic is an
+      // HBM-bound burst either way: staged 540 / 1513 us, direct 590 / 1525 us; r04, hi-only attention projections in f16m6 — 19x the logit
+      // error at 32 layers.)
       {
         int grid = ntiles < n_cu ? ntiles : n_cu;
-        grid &= ~7;
-        // A/B knob: register-resident residual epilogue (measured slower, profiles/README.md r03: all CUs reach their epilogue
-        // together and its 1.3 GB of fp32 residual traffic is an HBM-bound burst either way; staged 540 / 1513 us, direct 590 / 1525 us)
-        static const bool resid_staged = !WSEG_KNOB_SET("WSEG_PP_DIRECT_RESID");
-        // WSEG_F16M6, hi-only permission: the M6H instantiation (encoder q|k|v and o-proj: the EPIs it is built for)
-        if constexpr (std::is_same<T, M6>::value && (EPI == EPI_QKV_ENC || EPI == EPI_RESID)) {
-          static const bool no_hi = WSEG_KNOB_SET("WSEG_NO_HI_ONLY");      // A/B knob (variant builds)
-          if (g0.hi_only && !no_hi && g.K >= 256) {
-            hipLaunchKernelGGL((gemm_h16_pp_kernel<M6H, EPI, EPI == EPI_RESID>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K,
-                               g.ep, ntm, group_m, 1);
-            if (e1) (void)hipEventRecord(e1, s);
-            WSEG_LAUNCH_CHECK();
-            return WSEG_OK;
-          }
-        }
-        if (EPI == EPI_RESID && resid_staged)
-          hipLaunchKernelGGL((gemm_h16_pp_kernel<T, EPI, true>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K, g.ep, ntm,
-                             group_m, 1);
-        else
-          hipLaunchKernelGGL((gemm_h16_pp_kernel<T, EPI, false>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K, g.ep, ntm,
-                             group_m, 1);
+        grid = grid < 8 ? 8 : (grid & ~7);
+        hipLaunchKernelGGL((gemm_h16_pp_kernel<T, EPI>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K, g.ep, ntm, group_m, 1);
       }
     } else {
       const int ntm = cdiv(g.M, 128), ntiles = ntm * (g.N / 128);
-      if (persist && !no_swz && ntiles >= 16) {
+      if (persist && !no_swz && cdiv(pm, 128) * (g.N / 128) >= 16) {
         int grid = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;
-        grid &= ~7;
+        grid = grid < 8 ? 8 : (grid & ~7);
         hipLaunchKernelGGL((gemm_h16_persist_kernel<T, 128, 128, 2, 2, EPI>), dim3(grid), dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
                            g.K, g.ep, ntm, group_m);
       } else {
@@ -2395,12 +1902,13 @@ template <typename T> static int pp_splitk_plan(const GemmArgs& g) {
   static const int min_rows_env = WSEG_KNOB_INT("WSEG_PP_SPLITK_MIN_ROWS", 0);
   const int min_rows = min_rows_env ? min_rows_env : (IO<T>::split ? 448 : 2048);      // (r05: 480 rows = the 120 windows of a one-hour recording, 9.39 -> 8.99 ms per step; at 384 rows the stream kernel wins, 7.32 against 7.77)
   static const int min_kt = WSEG_KNOB_INT("WSEG_PP_SPLITK_MIN_KT", 40);
-  if (g.M < min_rows || g.N % 256 || g.K % 64 || g.K / 64 < min_kt || !g.splitk_ws) return 0;
-  const int nt = cdiv(g.M, 256) * (g.N / 256), nk = g.K / 64, n_cu = device_cu_count();
+  const int pm = plan_rows(g);
+  if (pm < min_rows || g.N % 256 || g.K % 64 || g.K / 64 < min_kt || !g.splitk_ws) return 0;
+  const int nt = cdiv(pm, 256) * (g.N / 256), nk = g.K / 64, n_cu = device_cu_count();
   static const int max_s = WSEG_KNOB_INT("WSEG_PP_SPLITK_MAX_S", 64), min_kt_per = WSEG_KNOB_INT("WSEG_PP_SPLITK_KT_PER", 4);
   int S = n_cu / nt;
   if (S > max_s) S = max_s;
-  while (S >= 2 && ((nt * S) % 8 || nk / S < min_kt_per || (size_t)S * g.M * g.N * sizeof(float) > g.splitk_ws_bytes)) --S;
+  while (S >= 2 && ((nt * S) % 8 || nk / S < min_kt_per || (size_t)S * pm * g.N * sizeof(float) > g.splitk_ws_bytes)) --S;
   // fewer than 96 workgroups of 5 K tiles each (d x d projections at 448-511 rows) lose to the stream family: 120 windows 8.9-9.1 -> 8.6 ms per
   // decode step, 112 windows 8.73 -> 8.13 (profiles/r05_epilogue_ab.txt)
   static const int min_wgs = WSEG_KNOB_INT("WSEG_PP_SPLITK_MIN_WGS", 96);
@@ -2413,10 +1921,10 @@ template <typename T> static int launch_pp_splitk(const GemmArgs& g, int S, hipS
   static const int group_m = WSEG_KNOB_INT("WSEG_GEMM_GROUP_M", 4);
   const int ntm = cdiv(g.M, 256), ntiles = ntm * (g.N / 256) * S, n_cu = device_cu_count();
   int grid = ntiles < n_cu ? ntiles : n_cu;
-  grid &= ~7;
+  grid = grid < 8 ? 8 : (grid & ~7);
   EpiParams ep;
   ep.out_f32 = g.splitk_ws; ep.ldc = g.N;
-  hipLaunchKernelGGL((gemm_h16_pp_kernel<T, EPI_F32, false, true>), dim3(grid), dim3(512), 0, s, (const HT*)g.A, g.lda, (const HT*)g.W, g.ldw,
+  hipLaunchKernelGGL((gemm_h16_pp_kernel<T, EPI_F32, true>), dim3(grid), dim3(512), 0, s, (const HT*)g.A, g.lda, (const HT*)g.W, g.ldw,
                      g.M, g.N, g.K, ep, ntm, group_m, S);
   WSEG_LAUNCH_CHECK();
   return WSEG_OK;
@@ -2506,11 +2014,8 @@ extern "C" int wseg_debug_gemm(int32_t dtype, int32_t epi, int32_t M, int32_t N,
                                const void* bias, const void* resid, void* out, void* splitk_ws, size_t splitk_ws_bytes,
                                void* stream) {
   using namespace wseg;
-  const bool hi_only = (epi & 0x100) != 0;
-  epi &= 0xff;
   if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || epi < 0 || epi > 2) { set_error("wseg_debug_gemm: bad argument"); return WSEG_ERR_INVALID; }
   GemmArgs g;
-  g.hi_only = hi_only;
   g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K;
   g.ep.bias = bias; g.ep.out = out; g.ep.ldc = N; g.ep.resid = resid;
   g.splitk_ws = (float*)splitk_ws; g.splitk_ws_bytes = splitk_ws_bytes;

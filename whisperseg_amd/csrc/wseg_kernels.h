@@ -67,8 +67,10 @@ struct GemmArgs {
   EpiParams ep;
   float* splitk_ws = nullptr;     // fp32 [splits][M_pad][N] when the launcher decides to split K
   size_t splitk_ws_bytes = 0;
-  bool hi_only = false;           // WSEG_F16M6, experiment (off in the model): the 256x256 kernel multiplies the hi
-                                  // halves only (M6H); kernels without that variant multiply the full M6 rows
+  int plan_m = 0;                 // > 0: choose the PLAN (kernel family, tile size, split-K ranges: everything that fixes the summation order of an
+                                  // output element) as for plan_m rows and launch it over the M rows given.  The admission pass of the slot scheduler
+                                  // runs whatever number of rows was admitted on the plan of the call's decode step, so that a window's numbers do not
+                                  // depend on how many neighbours were admitted with it.  plan_m >= M.
 };
 
 // dtype: WSEG_F32 (exact kernels), WSEG_BF16 / WSEG_F16 (MFMA) or WSEG_BF16X3 / WSEG_F16X3 (split-precision MFMA: A and W
@@ -78,6 +80,7 @@ struct GemmArgs {
 int launch_gemm(int dtype, EpiKind epi, const GemmArgs& g, hipStream_t s);
 // WSEG_F16M6: does an EPI_STORE / EPI_GELU launch of this (logical) shape write M6 rows (true) or hi | lo rows (false)?
 // splitk_ws_bytes: the split-K workspace the launch will be given (0: none) — the skinny family writes M6 rows when it splits K
+// (M: the rows the PLAN is chosen for — GemmArgs::plan_m when the launch sets it)
 bool gemm_out_is_mx(int dtype, int M, int N, int K, size_t splitk_ws_bytes = 0);
 // Split-K partial sums only (bf16 decoder rows): part[z][m_pad][N] fp32 in g.splitk_ws, no epilogue.  The consumer
 // kernel (decoder self-/cross-attention) finishes the reduction itself.  Returns false in *ok when the shape is not

@@ -77,7 +77,6 @@ struct wseg_model {
   size_t es;                 // element size of the model dtype
   bool x3 = false;           // split-precision mode (GEMM operands are hi | lo rows, everything else fp32)
   bool mx = false;           // WSEG_F16M6: GEMM operands are M6 rows (weights attached converted; activations converted before each GEMM)
-  bool attn_hi = false;      // WSEG_F16M6 experiment (WSEG_ATTN_HI=1): the encoder's attention projections (q|k|v, o) multiply the hi halves only
   int sdt = 0;               // dtype of every non-GEMM kernel (WSEG_F16M6 -> WSEG_F16X3)
   const void* dec_tok_f32 = nullptr;      // WSEG_F16M6: fp32 copy of the token embedding for the embedding lookup
   size_t ckv_es = 0;         // bytes per cross-attention K / V element: es, or 3 (24-bit planes) in the split modes with <= 4 beams
@@ -244,10 +243,10 @@ int to_mx(const wseg_model* m, const void*& A, int M, int K, char* scratch, hipS
 
 // mxa: scratch for the M6 image of A (WSEG_F16M6; null when A already is M6 rows)
 int gemm(const wseg_model* m, EpiKind epi, const void* A, int lda, const void* Wt, int ldw, int M, int N, int K,
-         const EpiParams& ep, const DecPlan* p, hipStream_t s, char* mxa = nullptr, bool hi_only = false) {
+         const EpiParams& ep, const DecPlan* p, hipStream_t s, char* mxa = nullptr, int plan_m = 0) {
   if (m->mx && mxa) { const int st = to_mx(m, A, M, K, mxa, s); if (st != WSEG_OK) return st; }
   GemmArgs g;
-  g.hi_only = hi_only;
+  g.plan_m = plan_m;
   g.A = A; g.lda = lda; g.W = Wt; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.ep = ep;
   if (p) { g.splitk_ws = (float*)p->splitk; g.splitk_ws_bytes = p->splitk_bytes; }
   return launch_gemm(m->cfg.dtype, epi, g, s);
@@ -280,11 +279,11 @@ int run_encoder(wseg_model* m, const float* feats, int W, Plan& p, void* enc_out
     e = EpiParams();
     e.bias = L.qkv_b; e.q = p.q; e.k = p.k; e.v = p.vt; e.d_model = d; e.t_len = T; e.t_pad = Tp; e.n_heads = H; e.scale = 0.125f;
     if (m->x3) { e.qkv_mode = x3_enc_attention_mode(); e.qkv_plane = (size_t)W * H * Tp * 64; }
-    WSEG_TRY(gemm(m, EPI_QKV_ENC, p.y, d, L.qkv_w, d, M, 3 * d, d, e, nullptr, s, nullptr, m->attn_hi));
+    WSEG_TRY(gemm(m, EPI_QKV_ENC, p.y, d, L.qkv_w, d, M, 3 * d, d, e, nullptr, s));
     WSEG_TRY(launch_enc_attention(gdt, p.q, p.k, p.vt, p.y, W, H, T, Tp, d, s));
     e = EpiParams();
     e.bias = L.o_b; e.out = p.x; e.resid = p.x; e.ldc = d;
-    WSEG_TRY(gemm(m, EPI_RESID, p.y, d, L.o_w, d, M, d, d, e, nullptr, s, attn_mx ? nullptr : p.mxa, m->attn_hi));
+    WSEG_TRY(gemm(m, EPI_RESID, p.y, d, L.o_w, d, M, d, d, e, nullptr, s, attn_mx ? nullptr : p.mxa));
     WSEG_TRY(launch_layernorm(gdt, (const float*)p.x, L.ln2_g, L.ln2_b, p.y, M, d, s));
     e = EpiParams();
     e.bias = L.fc1_b; e.out = p.hbuf; e.ldc = ffn;
@@ -301,7 +300,9 @@ int run_encoder(wseg_model* m, const float* feats, int W, Plan& p, void* enc_out
 // The forced prompt positions 0 .. np - 1 of n windows admitted together (device list `slots`), as one pass of n * np rows through the
 // decoder layers instead of np steps of every slot: the decoder weights and the windows' cross-attention K / V are read once for them
 // (split-precision modes, up to 4 beams; the admission kernel then starts the slots at position np).
-struct PromptPass { const int* slots; int n, np; bool logits; };      // logits: + the LM head on the LAST position's rows -> p.logits [n][vp]
+struct PromptPass { const int* slots; int n, np; bool logits; int plan_rows; };      // logits: + the LM head on the LAST position's rows -> p.logits [n][vp]
+// plan_rows: the rows the pass's GEMMs are PLANNED for (GemmArgs::plan_m) = max(slots x beams, np), a function of the call and not of the
+// admission; n * np <= plan_rows.
 
 // One decoder step for all R rows at position *st.pos (want_logits: final LN + LM head), or the prompt pass `pp` of newly admitted windows
 // (row i * np + j = window i at position j; no logits: the next token is forced).
@@ -314,8 +315,12 @@ int run_decoder_step(wseg_model* m, DecPlan& p, char* mxa, bool want_logits, hip
   if (pp) { view.W = pp->n; view.nb = pp->np; view.done = p.zeros; }
   const DecodeState& st = pp ? view : p.st;
   const int R = st.W * st.nb;
+  // The pass runs on the GEMM plans of the call's decode step (slots x beams rows) whatever number of windows was admitted: kernel family,
+  // tile size and split-K ranges — the summation order of every output element — then depend on the call's slot count only, like the
+  // steps themselves, and not on when a window's neighbours finished.
+  const int PR = pp ? pp->plan_rows : 0;
   if (pp) {
-    if (!m->x3 || x3_cross_kv_format(gdt, p.st.nb) == 0 || R > p.row_cap) { set_error("prompt pass: unsupported mode / row count %d", R); return WSEG_ERR_STATE; }
+    if (!m->x3 || x3_cross_kv_format(gdt, p.st.nb) == 0 || R > p.row_cap || R > PR) { set_error("prompt pass: unsupported mode / row count %d", R); return WSEG_ERR_STATE; }
     WSEG_TRY(launch_prompt_embed(m->mx ? WSEG_F32 : dt, p.st, R, pp->np, m->mx ? m->dec_tok_f32 : m->dec_tok, m->dec_pos, p.dx, d, s));
   } else {
     WSEG_TRY(launch_embed(m->mx ? WSEG_F32 : dt, st, m->mx ? m->dec_tok_f32 : m->dec_tok, m->dec_pos, p.dx, d, s));
@@ -323,11 +328,11 @@ int run_decoder_step(wseg_model* m, DecPlan& p, char* mxa, bool want_logits, hip
   EpiParams e;
   // WSEG_F16M6: LayerNorm outputs (dy) and attention outputs (dattn) are M6 rows already; the FFN hidden (dh) is when its GEMM
   // ran on a large-tile kernel (a_mx: the operand needs no conversion)
-  const bool dh_mx = gemm_out_is_mx(gdt, R, ffn, d, p.splitk_bytes);
+  const bool dh_mx = gemm_out_is_mx(gdt, pp ? PR : R, ffn, d, p.splitk_bytes);
   auto gemm_resid_ln = [&](const void* A, int K, const void* Wt, const void* bias, const void* g_, const void* b_, bool a_mx) -> int {
     if (!a_mx) WSEG_TRY(to_mx(m, A, R, K, mxa, s));
     GemmArgs g;
-    g.A = A; g.lda = K; g.W = Wt; g.ldw = K; g.M = R; g.N = d; g.K = K;
+    g.A = A; g.lda = K; g.W = Wt; g.ldw = K; g.M = R; g.N = d; g.K = K; g.plan_m = PR;
     g.ep.bias = bias; g.ep.out = p.dx; g.ep.resid = p.dx; g.ep.ldc = d;
     g.splitk_ws = (float*)p.splitk; g.splitk_ws_bytes = p.splitk_bytes;
     return launch_gemm_resid_ln(gdt, g, g_, b_, p.dy, s);
@@ -339,15 +344,16 @@ int run_decoder_step(wseg_model* m, DecPlan& p, char* mxa, bool want_logits, hip
     {   // q|k|v projection: partial sums only when possible; the attention kernel finishes the reduction
       const void* a_op = p.dy;
       GemmArgs g;
-      g.A = a_op; g.lda = d; g.W = L.qkv_w; g.ldw = d; g.M = R; g.N = 3 * d; g.K = d;
+      g.A = a_op; g.lda = d; g.W = L.qkv_w; g.ldw = d; g.M = R; g.N = 3 * d; g.K = d; g.plan_m = PR;
       g.splitk_ws = (float*)p.splitk; g.splitk_ws_bytes = p.splitk_bytes;
       PartialInfo pi; bool ok = false;
       WSEG_TRY(launch_gemm_partial(gdt, g, &pi, &ok, s));
       if (pp) {
-        if (!ok) {      // many windows admitted at once: q | k | v as fp32 rows of an un-split GEMM (bias added by the attention kernel)
+        if (!ok) {      // the step's plan does not split q | k | v: fp32 rows of an un-split GEMM (bias added by the attention kernel)
+          if ((size_t)R * 3 * d > (size_t)p.row_cap * m->vp) { set_error("prompt pass: %d rows of q | k | v do not fit the logits buffer", R); return WSEG_ERR_STATE; }
           e = EpiParams();
           e.out_f32 = (float*)p.logits; e.ldc = 3 * d;
-          WSEG_TRY(gemm(m, EPI_F32, a_op, d, L.qkv_w, d, R, 3 * d, d, e, &p, s));
+          WSEG_TRY(gemm(m, EPI_F32, a_op, d, L.qkv_w, d, R, 3 * d, d, e, &p, s, nullptr, PR));
         }
         WSEG_TRY(launch_prompt_self_attn(gdt, p.st, (const float*)p.logits, ok ? &pi : nullptr, L.qkv_b, p.sk + l * self_stride, p.sv + l * self_stride,
                                          pp->slots, pp->n, pp->np, p.dattn, H, d, 0.125f, s));
@@ -365,7 +371,7 @@ int run_decoder_step(wseg_model* m, DecPlan& p, char* mxa, bool want_logits, hip
     {   // cross-attention query: same scheme
       const void* a_op = p.dy;
       GemmArgs g;
-      g.A = a_op; g.lda = d; g.W = L.cq_w; g.ldw = d; g.M = R; g.N = d; g.K = d;
+      g.A = a_op; g.lda = d; g.W = L.cq_w; g.ldw = d; g.M = R; g.N = d; g.K = d; g.plan_m = PR;
       g.splitk_ws = (float*)p.splitk; g.splitk_ws_bytes = p.splitk_bytes;
       PartialInfo pi; bool ok = false;
       WSEG_TRY(launch_gemm_partial(gdt, g, &pi, &ok, s));
@@ -375,7 +381,7 @@ int run_decoder_step(wseg_model* m, DecPlan& p, char* mxa, bool want_logits, hip
       } else {
         e = EpiParams();
         e.bias = L.cq_b; e.out = p.dq; e.ldc = d; e.scale = 0.125f;
-        WSEG_TRY(gemm(m, EPI_SCALE, a_op, d, L.cq_w, d, R, d, d, e, &p, s));
+        WSEG_TRY(gemm(m, EPI_SCALE, a_op, d, L.cq_w, d, R, d, d, e, &p, s, nullptr, PR));
         WSEG_TRY(launch_dec_cross_attn(gdt, st, p.dq, p.ck + l * cross_stride, p.cv + l * cross_stride, p.dattn, H, Tk, d, nullptr, nullptr, 0.125f, s,
                                        pp ? pp->slots : nullptr));
       }
@@ -383,7 +389,7 @@ int run_decoder_step(wseg_model* m, DecPlan& p, char* mxa, bool want_logits, hip
     WSEG_TRY(gemm_resid_ln(p.dattn, d, L.co_w, L.co_b, L.ln3_g, L.ln3_b, dec_cross_attn_writes_mx(gdt, st.nb)));      // x += cross Wo ; y = LN3(x)
     e = EpiParams();
     e.bias = L.fc1_b; e.out = p.dh; e.ldc = ffn;
-    WSEG_TRY(gemm(m, EPI_GELU, p.dy, d, L.fc1_w, d, R, ffn, d, e, &p, s));
+    WSEG_TRY(gemm(m, EPI_GELU, p.dy, d, L.fc1_w, d, R, ffn, d, e, &p, s, nullptr, PR));
     const bool last = l + 1 == c.dec_layers;                                                 // x += fc2 ; y = next LN1 / final LN
     WSEG_TRY(gemm_resid_ln(p.dh, ffn, L.fc2_w, L.fc2_b, last ? m->dec_ln_g : m->dec[l + 1].ln1_g,
                            last ? m->dec_ln_b : m->dec[l + 1].ln1_b, dh_mx));
@@ -396,7 +402,7 @@ int run_decoder_step(wseg_model* m, DecPlan& p, char* mxa, bool want_logits, hip
   if (pp && pp->logits) {      // rows i * np + (np - 1) of the final LayerNorm: row stride np operand rows (es bytes per logical element)
     e = EpiParams();
     e.out_f32 = (float*)p.logits; e.ldc = m->vp;
-    WSEG_TRY(gemm(m, EPI_F32, p.dy + (size_t)(pp->np - 1) * d * m->es, pp->np * d, m->dec_tok, d, pp->n, m->vp, d, e, nullptr, s));
+    WSEG_TRY(gemm(m, EPI_F32, p.dy + (size_t)(pp->np - 1) * d * m->es, pp->np * d, m->dec_tok, d, pp->n, m->vp, d, e, nullptr, s, nullptr, PR));
   }
   return WSEG_OK;
 }
@@ -413,7 +419,6 @@ extern "C" int wseg_model_create(const wseg_model_config* cfg, wseg_model** out)
   m->es = (cfg->dtype == WSEG_BF16 || cfg->dtype == WSEG_F16) ? 2 : 4;
   m->x3 = cfg->dtype == WSEG_BF16X3 || cfg->dtype == WSEG_F16X3 || cfg->dtype == WSEG_F16M6;
   m->mx = cfg->dtype == WSEG_F16M6;
-  m->attn_hi = m->mx && WSEG_KNOB_SET("WSEG_ATTN_HI");      // experiment knob, off: 19x the logit error at 32 layers
   m->sdt = storage_dtype(cfg->dtype);
   m->ckv_es = m->es;
   m->kp1 = (int)align_up((size_t)3 * cfg->n_mels, 64);
@@ -714,13 +719,13 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
       if (units_in_use > stats.kv_units_peak) stats.kv_units_peak = units_in_use;
       WSEG_TRY(h2d_list(ln, tmp_b.data(), (int)tmp_b.size(), q.kv_pairs, s));
       WSEG_TRY(launch_kv_assign(q.kv_pt, q.kv_pairs, n, s));
-      const int chunk = q.row_cap / NPF;
+      const int plan_rows = std::max(S * nb, NPF), chunk = std::max(1, std::min(q.row_cap, plan_rows) / NPF);
       for (int c0 = 0; c0 < n; c0 += chunk) {
         const int nc = std::min(chunk, n - c0);
-        const PromptPass pp = {q.adm_slots + c0, nc, NPF, merged};
+        const PromptPass pp = {q.adm_slots + c0, nc, NPF, merged, plan_rows};
         WSEG_TRY(run_decoder_step(m, q, p.mxa, false, s, &pp));
         if (merged) {
-          if (snap_ok) {      // wseg_debug_first_logits (all windows of the call start together: window i sits in slot i): every beam row of
+          if (snap_ok && stats.n_admissions == 0) {      // wseg_debug_first_logits (all windows of the call start together: window i sits in slot i): every beam row of
             for (int j = 0; j < nb; ++j)      // a window gets the window's row
               WSEG_HIP_CHECK(hipMemcpy2DAsync(q.first_logits + ((size_t)c0 * nb + j) * m->vp * 4, (size_t)nb * m->vp * 4, q.logits, (size_t)m->vp * 4,
                                               (size_t)m->vp * 4, (size_t)nc, hipMemcpyDeviceToDevice, s));

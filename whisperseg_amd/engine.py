@@ -363,7 +363,7 @@ class Engine:
             try:
                 self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             except torch.OutOfMemoryError as exc:
-                raise _lib.WsegError(
+                raise _lib.WsegOutOfMemory(
                     f"cannot allocate the {need / 2 ** 30:.1f}-GiB decode workspace for {n_slots} window slots on {self.device} (the slot "
                     "count is derived from the device's TOTAL memory so that results never depend on what else is resident; "
                     "lower it with segmenter.max_slots / $WSEG_SLOTS when the GPU is shared)") from exc
@@ -421,21 +421,30 @@ class Engine:
         max_length = int(min(max_length, self.geo["dec_positions"]))
         with torch.cuda.device(self.device):
             slots = self.pick_slots(W, num_beams, max_length, n_slots, kv_positions)
+            pinned = n_slots is not None or bool(os.environ.get("WSEG_SLOTS"))
+            self.slots_halved = 0
             while True:
                 try:
                     ws = self._workspace(slots, num_beams, max_length, kv_positions)
                     break
-                except _lib.WsegError:
-                    # The budget ignores other residents of the GPU (a sibling engine, another process).  In the exact and the split
-                    # modes a window's tokens are tested independent of the slot count, so fewer slots is only slower: halve and warn
-                    # (last_stats()["n_slots"] reports what ran).  The plain 16-bit modes' logits follow the row count: there a silent
-                    # change of the slot count could change a recording's rows run to run, so the error stands.
-                    if slots <= 1 or n_slots is not None or self.dtype_name in ("bf16", "f16"):
+                except _lib.WsegOutOfMemory:
+                    # The budget ignores other residents of the GPU (a sibling engine, another process).  Only the allocation failure
+                    # itself is answered with fewer slots (any other error stands), never when the caller pinned the count
+                    # (n_slots / segmenter.max_slots / $WSEG_SLOTS), and only in the exact mode — whose tokens are structurally
+                    # independent of the slot count — and the split modes, where that independence is TESTED on the committed
+                    # geometries (trained models: exact; flat random-weight logits: 4 094 of 4 096 windows, bench `check`), so a
+                    # near-tie may resolve differently: the warning says so and last_stats() records it (n_slots, slots_halved).
+                    # The plain 16-bit modes' logits follow the row count visibly: there the error stands.
+                    if slots <= 1 or pinned or self.dtype_name in ("bf16", "f16"):
                         raise
                     import warnings
                     warnings.warn(f"decode workspace for {slots} window slots does not fit beside the GPU's other allocations: "
-                                  f"retrying with {(slots + 1) // 2} slots (tokens do not depend on the slot count in mode {self.dtype_name})")
+                                  f"retrying with {(slots + 1) // 2} slots (mode {self.dtype_name}: the GEMM plans follow the slot count; "
+                                  + ("tokens are unaffected" if self.dtype_name == "f32" else
+                                     "tokens are tested equal on the committed geometries, a near-tie between two hypotheses may still resolve differently")
+                                  + "; pin the count with max_slots / $WSEG_SLOTS for run-to-run identical plans)")
                     slots = (slots + 1) // 2
+                    self.slots_halved += 1
         sup = torch.tensor(list(suppress_tokens) or [0], dtype=torch.int32, device=self.device)
         bsup = torch.tensor(list(begin_suppress_tokens) or [0], dtype=torch.int32, device=self.device)
         gp = _lib.GenerateParams()
@@ -482,6 +491,7 @@ class Engine:
         st = _lib.GenerateStats()
         _lib.check(self.lib.wseg_last_stats(self.handle, C.byref(st)))
         out = {k: int(getattr(st, k)) for k, _ in st._fields_ if not k.endswith("_")}
+        out["slots_halved"] = int(getattr(self, "slots_halved", 0))      # times generate() halved the slot count after an allocation failure
         out["occupancy"] = out["slot_steps_active"] / max(1, out["slot_steps_total"])
         out["steady_occupancy"] = out["queued_slot_steps_active"] / max(1, out["queued_slot_steps_total"])
         return out
