@@ -250,6 +250,129 @@ def make_backend(args, device):
     return lib, eng, lambda sr, sts: get_feature_extractor(sr, sts, 0, 30, 1000, device)
 
 
+def make_segmenter(args, eng):
+    """The public segmenter class over the bench's engine (seeded random weights, the synthetic tokenizer above)."""
+    from whisperseg_amd.model import WhisperSegmenterForEval
+    eng.hf_config = dict(hf_config(args.model), cluster_codebook={str(i): i for i in range(10)})
+    seg = WhisperSegmenterForEval(model=eng, tokenizer=fake_tokenizer())
+    seg.suppress_tokens, seg.begin_suppress_tokens = SUPPRESS, BEGIN_SUPPRESS
+    return seg
+
+
+def dist_configs(args, seg, rank, world, device):
+    """BASELINE configs[3] and configs[4] AS WRITTEN, through the product's own multi-GPU entry points (whisperseg_amd/dist.py; the
+    fan-out they re-express is reference model.py:169-189).  EVERY rank calls this (the entry points are collective):
+
+      configs[3]  one synthetic one-hour recording (120 x 30 s windows) through dist.segment_distributed — rank 0's PCM is broadcast,
+                  every rank decodes its contiguous ceil(N / world) windows, the token ids are all-gathered;
+      configs[4]  a clip batch of 64 recordings (256 windows of 30 s) cycling through the 16 / 32 / 48 kHz front-end configurations through
+                  dist.segment_batch_distributed — metadata broadcast, PCM point-to-point to the ranks that read it, one pooled decode
+                  per rank, all-gather of the token ids.
+
+    STRONG scaling (the work is fixed, a rank's share shrinks with the world size: 15 and 32 windows per GPU at world 8) — labelled so;
+    the headline above stays weak scaling.  Each entry is checked: rank 0 afterwards decodes, ALONE and without collectives, every
+    rank's shard of the same windows (same shard sizes, hence the same GEMM plans) and the gathered token ids must be identical."""
+    import torch.distributed as td
+    from whisperseg_amd import dist as wdist
+    from whisperseg_amd.windows import window_table
+    on_gpu = device.type == "cuda"
+    sts, beams = args.spec_time_step, args.beams
+    gen = dict(max_length=3 + args.gen_tokens, num_beams=beams)
+    cols = seg.total_spec_columns
+    live = td.is_available() and td.is_initialized()
+
+    def barrier():
+        if live:
+            td.barrier()
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    captured = []
+    orig = seg.tokens_to_texts
+
+    def tap(tokens, lengths):      # after gather_rows every rank holds the token ids of ALL windows of the call / group
+        captured.append((np.array(tokens), np.array(lengths)))
+        return orig(tokens, lengths)
+
+    def timed(fn):
+        fn()                       # workspace, step graph and communicator warm-up
+        barrier()
+        captured.clear()
+        t0 = time.perf_counter()
+        res = fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if live:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+            td.all_reduce(tmax, op=td.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, res
+
+    def alone(pooled, n_total):
+        """rank 0, no collectives: every rank's shard decoded separately -> (tokens, lengths) in window order"""
+        parts = []
+        for r in range(world):
+            lo, hi = wdist.my_shard(n_total, r, world)
+            if hi > lo:
+                t, l = seg.decode_shard_tokens(pooled[lo:hi], **wdist._decode_kwargs(gen))
+                parts.append((t.cpu().numpy(), l.cpu().numpy()))
+        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+    def same(a, b):
+        return bool(a[0].shape == b[0].shape and np.array_equal(a[1], b[1])
+                    and all(np.array_equal(a[0][i, :a[1][i]], b[0][i, :b[1][i]]) for i in range(len(a[1]))))
+
+    out = []
+    seg.tokens_to_texts = tap
+    try:
+        # ---- configs[3]: the windows of ONE recording over the ranks ---------------------------------------------------------
+        sr3, n3 = 16000, args.dist3_windows
+        wl3 = int(cols * sts * sr3)
+        hour = synth_pcm(n3, wl3, sr3, seed=9) if rank == 0 else None
+        dt, pred = timed(lambda: wdist.segment_distributed(seg, hour, sr3, spec_time_step=sts, min_frequency=0, **gen))
+        n_total = len(window_table(n3 * wl3, sr3, sts, 1, cols))
+        entry = {"config": "configs[3] whisperseg-%s %s, one recording of %d x %.0f s windows clip-sharded across %d rank(s)"
+                           % (args.model, args.dtype, n3, cols * sts, world),
+                 "entry_point": "whisperseg_amd.dist.segment_distributed", "scaling": "strong", "windows": n_total,
+                 "windows_per_rank": [hi - lo for lo, hi in (wdist.my_shard(n_total, r, world) for r in range(world))],
+                 "audio_sec_per_s": n3 * cols * sts / dt, "seconds": dt, "segments": len(pred["onset"]),
+                 "collectives": "broadcast (PCM), all_gather (token ids + lengths)"}
+        if rank == 0:
+            got = captured[-1]
+            pcm = torch.as_tensor(hour).to(device)
+            pooled = seg.sliced_features_from_device_pcm(pcm, sr3, 0, sts, 1, window_range=(0, n_total))["shard"]
+            entry["tokens_equal_to_rank0_alone"] = same(got, alone(pooled, n_total))
+            del pooled, pcm
+        out.append(entry)
+        # ---- configs[4]: a mixed-rate clip batch, its POOLED window list over the ranks ----------------------------------------
+        rates = (16000, 32000, 48000)
+        n_rec, per_rec = max(1, args.dist4_windows // 4), 4
+        srs = [rates[i % 3] for i in range(n_rec)]
+        audios = [synth_pcm(per_rec, int(cols * sts * sr), sr, seed=100 + i) for i, sr in enumerate(srs)] if rank == 0 else None
+        dt, preds = timed(lambda: wdist.segment_batch_distributed(seg, audios, srs if rank == 0 else None, spec_time_step=sts,
+                                                                  min_frequency=0, **gen))
+        counts = [len(window_table(per_rec * int(cols * sts * sr), sr, sts, 1, cols)) for sr in srs]
+        n_total = int(sum(counts))
+        entry = {"config": "configs[4] whisperseg-%s %s, clip batch of %d recordings (%d x %.0f s windows, 16 / 32 / 48 kHz front-ends "
+                           "round-robin) partitioned across %d rank(s)" % (args.model, args.dtype, n_rec, n_total, cols * sts, world),
+                 "entry_point": "whisperseg_amd.dist.segment_batch_distributed", "scaling": "strong", "windows": n_total,
+                 "windows_per_rank": [hi - lo for lo, hi in (wdist.my_shard(n_total, r, world) for r in range(world))],
+                 "audio_sec_per_s": n_total * cols * sts / dt, "seconds": dt, "segments": int(sum(len(p["onset"]) for p in preds)),
+                 "collectives": "broadcast_object_list (metadata), send / recv (PCM), all_gather (token ids + lengths)"}
+        if rank == 0:
+            got = (np.concatenate([c[0] for c in captured]), np.concatenate([c[1] for c in captured]))
+            pooled = []
+            for a, sr, c in zip(audios, srs, counts):
+                pcm = torch.as_tensor(a).to(device)
+                pooled += seg.sliced_features_from_device_pcm(pcm, sr, 0, sts, 1, window_range=(0, c))["shard"]
+            entry["tokens_equal_to_rank0_alone"] = same(got, alone(pooled, n_total))
+            del pooled
+        out.append(entry)
+    finally:
+        seg.tokens_to_texts = orig
+    return out
+
+
 def self_launch(args, argv):
     """`python bench.py --gpus N` outside torchrun: start N ranks in a FRESH child (nothing in this process has touched
     the GPU yet) and relay its output and exit code."""
@@ -291,6 +414,9 @@ def main(argv=None, backend=make_backend):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-dist-configs", action="store_true", help="world > 1: skip the configs[3] / configs[4] lines (dist_configs)")
+    ap.add_argument("--dist3-windows", type=int, default=120, help="windows of the one recording of configs[3] (120 = one hour at 30 s)")
+    ap.add_argument("--dist4-windows", type=int, default=256, help="windows of the clip batch of configs[4]")
     ap.add_argument("--device", default="cuda", help=argparse.SUPPRESS)      # tests drive the distributed logic on "cpu" with a stub backend
     ap.add_argument("--check-on-cpu", action="store_true", help=argparse.SUPPRESS)   # ... including the self-check branch
     args = ap.parse_args(argv)
@@ -308,7 +434,9 @@ def main(argv=None, backend=make_backend):
     device = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
     if on_gpu:
         torch.cuda.set_device(device)
-    lib, eng, make_extractor = backend(args, device)
+    made = backend(args, device)
+    lib, eng, make_extractor = made[:3]
+    segmenter_of = made[3] if len(made) > 3 else (lambda: make_segmenter(args, eng))      # (the CPU tests hand in a stand-in)
     distributed = world > 1 or torch.distributed.is_initialized()
 
     def sync():
@@ -391,6 +519,18 @@ def main(argv=None, backend=make_backend):
         torch.distributed.all_gather_object(ranks, me)
         ranks_seen = torch.distributed.get_world_size()      # the size of the group the collectives above actually ran in
 
+    # BASELINE configs[3] / configs[4] as written, through the product's own multi-GPU entry points: on every rank (collective), after the
+    # headline is timed.  (WSEG_FORCE_DIST=1 initialises the group at world size 1 too: the GPU box's single-rank first contact.)
+    dist_cfg = None
+    if distributed and not args.no_dist_configs:
+        try:
+            dist_cfg = dist_configs(args, segmenter_of(), rank, world, device)
+        except Exception as exc:
+            if world > 1:      # a rank that leaves a collective sequence early would hang the others: fail the whole job loudly
+                raise
+            dist_cfg = {"error": f"{type(exc).__name__}: {exc}"[:500]}
+        eng.release_workspace() if hasattr(eng, "release_workspace") else None
+
     roofline = None
     if on_gpu and not args.no_roofline and args.dtype != "f32":
         roofline = roofline_leg(args, lib, step, W, world, windows_per_s, enc_f + ckv_f + dec_f)
@@ -433,6 +573,8 @@ def main(argv=None, backend=make_backend):
                                               "windows_differing": int(round((1.0 - agree) * extra["inflight_batching"]["windows"]))}
             check["ok"] = bool(check["ok"] and agree >= need)
     failed = bool(check and not check["ok"])
+    if isinstance(dist_cfg, list) and any(e.get("tokens_equal_to_rank0_alone") is False for e in dist_cfg):
+        failed = True
     if rank == 0:
         out = {
             "metric": "audio-sec/s segmented (whisperseg-large, 30 s windows)" if args.model == "large"
@@ -464,7 +606,9 @@ def main(argv=None, backend=make_backend):
             "roofline": roofline, "cpu_baseline": cpu, "check": check,
             # the r01 / r02 headline workload (256 windows through 256 slots) in the SAME mode, as a second top-level value
             "step_256_windows": (extra or {}).get("step_256_windows"),
-            "extra": extra,
+            # world > 1: BASELINE configs[3] / configs[4] through dist.segment_distributed / dist.segment_batch_distributed (strong scaling)
+            "dist_configs": dist_cfg,
+            "extra": extra if extra is not None else ({"dist_configs": dist_cfg} if dist_cfg is not None else None),
         }
         try:      # libraries (RCCL's version banner) write to C stdio: flush it first so that the JSON line is the last line
             C.CDLL(None).fflush(None)
@@ -525,7 +669,7 @@ def roofline_leg(args, lib, step, W, world, windows_per_s, flops_window):
 def self_check(args, eng, step, main_in, hashes, W):
     """The timed configuration must be right, not only fast.
     (1) determinism: every warm-up / timed step saw the same input, so all token digests must be equal;
-    (2) the same kernels in exact-parity f32 mode (VALU GEMM, fmaf chains) on the SAME bf16-rounded weights decode a subset
+    (2) the same kernels in exact-parity f32 mode (GEMMs on the fp32 matrix cores = k-ordered fmaf chains) on the SAME weight values decode a subset
         of the windows alone: first-step logits must agree (cosine >= 0.999 per row, max |diff| <= 10 % of the logit
         scale — the bf16 tolerance of tests/test_model_gpu.py), beams of a window must be identical at the first step;
         token agreement is reported (random weights give nearly flat logits, so bf16 rounding may legitimately flip an
@@ -745,7 +889,10 @@ def extra_lines(args, eng, step, main_in, make_extractor, device, W, slots):
         return {"config": label, "windows": n, "audio_sec_per_s": n * 1000 * args.spec_time_step / dt, "ms_per_call": dt * 1e3,
                 "encoder_ms": enc_ms, "cross_kv_ms": ckv_ms, "decode_ms": dec_ms, "decode_ms_per_step": dec_ms / max(n_steps, 1)}
     cfgs = [config_line(eng, 8, f"configs[2] whisperseg-large {args.dtype}, 8 windows"),
-            config_line(eng, 120, f"configs[3] whisperseg-large {args.dtype}, 120 windows (1 h recording), one GPU")]
+            config_line(eng, 120, f"configs[3] whisperseg-large {args.dtype}, 120 windows (1 h recording), one GPU"),
+            # the per-GPU shares of the 8-GPU configurations (what one rank of dist.segment_distributed / segment_batch_distributed decodes)
+            config_line(eng, 15, f"configs[3] share of one of 8 GPUs: whisperseg-large {args.dtype}, 15 windows"),
+            config_line(eng, 32, f"configs[4] share of one of 8 GPUs: whisperseg-large {args.dtype}, 32 windows")]
     try:
         from whisperseg_amd.engine import Engine
         base = Engine.random(hf_config("base"), device, args.dtype, seed=0)

@@ -42,8 +42,16 @@ class StubEngine:
         return (0.0, 0.0, 0.0, 0.0)
 
 
+def stub_segmenter():
+    """dist_configs (BASELINE configs[3] / configs[4] through whisperseg_amd.dist): the CPU stand-in segmenter of tests/test_dist_cpu.py —
+    window table, sharding, collectives and parse are the product's, only the decode is a pure function of the window content."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_dist_cpu import FakeSegmenter
+    return FakeSegmenter()
+
+
 def backend(args, device):
-    return None, StubEngine(device), lambda sr, sts: StubExtractor()
+    return None, StubEngine(device), lambda sr, sts: StubExtractor(), stub_segmenter
 
 
 if __name__ == "__main__":

@@ -44,11 +44,12 @@ WINDOW_TABLE_CASES = [  # sr, sts, n_samples, num_trials
 ]
 
 
-def tiny_recording(seed, n_windows=3, tail=0.37):
-    """Concatenated synthetic tone-burst clips (tools/tiny_model.synth_clip) -> a multi-window recording."""
+def tiny_recording(seed, n_windows=3, tail=0.37, variant="tiny"):
+    """Concatenated synthetic tone-burst clips (tools/tiny_model.synth_clip) -> a multi-window recording.
+    variant: the signal family of the fixture model the recording is for (tools/tiny_model.VARIANTS)."""
     from tools import tiny_model as TM
     rng = np.random.default_rng(seed)
-    parts = [TM.synth_clip(rng)[0] for _ in range(n_windows)]
+    parts = [TM.synth_clip(rng, variant=variant)[0] for _ in range(n_windows)]
     x = np.concatenate(parts)
     cut = int(len(parts[-1]) * (1.0 - tail))
     return x[: len(x) - cut].astype(np.float32)

@@ -12,7 +12,23 @@ from conftest import ROOT
 
 DRIVER = os.path.join(ROOT, "tests", "bench_stub_driver.py")
 ARGS = ["--device", "cpu", "--steps", "2", "--warmup", "1", "--windows", "5", "--model", "tiny", "--gen-tokens", "5",
-        "--sr", "16000", "--spec-time-step", "0.001", "--no-cpu-baseline"]
+        "--sr", "16000", "--spec-time-step", "0.001", "--no-cpu-baseline", "--dist3-windows", "20", "--dist4-windows", "24"]
+
+
+def check_dist_configs(out, world):
+    """r06: under world > 1 the bench sends BASELINE configs[3] (one recording, its windows over the ranks: dist.segment_distributed) and
+    configs[4] (a mixed-rate clip batch, its pooled window list over the ranks: dist.segment_batch_distributed) through the product's
+    own multi-GPU entry points on every rank, and rank 0 re-decodes every rank's shard alone: the gathered token ids must be identical."""
+    dc = out["dist_configs"]
+    assert isinstance(dc, list) and len(dc) == 2, dc
+    assert out["extra"]["dist_configs"] == dc
+    c3, c4 = dc
+    assert c3["entry_point"].endswith("segment_distributed") and c4["entry_point"].endswith("segment_batch_distributed")
+    per = -(-20 // world)
+    assert c3["windows"] == 20 and c3["windows_per_rank"] == [max(0, min(per, 20 - r * per)) for r in range(world)]
+    assert c4["windows"] == 24 and sum(c4["windows_per_rank"]) == 24 and len(c4["windows_per_rank"]) == world
+    for c in dc:
+        assert c["scaling"] == "strong" and c["tokens_equal_to_rank0_alone"] is True and c["audio_sec_per_s"] > 0 and c["segments"] > 0
 
 
 def clean_env():
@@ -39,6 +55,7 @@ def test_gpus_2_self_launches_two_ranks():
     # whole-job value: 2 ranks x 5 windows x 1 s per step
     assert out["value"] == pytest.approx(2 * 5 * 1.0 * 2 / (out["ms_per_step"] * 2 / 1e3), rel=1e-6)
     assert out["config"]["windows_per_gpu"] == 5
+    check_dist_configs(out, 2)
 
 
 @pytest.mark.timeout(600)
@@ -57,6 +74,7 @@ def test_gpus_8_first_contact_shape():
     assert out["config"]["windows_per_gpu"] == 5 and out["config"]["parallelism"] == "clip-sharded x8"
     assert out["value"] == pytest.approx(8 * 5 * 1.0 * 2 / (out["ms_per_step"] * 2 / 1e3), rel=1e-6)
     assert out["check"]["ok"] and out["check"]["deterministic"]      # the stub decodes 15 + 0 only once rank 0's weights arrived everywhere
+    check_dist_configs(out, 8)      # 20 windows over 8 ranks: 3 3 3 3 3 3 2 0 — the last rank idles through every collective
 
 
 @pytest.mark.timeout(300)
@@ -64,7 +82,7 @@ def test_single_process_default_and_mismatch():
     res = subprocess.run([sys.executable, DRIVER] + ARGS, env=clean_env(), capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr[-3000:]
     out = last_json(res.stdout)
-    assert out["n_gpus"] == 1 and out["world_size"] == 1 and len(out["ranks"]) == 1
+    assert out["n_gpus"] == 1 and out["world_size"] == 1 and len(out["ranks"]) == 1 and out["dist_configs"] is None
     env = clean_env()
     env.update(RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     res = subprocess.run([sys.executable, DRIVER, "--gpus", "1"] + ARGS, env=env, capture_output=True, text=True, timeout=120)

@@ -60,5 +60,42 @@ def test_16_bit_modes_stay_inside_their_measured_envelope(gpu_lib, sweep, dtype)
     assert res["cluster_mismatch_rows"] == 0
 
 
+# ---- the HELD-OUT sweep (r06) -------------------------------------------------------------------------------------
+# 1 000 recordings (250 new seeds x trials {1, 3} x beams {1, 4}) of a second, independently trained fixture model of another shape with
+# full-mantissa fp32 weights (tests/golden/tiny_model2, tools/tiny_model.py variant "tiny2"), rows recorded from the reference by
+# tools/make_golden.py --only sweep2.  No precision format was chosen on it: they were frozen before it was recorded.
+MODEL2_DIR = os.path.join(GOLDEN, "tiny_model2")
+
+
+@pytest.fixture(scope="module")
+def sweep2():
+    with open(os.path.join(GOLDEN, "tiny2_sweep.json")) as f:
+        return json.load(f)
+
+
+def test_heldout_sweep_is_big_enough(sweep2):
+    assert len(sweep2) == 1000
+    assert sum(len(r["expected"]["onset"]) for r in sweep2) >= 4000
+    assert len([r for r in sweep2 if r["kwargs"]["num_trials"] == 3 and r["expected"]["onset"]]) >= 250
+
+
+def test_heldout_f32_mode_reproduces_every_row(gpu_lib, sweep2):
+    from tools.parity_sweep import score
+    from whisperseg_amd.model import WhisperSegmenter
+    res = score(WhisperSegmenter(MODEL2_DIR, device="cuda", device_ids=[0], dtype="f32"), sweep2, "tiny2")
+    assert res["exact_runs"] == len(sweep2), (res["structure_mismatch_runs"][:3], res["beyond_one_frame_runs"][:3])
+
+
+@pytest.mark.parametrize("dtype", ["f16m6", "f16x3", "bf16x3"])
+def test_heldout_split_precision_modes_meet_the_north_star_tolerance(gpu_lib, sweep2, dtype):
+    from tools.parity_sweep import score
+    from whisperseg_amd.model import WhisperSegmenter
+    res = score(WhisperSegmenter(MODEL2_DIR, device="cuda", device_ids=[0], dtype=dtype), sweep2, "tiny2")
+    print(dtype, json.dumps({k: v for k, v in res.items() if not k.endswith("_runs") or isinstance(v, int)}))
+    assert res["structure_mismatch_runs"] == [] and res["beyond_one_frame_runs"] == [], (res["structure_mismatch_runs"][:3], res["beyond_one_frame_runs"][:3])
+    assert res["cluster_mismatch_rows"] == 0
+    assert res["within_tolerance_runs"] == len(sweep2)
+
+
 # runs (of 200) allowed outside "clusters exact, boundaries within +-1 frame"; set from the measured sweeps
 MAX_BAD_RUNS = {"f16": 12, "bf16": 36}      # measured: f16 10 / bf16 28 (r02), f16 8 / bf16 30 (r03: another log-mel kernel moves other near-ties)

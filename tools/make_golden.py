@@ -1,7 +1,7 @@
 """Generate tests/golden/* by running the REFERENCE itself (imported read-only from /root/reference,
 tools/ref_import.py) and its HuggingFace backend in the build container.
 
-    python tools/make_golden.py [--only frontend|windows|parse|tiny]
+    python tools/make_golden.py [--only frontend|windows|parse|tiny|sweep2]
 
 Only inputs (seeds, parameters, hand-written generated texts) and expected outputs are stored — never
 reference source.  The tests regenerate the inputs from tests/golden_inputs.py.
@@ -15,6 +15,7 @@ Files written
   tiny_generate.npz/json  G6/G7 encoder output, first-step logits, token ids and segment() results of the
                        tiny trained model driven through the reference's WhisperSegmenterForEval
   meerkat_5s.wav       first 5 s of a 16 kHz example clip (input data for the CLI plumbing test)
+  tiny2_sweep.json / tiny2_generate.npz   G9 (--only sweep2): the held-out sweep — 1 000 recordings of the second fixture model
 """
 import argparse
 import hashlib
@@ -196,10 +197,11 @@ class FakeTokenizer:
         return ["".join(self.dec.get(int(i), "") for i in row) for row in ids.tolist()]
 
 
-def make_tiny(ref_audio, ref_model):
+def load_fixture_segmenter(ref_model, mdir):
+    """The reference's WhisperSegmenterForEval over a fixture model directory (HF fp32 on the CPU) -> (hf model, segmenter, list that
+    collects the token ids of every generate call)."""
     from safetensors.torch import load_file
     from transformers import WhisperConfig, WhisperForConditionalGeneration
-    mdir = os.path.join(OUT, "tiny_model")
     cd = json.load(open(os.path.join(mdir, "config.json")))
     extra = {k: cd.pop(k) for k in ("total_spec_columns", "cluster_codebook", "default_segmentation_config", "model_type")}
     cfg = WhisperConfig(**cd, suppress_tokens=None, begin_suppress_tokens=None)
@@ -235,6 +237,11 @@ def make_tiny(ref_audio, ref_model):
             return ids
 
     segm = ref_model.WhisperSegmenterForEval(model=Shim(), tokenizer=FakeTokenizer())
+    return hf, segm, captured
+
+
+def make_tiny(ref_audio, ref_model):
+    hf, segm, captured = load_fixture_segmenter(ref_model, os.path.join(OUT, "tiny_model"))
     arrays, meta = {}, []
     runs = [  # seed, n_windows, kwargs
         (100, 3, dict(num_beams=1, num_trials=1, batch_size=4)),
@@ -300,6 +307,34 @@ def make_tiny(ref_audio, ref_model):
         json.dump(meta, f)
 
 
+def make_sweep2(ref_audio, ref_model):
+    """G9, the HELD-OUT parity sweep (r06): the reference's segment() rows for 1 000 recordings — 250 NEW seeds x
+    trials {1, 3} x beams {1, 4} — of a SECOND, independently trained fixture model (tests/golden/tiny_model2: tools/tiny_model.py variant
+    "tiny2" — d 256, 4 heads, 3 + 3 layers, another init seed, another data stream and signal family, full-mantissa fp32 weights).
+    Every precision format of r03-r05 (fp6 cross terms, block-floating-point cross K / V, 24-bit rows, fp32 self-attention cache, ...)
+    was chosen on tiny_sweep.json; nothing was tuned on this file: the formats were frozen (commit before this one) when it was recorded."""
+    hf, segm, captured = load_fixture_segmenter(ref_model, os.path.join(OUT, "tiny_model2"))
+    sweep = []
+    for seed in range(5000, 5250):
+        nw = 1 + seed % 3
+        audio = GI.tiny_recording(seed, nw, variant="tiny2")
+        for trials in (1, 3):
+            for beams in (1, 4):
+                kw = dict(num_beams=beams, num_trials=trials, batch_size=8)
+                sweep.append(dict(seed=seed, n_windows=nw, kwargs=kw, expected=segm.segment(audio, TM.SR, **kw)))
+        print("sweep2 seed", seed, [len(r["expected"]["onset"]) for r in sweep[-4:]], flush=True)
+    with open(os.path.join(OUT, "tiny2_sweep.json"), "w") as f:
+        json.dump(sweep, f)
+    # first-step logits of 4 windows (pins the oracle / the engines on this model's geometry as G6 does for the first model)
+    audio = GI.tiny_recording(5000, 3, variant="tiny2")
+    sliced = segm.get_sliced_audios_features(audio, TM.SR, 0, TM.STS, 1)
+    feats = torch.from_numpy(np.asarray([s[2] for s in sliced]))
+    with torch.no_grad():
+        enc = hf.model.encoder(feats).last_hidden_state
+        logits = hf(input_features=feats, decoder_input_ids=torch.tensor([TM.PROMPT] * feats.shape[0])).logits[:, -1]
+    np.savez_compressed(os.path.join(OUT, "tiny2_generate.npz"), enc_out_sample=enc.numpy()[:, ::25, :], first_logits=logits.numpy())
+
+
 def make_wav():
     import struct
     src = "/root/reference/data/example_subset/Meerkat/test/VALP007_AL_6_15DEC2022_MF_ML.wav"
@@ -321,7 +356,7 @@ def main():
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     ref_audio, ref_model = import_reference()
-    steps = dict(frontend=make_frontend, windows=make_windows, parse=make_parse, tiny=make_tiny)
+    steps = dict(frontend=make_frontend, windows=make_windows, parse=make_parse, tiny=make_tiny, sweep2=make_sweep2)
     for name, fn in steps.items():
         if args.only in (None, name):
             print("==", name)

@@ -2,7 +2,10 @@
 200 recordings (50 seeds x trials {1, 3} x beams {1, 4}) of the tiny trained model, expected rows recorded by driving HF fp32
 through the reference's WhisperSegmenterForEval (tools/make_golden.py, G8).
 
-    python tools/parity_sweep.py [out.json]          (needs the GPU)
+    python tools/parity_sweep.py [out.json] [modes ...]          (needs the GPU)
+    python tools/parity_sweep.py --sweeps profiles/r06_parity_sweeps.json      both sweeps (r06): the 200 recordings above AND the held-out
+                                 1 000 recordings of the second fixture model (tests/golden/tiny2_sweep.json, tiny_model2) in every mode;
+                                 bench.py reads its `parity` strings from the committed file
 
 Per dtype: runs whose rows have the same count and clusters as the reference's ("structure"), the histogram of boundary
 deviations in mel frames (spec_time_step units) over all rows of those runs, and the list of runs outside the north-star
@@ -20,9 +23,11 @@ import golden_inputs as GI  # noqa: E402
 from tools import tiny_model as TM  # noqa: E402
 
 MODEL_DIR = os.path.join(ROOT, "tests", "golden", "tiny_model")
+# name -> (rows recorded from the reference, fixture model directory, signal family of its recordings)
+SWEEPS = {"sweep1": ("tiny_sweep.json", "tiny_model", "tiny"), "sweep2_heldout": ("tiny2_sweep.json", "tiny_model2", "tiny2")}
 
 
-def score(seg, sweep):
+def score(seg, sweep, variant="tiny"):
     hist = {"0": 0, "<=0.5": 0, "<=1": 0, "<=2": 0, ">2": 0}
     out = dict(runs=len(sweep), rows_expected=0, rows_compared=0, exact_runs=0, within_tolerance_runs=0,
                structure_mismatch_runs=[], beyond_one_frame_runs=[], cluster_mismatch_rows=0, frame_hist=hist, max_dev_frames=0.0)
@@ -30,7 +35,7 @@ def score(seg, sweep):
     for idx, run in enumerate(sweep):
         key = (run["seed"], run["n_windows"])
         if key not in audio_cache:
-            audio_cache[key] = GI.tiny_recording(*key)
+            audio_cache[key] = GI.tiny_recording(*key, variant=variant)
         got = seg.segment(audio_cache[key], TM.SR, **run["kwargs"])
         want = run["expected"]
         out["rows_expected"] += len(want["onset"])
@@ -67,8 +72,35 @@ class HybridEngine:
         return self.dec.generate(feats, *a, encoder_output=self.enc.encode(feats), **kw)
 
 
+def summary(r):
+    """The part of a score() result that is committed (run lists cut to their first entries)."""
+    out = {k: v for k, v in r.items() if not k.endswith("_runs") or isinstance(v, int)}
+    out["structure_mismatch_runs"] = len(r["structure_mismatch_runs"])
+    out["beyond_one_frame_runs"] = len(r["beyond_one_frame_runs"])
+    out["first_bad_runs"] = (r["structure_mismatch_runs"] + r["beyond_one_frame_runs"])[:5]
+    return out
+
+
+def both_sweeps(dest, modes):
+    from whisperseg_amd.model import WhisperSegmenter
+    res = {}
+    for name, (rows, mdir, variant) in SWEEPS.items():
+        with open(os.path.join(ROOT, "tests", "golden", rows)) as f:
+            sweep = json.load(f)
+        for dtype in modes:
+            seg = WhisperSegmenter(os.path.join(ROOT, "tests", "golden", mdir), device="cuda", device_ids=[0], dtype=dtype)
+            r = summary(score(seg, sweep, variant))
+            res.setdefault(dtype, {})[name] = r
+            print(name, dtype, "runs", r["runs"], "exact", r["exact_runs"], "within +-1 frame", r["within_tolerance_runs"], "hist", r["frame_hist"], flush=True)
+            del seg
+    with open(dest, "w") as f:
+        json.dump(res, f, indent=1)
+
+
 def main():
     from whisperseg_amd.model import WhisperSegmenter
+    if len(sys.argv) > 1 and sys.argv[1] == "--sweeps":
+        return both_sweeps(sys.argv[2], sys.argv[3:] or ["f32", "f16m6", "f16x3", "bf16x3", "f16", "bf16"])
     with open(os.path.join(ROOT, "tests", "golden", "tiny_sweep.json")) as f:
         sweep = json.load(f)
     res = {}
