@@ -116,3 +116,51 @@ def test_generate_rejects_bad_requests(gpu_lib):
     # encode: zero windows is a no-op, null output is rejected
     assert lib.wseg_encode(eng.handle, feats.data_ptr(), 0, ws.data_ptr(), ws.numel(), toks.data_ptr(), _lib.stream_ptr()) == 0
     assert lib.wseg_encode(eng.handle, feats.data_ptr(), W, ws.data_ptr(), ws.numel(), None, _lib.stream_ptr()) == INVALID
+
+
+@pytest.mark.gpu
+def test_only_an_allocation_failure_halves_the_slot_count(gpu_lib, monkeypatch):
+    """Engine.generate answers ONLY the allocation failure of the decode workspace (WsegOutOfMemory) with fewer slots — with a
+    warning, recorded in last_stats() — and never when the caller pinned the count (n_slots / $WSEG_SLOTS), never in the plain 16-bit
+    modes (their tokens follow the row count), never for another error (a rejected request used to be retried down to 1 slot)."""
+    import warnings
+    from whisperseg_amd import _lib
+    from whisperseg_amd.engine import Engine
+    from tools import tiny_model as TM
+    mdir = os.path.join(GOLDEN, "tiny_model")
+    x = torch.randn(12, 80, 1000, device="cuda") * 0.3
+    kw = dict(max_length=12, num_beams=2, suppress_tokens=TM.SUPPRESS, begin_suppress_tokens=TM.BEGIN_SUPPRESS)
+
+    def failing(engine, limit, exc):
+        real = engine._workspace
+
+        def ws(n_slots, *a, **k):
+            if n_slots > limit:
+                raise exc
+            return real(n_slots, *a, **k)
+        return ws
+
+    eng = Engine.from_pretrained(mdir, "cuda:0", "f16m6")
+    want, want_l = eng.generate(x, TM.PROMPT, TM.EOT, TM.EOT, **kw)
+    monkeypatch.delenv("WSEG_SLOTS", raising=False)
+    monkeypatch.setattr(eng, "_workspace", failing(eng, 3, _lib.WsegOutOfMemory("cannot allocate")))
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        got, got_l = eng.generate(x, TM.PROMPT, TM.EOT, TM.EOT, **kw)
+    st = eng.last_stats()
+    assert st["n_slots"] == 3 and st["slots_halved"] == 2                      # 12 -> 6 -> 3
+    assert len(caught) == 2 and "near-tie" in str(caught[0].message)
+    assert torch.equal(got, want) and torch.equal(got_l, want_l)                # the trained model: tokens independent of the slot count
+    with pytest.raises(_lib.WsegOutOfMemory):                                   # pinned by the caller
+        eng.generate(x, TM.PROMPT, TM.EOT, TM.EOT, n_slots=12, **kw)
+    monkeypatch.setenv("WSEG_SLOTS", "12")
+    with pytest.raises(_lib.WsegOutOfMemory):                                   # pinned through the environment
+        eng.generate(x, TM.PROMPT, TM.EOT, TM.EOT, **kw)
+    monkeypatch.delenv("WSEG_SLOTS")
+    monkeypatch.setattr(eng, "_workspace", failing(eng, 3, _lib.WsegError("wseg_workspace_bytes rejected the request")))
+    with pytest.raises(_lib.WsegError, match="rejected"):                       # not an allocation failure: no retry
+        eng.generate(x, TM.PROMPT, TM.EOT, TM.EOT, **kw)
+    plain = Engine.from_pretrained(mdir, "cuda:0", "bf16")
+    monkeypatch.setattr(plain, "_workspace", failing(plain, 3, _lib.WsegOutOfMemory("cannot allocate")))
+    with pytest.raises(_lib.WsegOutOfMemory):                                   # plain 16-bit mode: the error stands
+        plain.generate(x, TM.PROMPT, TM.EOT, TM.EOT, **kw)

@@ -5,7 +5,8 @@
     bench's row count: 256x256 ping-pong encoder tiles, the 1024-row decode plans, the 51 968-wide LM head) — windows are
     independent, so the oracle is run on a subset of the 256 windows.
 (b) the full 32 + 32 layers at 8 and 120 windows through size-independent properties: determinism, window-permutation
-    equivariance, beams equal at the first step, bf16 first-step logits vs the exact-parity f32 mode of the same kernels.
+    equivariance, beams equal at the first step, bf16 first-step logits vs the exact-parity f32 mode of the same kernels; the split
+    modes at 16 windows against the f32 mode: logits, and whole beam sequences equal or oracle-scored near-ties.
 Tolerances: f32 mode 1e-3 abs on logits and token-exact; bf16 cosine >= 0.999 per logit row and 10 % of the logit scale
 (bf16 has 8 mantissa bits; same class as tests/test_model_gpu.py)."""
 import numpy as np
@@ -231,34 +232,52 @@ def test_full_large_properties(gpu_lib, full_large, n, dt):
     assert torch.equal(tp, toks[perm]) and torch.equal(lp, lens[perm])
 
 
-@pytest.mark.parametrize("dt,rel", [("f16x3", 1e-4), ("bf16x3", 5e-4), ("f16m6", 5e-4)])
-def test_full_large_split_precision_vs_f32_mode(gpu_lib, full_large, dt, rel):
-    """32 + 32 layers: the split-precision modes (product default f16m6; f16x3, bf16x3) against the exact-parity f32 mode on the same
-    fp32 weights: encoder output and first-step logits within rel x scale (measured 2.8e-5 / 1.1e-4 / 3.0e-4 of the logit scale,
-    profiles/r03_logit_error.txt, r04_logit_error.txt: the margin histogram of the parity sweep has 8 decisions below 1e-4), greedy
-    first-step decisions equal up to ties, beam-search results equal for at least 3 of 4 windows (see below)."""
+@pytest.fixture(scope="module")
+def full_large_f32():
+    """32 + 32 layers with FULL-MANTISSA fp32 weights in HF naming (so that the CPU oracle can score hypotheses on exactly the values the
+    engines compute with), the exact-parity f32 engine over them and its decode of 16 windows."""
     from whisperseg_amd.engine import Engine
-    w32 = {k: v.float() for k, v in full_large.weights.items()}
-    f32 = Engine(full_large.geo, w32, full_large.device, "f32")
+    cfg = large_cfg(32)
+    rc = R.RefConfig.from_hf_dict(cfg)
+    sd = R.random_state_dict(rc, seed=5, fast=True)
+    f32 = Engine.from_state_dict(sd, cfg, "cuda:0", "f32")
+    x = feats(16, seed=33)
+    t32, l32, g32 = (t.cpu() for t in gen(f32, x, 4, 12, return_first_logits=True))
+    return cfg, rc, sd, f32, x, t32, l32, g32
+
+
+@pytest.mark.parametrize("dt,rel", [("f16x3", 1e-4), ("bf16x3", 5e-4), ("f16m6", 5e-4)])
+def test_full_large_split_precision_vs_f32_mode(gpu_lib, full_large_f32, dt, rel):
+    """32 + 32 layers, 16 windows: the split-precision modes (product default f16m6; f16x3, bf16x3) against the exact-parity f32 mode on the
+    same fp32 weights.  Encoder output and first-step logits within rel x scale (measured 2.8e-5 / 1.1e-4 / 3.0e-4 of the logit scale).
+    WHOLE beam-search results (12 positions, 4 beams): identical to the f32 mode's, or — these are random weights, their distributions are
+    flat and hypotheses whose total scores tie to ~1e-4 exist — a hypothesis the CPU ORACLE scores the same as the f32 mode's choice to
+    within the mode's own measured logit error (r06, VERDICT r05 item 1b: the differing windows are ASSERTED near-ties through
+    oracle.whisper_ref.score_sequence on the fp32 weights, as assert_equally_scored does at 2 layers; anything else fails).  At most a
+    quarter of the windows may differ at all."""
+    cfg, rc, sd, f32, x, t32, l32, g32 = full_large_f32
     x3 = f32.sibling(dt)
-    x = feats(4, seed=21)
-    e3, e32 = x3.encode(x.cuda()).float(), f32.encode(x.cuda())
+    e3, e32 = x3.encode(x[:4].cuda()).float(), f32.encode(x[:4].cuda())
     assert (e3 - e32).abs().max().item() <= rel * max(1.0, e32.abs().max().item())
-    t3, l3, g3 = gen(x3, x, 4, 12, return_first_logits=True)
-    t32, l32, g32 = gen(f32, x, 4, 12, return_first_logits=True)
+    t3, l3, g3 = (t.cpu() for t in gen(x3, x, 4, 12, return_first_logits=True))
+    err = (g3 - g32).abs().max().item()
     bound = rel * max(1.0, g32.abs().max().item())
-    assert (g3 - g32).abs().max().item() <= bound
-    # Decisions.  Greedy choice of every beam row at the first step: equal, or — these are random weights, their logits are nearly flat —
-    # a tie in the f32 mode's OWN logits to within twice the asserted logit error.  Whole beam-search results (12 positions, 4 beams over
-    # those flat distributions: hypotheses whose total scores tie to ~1e-4 exist, and which one wins follows the last bits of every step):
-    # identical for at least three of the four windows.  (r05: one window's winner changed when the cross K / V storage changed while the
-    # measured logit error did not move — tools/logit_error.py: 3.0e-4 before and after, 8 / 8 sequences on its own seeds; what decides
-    # parity on REAL margins is the 200-recording sweep, tests/test_parity_sweep_gpu.py.)
+    assert err <= bound, (err, bound)
+    # greedy choice of every beam row at the first step: equal, or a tie in the f32 mode's OWN logits to within twice the asserted error
     a3, a32 = g3.argmax(dim=1), g32.argmax(dim=1)
     for r_ in (a3 != a32).nonzero().flatten().tolist():
         assert abs(float(g32[r_, a3[r_]] - g32[r_, a32[r_]])) <= 2 * bound, (r_, int(a3[r_]), int(a32[r_]))
-    same = sum(int(torch.equal(t3[w_], t32[w_]) and int(l3[w_]) == int(l32[w_])) for w_ in range(t3.shape[0]))
-    assert same >= t3.shape[0] - 1, same
+    n = t3.shape[0]
+    differing = [w_ for w_ in range(n) if not (torch.equal(t3[w_], t32[w_]) and int(l3[w_]) == int(l32[w_]))]
+    print(dt, "first-step logit error", err, "windows whose beam result differs from the f32 mode:", differing)
+    assert len(differing) <= n // 4, differing
+    # A hypothesis score is a mean of log-probabilities, each of which moves by at most ~2 x the logit error (the logit and the
+    # log-sum-exp): two hypotheses may swap when the oracle's scores are within 4 x the mode's measured error.
+    tie = 4 * max(err, 2e-5)
+    for w_ in differing:
+        s_got = R.score_sequence(sd, rc, x[w_:w_ + 1], gp(4, 12), t3[w_, :int(l3[w_])].tolist())
+        s_want = R.score_sequence(sd, rc, x[w_:w_ + 1], gp(4, 12), t32[w_, :int(l32[w_])].tolist())
+        assert abs(s_got - s_want) <= tie, (dt, w_, s_got, s_want, tie)
 
 
 def test_full_large_bf16_vs_f32_mode(gpu_lib, full_large):

@@ -66,7 +66,7 @@ def test_slot_refill_gives_the_same_tokens(gpu_lib, dtype, nb):
             # f32: every dot product is one k-ordered chain whatever the plan -> bit-identical.  Split-precision modes (the
             # product default): split-K plans follow the row count, which moves logits by fp32 summation-order noise (~1e-7 of
             # their scale) — four orders of magnitude below the smallest top-1 / top-2 margin of the parity sweep (1e-5,
-            # profiles/r03_precision_study.json "margins") — so the TOKENS must not depend on the slot count 1 / 5 / 8 / 23
+            # profiles/history/r03_precision_study.json "margins") — so the TOKENS must not depend on the slot count 1 / 5 / 8 / 23
             assert torch.equal(l, ref_l) and torch.equal(t, ref_t), (dtype, slots, refill)
         if dtype != "f32":   # 16-bit GEMM operands: results are bit-stable for a FIXED slot count whatever ran beside a window
             t2, l2 = gen(eng, x.flip(0), nb, n_slots=slots, refill_min=refill)

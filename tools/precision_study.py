@@ -41,7 +41,11 @@ from whisperseg_amd import postprocess  # noqa: E402
 from whisperseg_amd.model import SegmenterBase  # noqa: E402
 from whisperseg_amd.tokenizer import WhisperSegTokenizer  # noqa: E402
 
-MODEL_DIR = os.path.join(ROOT, "tests", "golden", "tiny_model")
+# STUDY_SWEEP=sweep2_heldout (r06): the held-out 1 000-recording sweep of the second fixture model instead of the 200 recordings every
+# format was chosen on (tools/parity_sweep.py SWEEPS)
+from tools.parity_sweep import SWEEPS  # noqa: E402
+SWEEP_ROWS, SWEEP_MODEL, SWEEP_VARIANT = SWEEPS[os.environ.get("STUDY_SWEEP", "sweep1")]
+MODEL_DIR = os.path.join(ROOT, "tests", "golden", SWEEP_MODEL)
 
 
 def rnd(x, fmt):
@@ -393,7 +397,7 @@ def main():
     from tools.parity_sweep import score
     torch.set_num_threads(int(os.environ.get("STUDY_THREADS", 8)))
     dest = sys.argv[1]
-    with open(os.path.join(ROOT, "tests", "golden", "tiny_sweep.json")) as f:
+    with open(os.path.join(ROOT, "tests", "golden", SWEEP_ROWS)) as f:
         sweep = json.load(f)
     limit = int(os.environ.get("STUDY_RUNS", len(sweep)))
     sweep = sweep[:limit]
@@ -408,7 +412,7 @@ def main():
             sego, segp = OracleSegmenter(Policy("")), OracleSegmenter(Policy(pol))
             errs, scale = [], 0.0
             for run in sweep[:32:4]:
-                audio = GI.tiny_recording(run["seed"], run["n_windows"])
+                audio = GI.tiny_recording(run["seed"], run["n_windows"], variant=SWEEP_VARIANT)
                 sl = sego.get_sliced_audios_features(audio, TM.SR, 0, TM.STS, 1)
                 feats = torch.from_numpy(np.stack([s_[2] for s_ in sl[:2]]))
                 outs = []
@@ -425,7 +429,7 @@ def main():
             continue
         if text == "margins":
             seg = OracleSegmenter(Policy(""), collect_margins=True)
-            r = score(seg, sweep)
+            r = score(seg, sweep, SWEEP_VARIANT)
             m = np.array([x[0] for x in MARGINS])
             is_time = np.array([x[1] for x in MARGINS])
             edges = [0, 1e-5, 1e-4, 3e-4, 1e-3, 3e-3, 1e-2, 3e-2, 0.1, 0.3, 1.0, 3.0, 1e9]
@@ -436,7 +440,7 @@ def main():
             print("margins", json.dumps(res["margins"]), flush=True)
         else:
             seg = OracleSegmenter(Policy(text))
-            r = score(seg, sweep)
+            r = score(seg, sweep, SWEEP_VARIANT)
             res[text] = r
             print(text, "runs", r["runs"], "exact", r["exact_runs"], "within +-1 frame", r["within_tolerance_runs"],
                   "structure mismatches", len(r["structure_mismatch_runs"]), "hist", r["frame_hist"], flush=True)

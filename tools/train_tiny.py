@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--out", default="tests/golden/tiny_model")
     ap.add_argument("--variant", default="tiny", choices=sorted(TM.VARIANTS))
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--lr", type=float, default=2e-3)
     args = ap.parse_args()
     var = TM.VARIANTS[args.variant]
     from transformers import WhisperConfig, WhisperForConditionalGeneration
@@ -56,8 +57,8 @@ def main():
     extra = {k: cd.pop(k) for k in ("total_spec_columns", "cluster_codebook", "default_segmentation_config", "model_type")}
     cfg = WhisperConfig(**cd, suppress_tokens=None, begin_suppress_tokens=None)
     model = WhisperForConditionalGeneration(cfg)
-    opt = torch.optim.AdamW(model.parameters(), lr=2e-3, weight_decay=0.01)
-    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=2e-3, total_steps=args.steps, pct_start=0.1)
+    opt = torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=args.lr, total_steps=args.steps, pct_start=0.1)
     rng = np.random.default_rng(var["data_seed"])
     model.train()
     t0 = time.time()

@@ -118,6 +118,15 @@ template <typename HT> __device__ __forceinline__ uint4 pack8(const float v[8]) 
   return make_uint4(H16<HT>::pack(v[0], v[1]), H16<HT>::pack(v[2], v[3]), H16<HT>::pack(v[4], v[5]), H16<HT>::pack(v[6], v[7]));
 }
 
+// V^T of the encoder self-attention in MFMA operand order (r06; EpiParams::vt_tiled): per (window, head) the [64 hd][t_pad keys] matrix is
+// stored key tile by key tile — [t / 64][hd][64 keys] — and inside a 128-byte row the 16-byte slot 2 G + g2 holds the 8 keys that lane
+// half g2 of v_mfma_f32_32x32x16 contracts for the 16-key group G: keys 16 G + 4 g2 + {0..3} | 16 G + 8 + 4 g2 + {0..3}.  The attention
+// kernel then fetches a tile by LDS-DMA like the K tile and a fragment is one ds_read_b128.  Element offset inside the (window, head) block:
+__host__ __device__ __forceinline__ int vt_tiled_index(int hd, int t) {
+  const int k = t & 63, gi = (k >> 2) & 3;
+  return (t >> 6) * 4096 + hd * 64 + ((2 * (k >> 4) + (gi & 1)) << 3) + ((gi >> 1) << 2) + (k & 3);
+}
+
 // Element-type traits: T = float (exact-parity mode), bf16_t or f16_t (production modes).
 template <typename T> struct El {      // 16-bit types
   static __device__ __forceinline__ float ld(const T* p) { return H16<T>::one(*p); }

@@ -142,11 +142,16 @@ template <typename HT, typename TO, bool SPLIT = false>
 __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(const HT* __restrict__ Q, const HT* __restrict__ K,
                                                                 const HT* __restrict__ Vt, void* __restrict__ out,
                                                                  int H, int T, int Tp, int d, size_t plane) {
-  // [key][64 hd], 16-B slots XOR ((key >> 1) & 7): a 32-row MFMA fragment read (lane = row + 32*half) is serviced in the
-  // lane groups {0-3,12-15,20-27}, ... and needs 16 distinct (row & 1, slot) pairs per group — XOR (key & 7), right for
-  // 16-row fragments, was 2-way conflicted here (SQ_LDS_BANK_CONFLICT 44 % of LDS cycles)
-  __shared__ __attribute__((aligned(16))) HT sK[2][64 * 64];   // double-buffered: filled by LDS-DMA, no registers in between
-  __shared__ __attribute__((aligned(16))) HT sV[64 * 64];   // [hd][64 keys] in 16-byte operand-order slots (WSEG_EA_VSWZ)
+  // K tile [key][64 hd] and V^T tile [hd][64 keys in MFMA operand order], 16-byte slots XOR ((row >> 1) & 7): a 32-row MFMA fragment read
+  // (lane = row + 32 * half) is serviced in the lane groups {0-3,12-15,20-27}, ... and needs 16 distinct (row & 1, slot) pairs per group —
+  // XOR (row & 7), right for 16-row fragments, was 2-way conflicted here (SQ_LDS_BANK_CONFLICT 44 % of LDS cycles).
+  // Both tiles arrive by LDS-DMA (no registers in between; the swizzle is applied on the SOURCE side: LDS slot c of a row holds its global
+  // slot (c & 7) ^ ((row >> 1) & 7)).  V^T (r06): the q | k | v GEMM epilogue writes it tile by tile in operand order — global
+  // [b][h][key tile][hd][8 slots]: slot 2 G + g2 of a row holds the 8 keys lane half g2 contracts for the 16-key group G, keys
+  // 16 G + 4 g2 + {0..3} | 16 G + 8 + 4 g2 + {0..3} (vt_tiled_index, wseg_common.h) — so a fragment is ONE ds_read_b128 and the tile needs no
+  // register round trip (r02-r05: two 16-byte loads per thread into registers, four ds_write_b64 behind a barrier of their own).
+  __shared__ __attribute__((aligned(16))) HT sK[2][64 * 64];   // double-buffered: K tile kt + 1 streams in under tile kt
+  __shared__ __attribute__((aligned(16))) HT sV[64 * 64];      // single: V^T tile kt is requested when every wave is done with tile kt - 1
   __shared__ __attribute__((aligned(16))) HT sKl[SPLIT ? 2 : 1][SPLIT ? 64 * 64 : 8];      // lo planes (SPLIT)
   __shared__ __attribute__((aligned(16))) HT sVl[SPLIT ? 64 * 64 : 8];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -172,108 +177,54 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
   float m_run = -1.0e30f, l_run = 0.f;
 
   const int n_tiles = (T + 63) / 64;
-  // per-lane byte offsets of the MFMA fragment reads (see the key-block loop)
+  // per-lane byte offset of the MFMA fragment reads of both tiles (see the key-block loop)
   const unsigned kfrag = (unsigned)(qi * 128 + ((g2 ^ ((qi >> 1) & 7)) << 4));
-#ifndef WSEG_EA_VSWZ
-// LDS image of the V^T tile (r05; profiles/r05_encattn_ab.txt).  2: 16-byte slots in MFMA operand order, XOR ((hd >> 1) & 7) like the K tile — a
-// fragment is one ds_read_b128, no bank conflicts (1 169 -> 1 111 us per 256-window launch).  1: 8-byte granules XOR (hd & 15): conflict-free
-// (SQ_LDS_BANK_CONFLICT 2.1e7 -> 0 per launch) but two ds_read_b64 per fragment, which the compiler pairs across fragments (ds_read2_b64) and
-// re-sorts with ~50 v_mov per tile.  0: XOR ((hd >> 1) & 15), r02-r04: every 16-lane read group hit each bank pair twice.
-#define WSEG_EA_VSWZ 2
-#endif
-  const unsigned vfrag = (unsigned)(qi * 128 + ((g2 ^ (WSEG_EA_VSWZ ? (qi & 15) : ((qi >> 1) & 15))) << 3));
-  // K tile and V^T tile (each 8 KiB = 512 16-byte chunks, 2 per thread; rows are padded to Tp, so a tile is always readable).
-  // The NEXT tile is requested while the current one is multiplied: K by LDS-DMA straight into the other sK buffer (the
-  // swizzle is applied on the source side: LDS slot c holds global slot (c & 7) ^ ((row >> 1) & 7) of its row), V^T into 8
-  // registers (its 8-byte-granule swizzle is finer than a DMA element).  Keeping the K chunks in registers as well made the
-  // compiler spill them right behind their loads (a scratch store that waits for the load: the prefetch was serialised).
-  uint4 v0, v1, v0l, v1l;
-  // V^T row of this thread's two chunks: rows 4j + {0, 2, 1, 3} for consecutive 8-lane groups, so that the two rows sharing a
-  // 16-lane ds_write_b64 group have swizzles of different parity (rows 2k and 2k + 1 share theirs and collided 2-way)
-  const int vrow = WSEG_EA_VSWZ == 1 ? (tid >> 3) : (((tid >> 3) & ~3) | (((tid >> 3) & 1) << 1) | (((tid >> 3) >> 1) & 1));
-  auto fetch = [&](int kt) {
-    const HT* ksrc = Kb + (size_t)(kt * 64) * 64;
-    HT* kdst = sK[kt & 1];
+  // A tile is 8 KiB = 512 16-byte chunks, 2 per thread (rows are padded to Tp, so a tile is always readable).
+  constexpr int NDMA = SPLIT ? 4 : 2;      // LDS-DMA instructions per thread and tile
+  auto fetch_tile = [&](const HT* src, HT* dst, HT* dst_lo) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = tid + i * 256, row = c >> 3, sl = (c & 7) ^ ((row >> 1) & 7);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + row * 64 + sl * 8),
-                                       (__attribute__((address_space(3))) void*)(kdst + (i * 256 + wave * 64) * 8), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + row * 64 + sl * 8),
+                                       (__attribute__((address_space(3))) void*)(dst + (i * 256 + wave * 64) * 8), 16, 0, 0);
       if constexpr (SPLIT)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + plane + row * 64 + sl * 8),
-                                         (__attribute__((address_space(3))) void*)(sKl[kt & 1] + (i * 256 + wave * 64) * 8), 16, 0, 0);
-    }
-    {
-      const int r0 = vrow, sl = tid & 7;
-      v0 = *(const uint4*)(Vb + (size_t)r0 * Tp + kt * 64 + sl * 8);
-      v1 = *(const uint4*)(Vb + (size_t)(r0 + 32) * Tp + kt * 64 + sl * 8);
-      if constexpr (SPLIT) {
-        v0l = *(const uint4*)(Vb + plane + (size_t)r0 * Tp + kt * 64 + sl * 8);
-        v1l = *(const uint4*)(Vb + plane + (size_t)(r0 + 32) * Tp + kt * 64 + sl * 8);
-      }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + plane + row * 64 + sl * 8),
+                                         (__attribute__((address_space(3))) void*)(dst_lo + (i * 256 + wave * 64) * 8), 16, 0, 0);
     }
   };
-  fetch(0);
+  auto fetch_k = [&](int kt) { fetch_tile(Kb + (size_t)(kt * 64) * 64, sK[kt & 1], sKl[kt & 1]); };
+  auto fetch_v = [&](int kt) { fetch_tile(Vb + (size_t)kt * 64 * 64, sV, sVl); };
+  // Hand-over protocol (two barriers per tile): barrier C at the top of tile kt — every wave's K chunks of tile kt have landed (they were
+  // requested a whole tile earlier) and every wave is done with tile kt - 1, so sV and the other sK buffer may be refilled: V^T(kt) and
+  // K(kt + 1) are requested; S^T = K Q^T and the softmax of the tile run while V^T(kt) lands; barrier D in front of P V.
+  fetch_k(0);
   for (int kt = 0; kt < n_tiles; ++kt) {
     const HT* cK = sK[kt & 1];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's K chunks have landed in LDS, its V chunks in v0 / v1
-    __syncthreads();                                      // ... everyone's; and every wave is done with sV of the last tile
-    {
-      const int r0 = vrow, sl = tid & 7;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = r0 + i * 32;
-        const uint4 vv = i == 0 ? v0 : v1;
-#if WSEG_EA_VSWZ == 2
-        // 16-byte slots in MFMA operand order: slot 2 G + g2 of a row holds the 8 keys lane half g2 contracts for the 16-key group G —
-        // keys 16 G + 4 g2 + {0..3} | 16 G + 8 + 4 g2 + {0..3} — so a V^T fragment is ONE ds_read_b128 (it was two ds_read_b64 whose
-        // pairwise merging into ds_read2_b64 cost ~50 v_mov per tile to re-sort the halves); slots XOR ((row >> 1) & 7) like the K tile
-        const int sw = (row >> 1) & 7, G = sl >> 1, hf = sl & 1;
-        char* vrow_p = (char*)sV + row * 128 + hf * 8;
-        *(uint2*)(vrow_p + (((2 * G) ^ sw) << 4)) = make_uint2(vv.x, vv.y);
-        *(uint2*)(vrow_p + (((2 * G + 1) ^ sw) << 4)) = make_uint2(vv.z, vv.w);
-        if constexpr (SPLIT) {
-          const uint4 vl = i == 0 ? v0l : v1l;
-          char* vrowl_p = (char*)sVl + row * 128 + hf * 8;
-          *(uint2*)(vrowl_p + (((2 * G) ^ sw) << 4)) = make_uint2(vl.x, vl.y);
-          *(uint2*)(vrowl_p + (((2 * G + 1) ^ sw) << 4)) = make_uint2(vl.z, vl.w);
-        }
-#else
-        const int sw = WSEG_EA_VSWZ ? (row & 15) : ((row >> 1) & 15);
-        *(uint2*)(sV + row * 64 + (((2 * sl) ^ sw) << 2)) = make_uint2(vv.x, vv.y);
-        *(uint2*)(sV + row * 64 + (((2 * sl + 1) ^ sw) << 2)) = make_uint2(vv.z, vv.w);
-        if constexpr (SPLIT) {
-          const uint4 vl = i == 0 ? v0l : v1l;
-          *(uint2*)(sVl + row * 64 + (((2 * sl) ^ sw) << 2)) = make_uint2(vl.x, vl.y);
-          *(uint2*)(sVl + row * 64 + (((2 * sl + 1) ^ sw) << 2)) = make_uint2(vl.z, vl.w);
-        }
-#endif
-      }
-    }
-    __syncthreads();
-    if (kt + 1 < n_tiles) fetch(kt + 1);                  // the other sK buffer was last read two barriers ago
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's chunks of K(kt): the only request outstanding here
+    __syncthreads();                                      // barrier C
+    fetch_v(kt);
+    const bool more = kt + 1 < n_tiles;
+    if (more) fetch_k(kt + 1);
 #ifndef WSEG_EA_PRIO
 #define WSEG_EA_PRIO 1
 #endif
-#ifndef WSEG_EA_JOINT
-#define WSEG_EA_JOINT 1
-#endif
-    static_assert(WSEG_EA_JOINT == 1 || WSEG_EA_VSWZ != 2, "the operand-order V^T image is read by the joint key-half path only");
-#if WSEG_EA_JOINT
     // Both 32-key halves of the tile together (r05): two independent score accumulators (the 12 MFMAs of one half are a dependent chain on ONE
-    // accumulator: alternating halves lets the matrix pipe run back to back), one running maximum / rescale per 64 keys instead of per 32:
-    // 1 171 -> 1 127 us per 256-window launch together with the conflict-free V^T image (profiles/r05_encattn_ab.txt).  Measured and dropped:
-    // the second half's probabilities computed between the first half's P V MFMAs (1 350 us: VALU inside a wave's MFMA stretch stalls both), the
-    // exponent arguments / row sums on v_pk_fma_f32 / v_pk_add_f32 (1 143 us; the row sums alone on v_pk_add_f32: +1 %).
+    // accumulator: alternating halves lets the matrix pipe run back to back), one running maximum / rescale per 64 keys instead of per 32.
+    // Measured and dropped (profiles/r05_encattn_ab.txt): the second half's probabilities computed between the first half's P V MFMAs (+20 %: VALU
+    // inside a wave's MFMA stretch stalls both), the exponent arguments / row sums on v_pk_fma_f32 / v_pk_add_f32 (+1-2 %).
     {
       const int key_base = kt * 64;
       f32x16 s0, s1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-      unsigned kfo = kfrag, vfo = vfrag;
-      asm volatile("" : "+v"(kfo), "+v"(vfo));
+      // one lane offset per operand, made opaque once per key block so that its variants are v_xor'ed with a constant at the read instead of
+      // living in loop-invariant registers (r05: three of them were spilled and reloaded behind an s_waitcnt vmcnt(0) in every key block)
+      unsigned kfo = kfrag;
+      asm volatile("" : "+v"(kfo));
       const char* cKs = (const char*)cK;
       [[maybe_unused]] const char* cKls = (const char*)sKl[kt & 1];
+      // (three workgroups share a CU: a wave that has MFMAs to issue goes first — MI355X_MICROARCH.md, static priority — while its
+      // neighbours' softmax VALU fills the slots between them)
       if (WSEG_EA_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int hs = 0; hs < 4; ++hs) {
@@ -291,8 +242,8 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
         }
       }
       if (WSEG_EA_PRIO) __builtin_amdgcn_s_setprio(0);
-      if (key_base + 64 > T) {      // the ragged tile of a (window, head)
-        asm volatile("");
+      if (key_base + 64 > T) {      // the ragged tile of a (window, head): a real branch — if-converted, its key indices, compares and selects
+        asm volatile("");           // ran in every key block
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = key_base + (r & 3) + 8 * (r >> 2) + 4 * g2;
@@ -307,22 +258,27 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __expf(m_run - m_new);
       float ps = 0.f;
+      // exp(s - m) = exp2(s log2e - m log2e): one v_fma + v_exp per probability (__expf: v_sub, v_mul, v_exp)
       const float m_l2 = -m_new * 1.4426950408889634f;
-#if defined(WSEG_EA_TIMING) && WSEG_EA_TIMING == 1      // timing experiment (wrong results): no exponentials
-      ps = s0[0] + s1[5] + m_l2;
-#else
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], 1.4426950408889634f, m_l2));
         s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], 1.4426950408889634f, m_l2));
         ps += s0[r] + s1[r];
       }
-#endif
       m_run = m_new;
-      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {      // no query of this wave raised its maximum: 32 multiplies by 1.0 saved
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
       }
+      // this wave's chunks of V^T(kt) have landed (K(kt + 1), requested after them, stays in flight), then everyone's: barrier D
+      // (a bare s_barrier, not __syncthreads: the fence of the latter would wait for K(kt + 1) as well)
+      if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // O^T[hd][q] += V^T[hd][key] P^T[key][q]; the contraction slots of lane half g2 in MFMA (sub, mm) are the keys 32 sub + 16 mm + 4 g2 +
+      // {0,1,2,3, 8,9,10,11} == registers 8 mm .. 8 mm + 7 of s<sub>: 16-key group G = 2 sub + mm of the operand-order V^T rows
       if (WSEG_EA_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
@@ -337,27 +293,15 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
             for (int jj = 0; jj < 4; ++jj)
               pfl.u[jj] = H16<HT>::pack(H16<HT>::sub_lo(sv[8 * mm + 2 * jj], pf.u[jj]), H16<HT>::sub_hi(sv[8 * mm + 2 * jj + 1], pf.u[jj]));
           }
-          [[maybe_unused]] const unsigned va = vfo ^ ((sub * 8 + 4 * mm) << 3), vb = vfo ^ ((sub * 8 + 4 * mm + 2) << 3);
 #pragma unroll
           for (int ht = 0; ht < 2; ++ht) {
-            union { bf16x8 v; uint2 u[2]; } vf, vfl;
-#if WSEG_EA_VSWZ == 2
-            vf.v = *(const bf16x8*)((const char*)sV + ht * 4096 + (kfo ^ ((sub * 2 + mm) << 5)));      // the K fragment's address form: group G = 2 sub + mm
-#else
-            vf.u[0] = *(const uint2*)((const char*)sV + ht * 4096 + va);
-            vf.u[1] = *(const uint2*)((const char*)sV + ht * 4096 + vb);
-#endif
-            if (ht == 0) o0 = H16<HT>::mfma32(vf.v, pf.v, o0);
-            else o1 = H16<HT>::mfma32(vf.v, pf.v, o1);
+            const bf16x8 vf = *(const bf16x8*)((const char*)sV + ht * 4096 + (kfo ^ ((sub * 2 + mm) << 5)));      // the K fragment's address form
+            if (ht == 0) o0 = H16<HT>::mfma32(vf, pf.v, o0);
+            else o1 = H16<HT>::mfma32(vf, pf.v, o1);
             if constexpr (SPLIT) {
-#if WSEG_EA_VSWZ == 2
-              vfl.v = *(const bf16x8*)((const char*)sVl + ht * 4096 + (kfo ^ ((sub * 2 + mm) << 5)));
-#else
-              vfl.u[0] = *(const uint2*)((const char*)sVl + ht * 4096 + va);
-              vfl.u[1] = *(const uint2*)((const char*)sVl + ht * 4096 + vb);
-#endif
-              if (ht == 0) { o0 = H16<HT>::mfma32(vf.v, pfl.v, o0); o0 = H16<HT>::mfma32(vfl.v, pf.v, o0); }
-              else { o1 = H16<HT>::mfma32(vf.v, pfl.v, o1); o1 = H16<HT>::mfma32(vfl.v, pf.v, o1); }
+              const bf16x8 vfl = *(const bf16x8*)((const char*)sVl + ht * 4096 + (kfo ^ ((sub * 2 + mm) << 5)));
+              if (ht == 0) { o0 = H16<HT>::mfma32(vf, pfl.v, o0); o0 = H16<HT>::mfma32(vfl, pf.v, o0); }
+              else { o1 = H16<HT>::mfma32(vf, pfl.v, o1); o1 = H16<HT>::mfma32(vfl, pf.v, o1); }
             }
           }
         }
@@ -366,98 +310,6 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 4) void enc_attention_h16_kernel(c
       ps += lane_xor<32>(ps);
       l_run = l_run * alpha + ps;
     }
-#else
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      const int key_base = kt * 64 + sub * 32;
-      if (key_base >= T) break;
-      // S^T[key][q] = sum_hd K[key][hd] Q[q][hd]
-      f32x16 s;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = 0.f;
-      // fragment addresses: row sub*32 + qi, 16-byte slot (2 hs + g2) ^ ((row >> 1) & 7)  ==  sub*4096 + (kfrag ^ (hs << 5)) bytes.  One
-      // lane offset per operand, made opaque once per key block so that the variants are v_xor'ed with a constant at the read instead
-      // of living in 8 + 16 loop-invariant registers: under the 168-register cap of the SPLIT instantiations the compiler spilled
-      // three of them and reloaded them in every key block behind an s_waitcnt vmcnt(0) — the K / V^T prefetch of the next tile
-      // drained three times per block (r05, found by tools/isa_lint.py: scratch accesses inside a loop)
-      unsigned kfo = kfrag, vfo = vfrag;
-      asm volatile("" : "+v"(kfo), "+v"(vfo));
-      const char* cKs = (const char*)cK + sub * 4096;
-      [[maybe_unused]] const char* cKls = (const char*)sKl[kt & 1] + sub * 4096;
-      // (three workgroups share a CU: a wave that has MFMAs to issue goes first — MI355X_MICROARCH.md, static priority — while its
-      // neighbours' softmax VALU fills the slots between them)
-      if (WSEG_EA_PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int hs = 0; hs < 4; ++hs) {
-        const bf16x8 kf = *(const bf16x8*)(cKs + (kfo ^ (hs << 5)));
-        s = H16<HT>::mfma32(kf, qf[hs], s);
-        if constexpr (SPLIT) {
-          const bf16x8 kfl = *(const bf16x8*)(cKls + (kfo ^ (hs << 5)));
-          s = H16<HT>::mfma32(kf, qfl[hs], s);
-          s = H16<HT>::mfma32(kfl, qf[hs], s);
-        }
-      }
-      if (WSEG_EA_PRIO) __builtin_amdgcn_s_setprio(0);
-      if (key_base + 32 > T) {      // the one ragged key block of a (window, head): a real branch — if-converted, its 16 key indices, compares and
-        asm volatile("");           // selects (55 VALU instructions) ran in every key block (r05, from the loop's instruction histogram)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = key_base + (r & 3) + 8 * (r >> 2) + 4 * g2;
-          if (key >= T) s[r] = -1.0e30f;
-        }
-      }
-      float mx = s[0];
-#pragma unroll
-      for (int r = 1; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);      // v_max3_f32
-      mx = fmaxf(mx, s[15]);
-      mx = fmaxf(mx, lane_xor<32>(mx));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __expf(m_run - m_new);
-      float ps = 0.f;
-      // exp(s - m) = exp2(s log2e - m log2e): one v_fma + v_exp per probability (__expf: v_sub, v_mul, v_exp)
-      const float m_l2 = -m_new * 1.4426950408889634f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], 1.4426950408889634f, m_l2)); ps += s[r]; }
-      ps += lane_xor<32>(ps);
-      l_run = l_run * alpha + ps;
-      m_run = m_new;
-      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {      // no query of this wave raised its maximum: 32 multiplies by 1.0 saved
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-      }
-      // O^T[hd][q] += V^T[hd][key] P^T[key][q]; contraction slots of lane-half g2, MFMA mm:
-      // keys 16*mm + 4*g2 + {0,1,2,3, 8,9,10,11}  == registers 8*mm .. 8*mm+7 of s.
-      if (WSEG_EA_PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int mm = 0; mm < 2; ++mm) {
-        union { bf16x8 v; uint32_t u[4]; } pf, pfl;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pf.u[j] = H16<HT>::pack(s[8 * mm + 2 * j], s[8 * mm + 2 * j + 1]);
-        if constexpr (SPLIT) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            pfl.u[j] = H16<HT>::pack(H16<HT>::sub_lo(s[8 * mm + 2 * j], pf.u[j]), H16<HT>::sub_hi(s[8 * mm + 2 * j + 1], pf.u[j]));
-        }
-        // V^T row hd = ht*32 + qi, 8-byte granule (sub*8 + 4 mm + g2 [+ 2]) ^ ((hd >> 1) & 15)  ==  ht*4096 + (vfrag ^ (c << 3)) bytes
-        const unsigned va = vfo ^ ((sub * 8 + 4 * mm) << 3), vb = vfo ^ ((sub * 8 + 4 * mm + 2) << 3);
-#pragma unroll
-        for (int ht = 0; ht < 2; ++ht) {
-          union { bf16x8 v; uint2 u[2]; } vf, vfl;
-          vf.u[0] = *(const uint2*)((const char*)sV + ht * 4096 + va);
-          vf.u[1] = *(const uint2*)((const char*)sV + ht * 4096 + vb);
-          if (ht == 0) o0 = H16<HT>::mfma32(vf.v, pf.v, o0);
-          else o1 = H16<HT>::mfma32(vf.v, pf.v, o1);
-          if constexpr (SPLIT) {
-            vfl.u[0] = *(const uint2*)((const char*)sVl + ht * 4096 + va);
-            vfl.u[1] = *(const uint2*)((const char*)sVl + ht * 4096 + vb);
-            if (ht == 0) { o0 = H16<HT>::mfma32(vf.v, pfl.v, o0); o0 = H16<HT>::mfma32(vfl.v, pf.v, o0); }
-            else { o1 = H16<HT>::mfma32(vf.v, pfl.v, o1); o1 = H16<HT>::mfma32(vfl.v, pf.v, o1); }
-          }
-        }
-      }
-      if (WSEG_EA_PRIO) __builtin_amdgcn_s_setprio(0);
-    }
-#endif
   }
   const int q = q0 + qi;
   if constexpr (IsMx<TO>::v) {
@@ -855,6 +707,11 @@ static void launch_enc_attention_f32(const void* q, const void* k, const void* v
 }
 
 bool enc_attention_writes_mx(int dtype) { return dtype == WSEG_F16M6 && x3_enc_attention_mode() == 2; }
+bool enc_attention_vt_tiled(int dtype) {
+  if (dtype == WSEG_F32) return false;
+  const bool split = dtype == WSEG_BF16X3 || dtype == WSEG_F16X3 || dtype == WSEG_F16M6;
+  return !(split && x3_enc_attention_mode() == 1);
+}
 
 int launch_enc_attention(int dtype, const void* q, const void* k, const void* vt, void* out,
                          int B, int H, int T, int Tp, int d, hipStream_t s) {

@@ -116,7 +116,11 @@ __device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, fl
       typedef std::remove_pointer_t<decltype(base)> QT;
       if (sec == 0) Vec4<QT>::st((QT*)ep.q + plane + (bh * ep.t_pad + t) * 64 + e, x);
       else if (sec == 1) Vec4<QT>::st((QT*)ep.k + plane + (bh * ep.t_pad + t) * 64 + e, x);
-      else {
+      else if (ep.vt_tiled) {
+        QT* vt = (QT*)ep.v + plane + bh * 64 * ep.t_pad;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) El<QT>::st(vt + vt_tiled_index(e + i, t), x[i]);
+      } else {
         QT* vt = (QT*)ep.v + plane + (bh * 64 + e) * ep.t_pad + t;
 #pragma unroll
         for (int i = 0; i < 4; ++i) El<QT>::st(vt + (size_t)i * ep.t_pad, x[i]);
@@ -239,7 +243,11 @@ __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, f
       typedef std::remove_pointer_t<decltype(base)> QT;
       if (sec == 0) st8_h<QT>((QT*)ep.q + plane + (bh * ep.t_pad + t) * 64 + e, x);
       else if (sec == 1) st8_h<QT>((QT*)ep.k + plane + (bh * ep.t_pad + t) * 64 + e, x);
-      else {
+      else if (ep.vt_tiled) {
+        QT* vt = (QT*)ep.v + plane + bh * 64 * ep.t_pad;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) El<QT>::st(vt + vt_tiled_index(e + i, t), x[i]);
+      } else {
         QT* vt = (QT*)ep.v + plane + (bh * 64 + e) * ep.t_pad + t;
 #pragma unroll
         for (int i = 0; i < 8; ++i) El<QT>::st(vt + (size_t)i * ep.t_pad, x[i]);
@@ -292,6 +300,12 @@ __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, f
 #define WSEG_GLDS16(gptr, ldsptr)                                                              \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),      \
                                    (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
+// the same with the non-temporal policy (aux = 2): for weight slices that exactly ONE workgroup reads once — the decode steps of a few
+// windows (MI355X_MICROARCH.md, row nt-weights: issued -> landed -18 %, a decode layer -5..10 %); never where several workgroups
+// re-read the slice from L2 (there nt measured -6 % end to end)
+#define WSEG_GLDS16_NT(gptr, ldsptr)                                                           \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),      \
+                                   (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 2)
 
 // Measurement builds only (python -m whisperseg_amd.build --stamps 4, tools/pp_stamps.py): the ping-pong kernel's workgroup 0 records
 // the shader clock (s_memtime) of wave 0 (row group 0) and wave 4 (row group 1) around the L and M parts of both phases of K tiles 8..11.
@@ -307,6 +321,12 @@ __device__ unsigned long long g_pp_stamps[2 * 4 * 4 * 4 + 4];  // [group][K tile
 #define WSEG_PP_CLOCK() do { } while (0)
 #endif
 
+#ifndef WSEG_VT_TRANSPOSED
+#define WSEG_VT_TRANSPOSED 1      // (0: the row-wise 2-byte V^T stores of r01-r05, for same-box A/B builds)
+#endif
+#ifndef WSEG_SKINNY_NT
+#define WSEG_SKINNY_NT 1      // (0: same-box A/B builds)
+#endif
 #ifndef WSEG_PP_LATEWAIT
 #define WSEG_PP_LATEWAIT 1
 #endif
@@ -426,13 +446,23 @@ __global__ __launch_bounds__(WM * WN * 64, (BM <= 128 && BN <= 64 && WM * WN == 
     const int p = it * NT + tid, row = p >> 3, sl = (p & 7) ^ (row & 7);
     w_src[it] = W + (size_t)(n0 + row) * ldw + kbeg + sl * 8;
   }
+  // one row tile (2-D grid): every (column tile, K range) of W is read by exactly this workgroup, once -> non-temporal weight stream
+  // (r06, same-box A/B at 8 / 15 / 32 windows x 4 beams, f16m6: 3.03 -> 2.94, 3.47 -> 3.45, 4.40 -> 4.46 ms per decode step: the 128-row
+  // tile keeps the default policy)
+  const bool w_once = WSEG_SKINNY_NT && BN == 64 && BM <= 64 && ntm == 0 && gridDim.y == 1;
   auto issue = [&](int kt, int buf) {
 #pragma unroll
     for (int it = 0; it < A_IT; ++it)
       WSEG_GLDS16(a_src[it] + kt * BK, sA + buf * BM * BK + (it * NT + wave * 64) * 8);
+    if (w_once) {
 #pragma unroll
-    for (int it = 0; it < W_IT; ++it)
-      WSEG_GLDS16(w_src[it] + kt * BK, sW + buf * BN * BK + (it * NT + wave * 64) * 8);
+      for (int it = 0; it < W_IT; ++it)
+        WSEG_GLDS16_NT(w_src[it] + kt * BK, sW + buf * BN * BK + (it * NT + wave * 64) * 8);
+    } else {
+#pragma unroll
+      for (int it = 0; it < W_IT; ++it)
+        WSEG_GLDS16(w_src[it] + kt * BK, sW + buf * BN * BK + (it * NT + wave * 64) * 8);
+    }
   };
 
   f32x4 acc[NI][MI];
@@ -633,12 +663,82 @@ __device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NIT][MI], flo
       ep2.slot_map = nullptr;
     }
   }
+  // Decoder q | k | v into the PAGED self-attention cache (EPI_QKV_DEC): a row's destination needs three dependent lookups (idle flag,
+  // position, page-table entry).  Done row by row inside the store loop (r04-r05) every lookup queued behind the previous row's stores
+  // (vmcnt retires in order: a load issued after a store waits for it) — 16 serialised round trips per wave tile, ~30 of the 87 us of the
+  // 4 096-row launch.  Now all 16 rows of the lane are resolved before the first store (see the rule above).
+  [[maybe_unused]] int dec_kv[EPI == EPI_QKV_DEC ? NROW : 1];      // ((unit * beams + beam) * heads) * KV_PAGE + pos % KV_PAGE, or -1: no store
+  [[maybe_unused]] int dec_sec = 0;
+  if constexpr (EPI == EPI_QKV_DEC) {
+    dec_sec = nb / ep.d_model;      // wave-uniform: a 64-column wave tile lies inside one section and one head
+    if (dec_sec > 0) {
+      int pos_r[NROW], slot_r[NROW];
+#pragma unroll
+      for (int t = 0; t < NROW; ++t) {
+        const int m = mb + t * 8 + rr;
+        slot_r[t] = min(m, M - 1) / ep.pos_div;
+        dec_kv[t] = (m < M && !ep.idle_ptr[slot_r[t]]) ? 0 : -1;
+        pos_r[t] = ep.pos_ptr[slot_r[t]];
+      }
+#pragma unroll
+      for (int t = 0; t < NROW; ++t) {
+        const int m = min(mb + t * 8 + rr, M - 1), beam = m - slot_r[t] * ep.pos_div;
+        const int unit = ep.kv_pt[(size_t)slot_r[t] * ep.kv_npg + pos_r[t] / KV_PAGE];
+        if (dec_kv[t] == 0) dec_kv[t] = ((unit * ep.pos_div + beam) * ep.n_heads) * KV_PAGE + (pos_r[t] % KV_PAGE);
+      }
+    }
+  }
+  // V section of the fused encoder q | k | v GEMM (EPI_QKV_ENC, 16-bit V^T planes [b][h][64][t_pad]): the strip is read TRANSPOSED, a lane
+  // takes 4 consecutive positions t of one head dimension — one 8-byte store per plane where the row-wise path issues four 2-byte
+  // stores (r06: the 2-byte stores were 256 store instructions per wave tile, 8 x 16-byte segments each; now 64 instructions whose
+  // 16 lanes-of-4 cover 32 contiguous bytes per V^T row).  Window starts are multiples of 4 rows (t_len % 4 == 0, checked), so a
+  // granule never straddles two windows.  vt_fast is wave-uniform.
+  [[maybe_unused]] bool vt_fast = false;
+  [[maybe_unused]] float vt_bias[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (EPI == EPI_QKV_ENC && WSEG_VT_TRANSPOSED) {
+    typedef typename IO<T>::A AT;
+    vt_fast = sizeof(AT) == 2 && nb >= 2 * ep.d_model && (ep.t_len & 3) == 0 && (M & 3) == 0 && !(IO<T>::split && ep.qkv_mode == 1);
+    if (vt_fast && ep.bias) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) vt_bias[q] = El<PT>::ld((const PT*)ep.bias + nb + q * 16 + (lane >> 2));
+    }
+  }
 #pragma unroll
   for (int j = 0; j < MI; ++j) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
       *(float4*)(strip + fr * LDT + i * 16 + fg * 4) = make_float4(acc[I0 + i][j][0], acc[I0 + i][j][1], acc[I0 + i][j][2], acc[I0 + i][j][3]);
     // same-wave LDS RAW: ds ops of one wave complete in order, the compiler waits lgkmcnt before the reads
+    if constexpr (EPI == EPI_QKV_ENC && WSEG_VT_TRANSPOSED) {
+      if (vt_fast) {
+        typedef typename IO<T>::A AT;
+        const int g4 = lane & 3, hq = lane >> 2;
+        const int m = mb + j * 16 + g4 * 4;                      // first of the lane's 4 rows
+        const int b = m / ep.t_len, t = m - b * ep.t_len;
+        const int nn = nb - 2 * ep.d_model, h = nn >> 6;
+        AT* vbase = (AT*)ep.v + ((size_t)b * ep.n_heads + h) * 64 * ep.t_pad;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int hd = q * 16 + hq;
+          float x[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = strip[(g4 * 4 + r) * LDT + hd] + vt_bias[q];
+          if constexpr (IO<T>::split) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = H16<AT>::sat(x[r]);
+          }
+          const uint2 hi2 = make_uint2(H16<AT>::pack(x[0], x[1]), H16<AT>::pack(x[2], x[3]));
+          AT* dst = vbase + (ep.vt_tiled ? vt_tiled_index(hd, t) : hd * ep.t_pad + t);      // 4 consecutive keys are contiguous either way
+          if (m < M) *(uint2*)dst = hi2;
+          if (IO<T>::split && ep.qkv_mode == 2) {               // lo plane: x - rn(x)
+            const uint2 lo2 = make_uint2(H16<AT>::pack(H16<AT>::sub_lo(x[0], hi2.x), H16<AT>::sub_hi(x[1], hi2.x)),
+                                         H16<AT>::pack(H16<AT>::sub_lo(x[2], hi2.y), H16<AT>::sub_hi(x[3], hi2.y)));
+            if (m < M) *(uint2*)(dst + ep.qkv_plane) = lo2;
+          }
+        }
+        continue;
+      }
+    }
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       const int rw = hh * 8 + rr;
@@ -661,6 +761,16 @@ __device__ __forceinline__ void staged_epilogue(const f32x4 (&acc)[NIT][MI], flo
         int mm = m;
         if (ep.slot_map) { const int b = m / ep.t_len; mm = (b == kv_b0 ? kv_s0 : kv_s1) * ep.t_len + (m - b * ep.t_len); }
         if (m < M) epi_apply8<EPI, T>(ep2, mm, nc, v);
+      } else if constexpr (EPI == EPI_QKV_DEC) {
+        const int nn = nc - dec_sec * ep.d_model;
+        if (dec_sec == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= ep.scale;
+          if (m < M) st8_h<PT>((PT*)ep.q + (size_t)m * ep.d_model + nn, v);
+        } else {
+          const int kv = dec_kv[j * 2 + hh];
+          if (kv >= 0) st8_h<PT>((PT*)(dec_sec == 1 ? ep.k : ep.v) + ((size_t)kv + (size_t)(nn >> 6) * KV_PAGE) * 64 + (nn & 63), v);
+        }
       } else if constexpr (WSEG_EPI_M6_LDS && IsMx<T>::v && (EPI == EPI_GELU || EPI == EPI_STORE)) {
         // M6 rows: the quad's word exchange goes through the strip slots the quad has just read (8 floats per lane = its 128 bytes)
         if constexpr (EPI == EPI_GELU) {

@@ -54,6 +54,8 @@ struct EpiParams {
   int qkv_mode = 0;              // split-precision modes, EPI_QKV_ENC storage of Q / K / V^T (x3_enc_attention_mode): 0 = IEEE half,
                                  // 1 = fp32 (fp32 attention kernel), 2 = half hi + lo planes, the lo plane qkv_plane elements behind
   size_t qkv_plane = 0;
+  int vt_tiled = 0;              // EPI_QKV_ENC: V^T in the MFMA operand order of the 16-bit attention kernel (vt_tiled_index, wseg_common.h)
+                                 // instead of plain [b][h][64][t_pad] rows (the fp32 attention kernels): enc_attention_vt_tiled(dtype)
   int kv24 = 0;                  // split-precision modes, EPI_KV_CROSS storage of the cross K / V (x3_cross_kv_format): 0 = fp32;
                                  // 1 = 24-bit values in two planes per (slot, head): [t_len][64] top halves (16 bits) then [t_len][64]
                                  // third bytes (bf16x3 / f16x3); 2 (f16m6, r05) = block floating point, one block per (position, head) row:
@@ -102,6 +104,8 @@ int launch_layernorm(int dtype, const float* x, const void* g, const void* b, vo
 // Encoder self-attention over Q,K [B][H][Tp][64], Vt [B][H][64][Tp] (q pre-scaled) -> out [B*T][d].
 // WSEG_F16M6: *out_is_mx (may be null) reports whether out was written as M6 rows (split-precision attention) or as hi | lo rows.
 bool enc_attention_writes_mx(int dtype);
+// does launch_enc_attention(dtype, ...) read V^T in MFMA operand order (the 16-bit MFMA kernel) or as plain rows (the fp32 kernels)?
+bool enc_attention_vt_tiled(int dtype);
 int launch_enc_attention(int dtype, const void* q, const void* k, const void* vt, void* out,
                          int B, int H, int T, int Tp, int d, hipStream_t s);
 

@@ -279,6 +279,7 @@ int run_encoder(wseg_model* m, const float* feats, int W, Plan& p, void* enc_out
     e = EpiParams();
     e.bias = L.qkv_b; e.q = p.q; e.k = p.k; e.v = p.vt; e.d_model = d; e.t_len = T; e.t_pad = Tp; e.n_heads = H; e.scale = 0.125f;
     if (m->x3) { e.qkv_mode = x3_enc_attention_mode(); e.qkv_plane = (size_t)W * H * Tp * 64; }
+    e.vt_tiled = enc_attention_vt_tiled(gdt) ? 1 : 0;
     WSEG_TRY(gemm(m, EPI_QKV_ENC, p.y, d, L.qkv_w, d, M, 3 * d, d, e, nullptr, s));
     WSEG_TRY(launch_enc_attention(gdt, p.q, p.k, p.vt, p.y, W, H, T, Tp, d, s));
     e = EpiParams();

@@ -27,7 +27,7 @@ from .windows import shard_bounds, window_table
 PROMPT_TOKENS = ["<|startoftranscript|>", "<|en|>", "<|notimestamps|>"]   # reference model.py:656
 # Engine mode when neither the constructor nor $WHISPERSEG_AMD_DTYPE names one: "f16m6", the MIXED split-precision mode — the
 # reference computes in fp32 (model.py:655-666), and this is the fastest mode that meets the north-star tolerance (clusters
-# exact, boundaries within +-1 mel frame) on every recording of the 200-recording parity sweep (profiles/README.md): GEMM operands
+# exact, boundaries within +-1 mel frame) on every recording of the 200-recording parity sweep (profiles/README.md, profiles/r06_parity_sweeps.json): GEMM operands
 # as hi + lo IEEE-half pairs, hi*hi on the half matrix cores and both cross terms on the block-scaled fp6 MX matrix cores, fp32
 # everywhere else; first-step logits within 3.7e-5 of the logit scale of the exact mode at 32 + 32 layers.  "f16x3" takes all
 # three products on the half matrix cores (3.3e-6 of the scale, ~10 % slower), "bf16x3" the same with bfloat16 halves (1.3e-5; no
