@@ -201,6 +201,29 @@ def test_two_layer_1024_windows_4096_rows(gpu_lib, two_layer):
         assert torch.equal(mid_t, t), dt
 
 
+def test_two_layer_tokens_do_not_depend_on_the_admission(gpu_lib, two_layer):
+    """in the split modes the admission's pass (forced prompt + first generated step) and the cross-K/V GEMMs used to
+    run on GEMM plans that followed the ADMISSION size — which depends on when a window's neighbours finished.  Since r06 they run on
+    plans fixed by the call (GemmArgs::plan_m: the decode step's plan for the pass, a full encoder chunk's for the cross K / V) and
+    the top-k slices the vocabulary as a decode step does.  Flat random-weight logits are the sensitive probe (top-1 / top-2 margins
+    down to summation-order noise): 40 windows with uneven length caps through 16 slots — the same windows in reversed order and
+    with single-slot refills (admissions of 1-3 windows instead of 2+) meet other neighbours in admissions of other sizes and must
+    decode to the same tokens."""
+    cfg, rc, sd, engines = two_layer
+    x = feats(40, seed=17)
+    caps = (torch.randint(4, 12, (40,), generator=torch.Generator().manual_seed(9)) + 3).to(torch.int32)
+    perm = torch.arange(39, -1, -1)
+    for dt in ("f16m6", "f16x3", "bf16x3", "f32"):
+        eng = engines[dt]
+        a_t, a_l = (v.cpu() for v in gen(eng, x, 4, 14, n_slots=16, window_max_length=caps))
+        assert eng.last_stats()["n_admissions"] >= 3, dt
+        b_t, b_l = (v.cpu() for v in gen(eng, x[perm], 4, 14, n_slots=16, window_max_length=caps[perm]))
+        assert torch.equal(b_l, a_l[perm]) and torch.equal(b_t, a_t[perm]), dt
+        c_t, c_l = (v.cpu() for v in gen(eng, x, 4, 14, n_slots=16, window_max_length=caps, refill_min=1))
+        assert eng.last_stats()["n_admissions"] > 6, dt
+        assert torch.equal(c_l, a_l) and torch.equal(c_t, a_t), dt
+
+
 @pytest.fixture(scope="module")
 def full_large():
     from whisperseg_amd.engine import Engine

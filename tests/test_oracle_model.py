@@ -70,3 +70,48 @@ def test_eos_fires_at_varied_lengths(tiny):
     _, _, runs, _ = tiny
     lengths = {len(content(row)) for run in runs for b in run["token_batches"] for row in b}
     assert len(lengths) >= 5
+
+
+# ---- the second (held-out) fixture model: another geometry (d 256, 4 heads, 3 + 3 layers), full-mantissa fp32 weights -----------------
+@pytest.fixture(scope="module")
+def tiny2(golden_dir):
+    from safetensors.torch import load_file
+    mdir = os.path.join(golden_dir, "tiny_model2")
+    sd = {k: v.float() for k, v in load_file(os.path.join(mdir, "model.safetensors")).items()}
+    with open(os.path.join(mdir, "config.json")) as f:
+        cfg = json.load(f)
+    with open(os.path.join(golden_dir, "tiny2_sweep.json")) as f:
+        sweep = json.load(f)
+    return sd, W.RefConfig.from_hf_dict(cfg), sweep, np.load(os.path.join(golden_dir, "tiny2_generate.npz"))
+
+
+def test_second_fixture_model_is_another_model(tiny, tiny2):
+    sd1, rc1 = tiny[0], tiny[1]
+    sd2, rc2, sweep, _ = tiny2
+    assert (rc2.d_model, rc2.encoder_layers, rc2.decoder_layers) == (256, 3, 3) and rc1.d_model == 128
+    w = sd2["model.decoder.layers.0.fc1.weight"]
+    assert not torch.equal(w, w.half().float()) and not torch.equal(w, w.bfloat16().float())      # full-mantissa weights: lo halves are live
+    assert len(sweep) == 1000 and {r["seed"] for r in sweep} == set(range(5000, 5250))
+
+
+def test_second_fixture_encoder_and_first_logits(tiny2):
+    """oracle vs HF (recorded by tools/make_golden.py --only sweep2) on the held-out model's geometry"""
+    sd, rc, _, z = tiny2
+    audio = GI.tiny_recording(5000, 3, variant="tiny2")
+    sliced = F.sliced_audio_features(audio, TM.SR, 0, TM.STS, 1)
+    feats = torch.from_numpy(np.stack([s[2] for s in sliced]))
+    enc = W.encoder_forward(sd, rc, feats)
+    assert np.max(np.abs(enc.numpy()[:, ::25, :] - z["enc_out_sample"])) <= 5e-4
+    gp = W.GenParams(prompt=TM.PROMPT, eos_token_id=TM.EOT, pad_token_id=TM.EOT, max_length=8, num_beams=1)
+    _, logits = W.generate(sd, rc, feats, gp, return_first_logits=True)
+    assert np.max(np.abs(logits.numpy() - z["first_logits"])) <= 3e-3
+
+
+def test_oracle_reproduces_heldout_rows(tiny2, golden_dir):
+    """the CPU oracle + the product's host epilogue through 12 of the 1 000 held-out recordings (all four (trials, beams) combinations)"""
+    from tools.precision_study import OracleSegmenter, Policy
+    _, _, sweep, _ = tiny2
+    seg = OracleSegmenter(Policy(""), model_dir=os.path.join(golden_dir, "tiny_model2"))
+    for run in sweep[0:8] + sweep[500:504]:
+        got = seg.segment(GI.tiny_recording(run["seed"], run["n_windows"], variant="tiny2"), TM.SR, **run["kwargs"])
+        assert got == run["expected"], (run["seed"], run["kwargs"])

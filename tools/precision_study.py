@@ -332,16 +332,17 @@ MARGINS = []      # (margin, top1 is a time token, top1 id) of every decode row-
 class OracleSegmenter(SegmenterBase):
     """SegmenterBase with the device stages replaced by the CPU oracle under a precision policy."""
 
-    def __init__(self, policy, collect_margins=False):
+    def __init__(self, policy, collect_margins=False, model_dir=None):
         super().__init__()
         from safetensors.torch import load_file
         self.P = policy
-        self.sd = {k: v.float() for k, v in load_file(os.path.join(MODEL_DIR, "model.safetensors")).items()}
-        with open(os.path.join(MODEL_DIR, "config.json")) as f:
+        model_dir = model_dir or MODEL_DIR
+        self.sd = {k: v.float() for k, v in load_file(os.path.join(model_dir, "model.safetensors")).items()}
+        with open(os.path.join(model_dir, "config.json")) as f:
             hf = json.load(f)
         self.cfg = W.RefConfig.from_hf_dict(hf)
         self._adopt_config(hf)
-        self.tokenizer = WhisperSegTokenizer.from_pretrained(MODEL_DIR, language="english")
+        self.tokenizer = WhisperSegTokenizer.from_pretrained(model_dir, language="english")
         self.device_list = ["cpu-oracle"]
         self.collect = collect_margins
         self.feat_cache = {}

@@ -1825,7 +1825,7 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
           while (S >= 2 && ((rem_tiles * S) % 8 || pairs / S < 2 || (size_t)S * pm * n2 * sizeof(float) > g.splitk_ws_bytes)) --S;
           if (S >= 2 && rem_tiles * S * 4 >= n_cu * 3) {
             int grid = ntm * full_cols < n_cu ? ntm * full_cols : n_cu;
-            grid = grid < 8 ? 8 : (grid & ~7);
+            grid = (grid + 7) & ~7;      // (a multiple of 8: one share per XCD; workgroups beyond the tile count return at once)
             hipLaunchKernelGGL((gemm_h16_pp_kernel<T, EPI>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, n1, g.K, g.ep, ntm, group_m, 1);
             GemmArgs g2 = g;
             g2.W = W + (size_t)n1 * g.ldw;
@@ -1849,14 +1849,14 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
       // error at 32 layers.)
       {
         int grid = ntiles < n_cu ? ntiles : n_cu;
-        grid = grid < 8 ? 8 : (grid & ~7);
+        grid = (grid + 7) & ~7;      // (a multiple of 8: one share per XCD; workgroups beyond the tile count return at once)
         hipLaunchKernelGGL((gemm_h16_pp_kernel<T, EPI>), dim3(grid), dim3(512), 0, s, A, g.lda, W, g.ldw, g.M, g.N, g.K, g.ep, ntm, group_m, 1);
       }
     } else {
       const int ntm = cdiv(g.M, 128), ntiles = ntm * (g.N / 128);
       if (persist && !no_swz && cdiv(pm, 128) * (g.N / 128) >= 16) {
         int grid = ntiles < 2 * n_cu ? ntiles : 2 * n_cu;
-        grid = grid < 8 ? 8 : (grid & ~7);
+        grid = (grid + 7) & ~7;      // (a multiple of 8: one share per XCD; workgroups beyond the tile count return at once)
         hipLaunchKernelGGL((gemm_h16_persist_kernel<T, 128, 128, 2, 2, EPI>), dim3(grid), dim3(256), 0, s, A, g.lda, W, g.ldw, g.M, g.N,
                            g.K, g.ep, ntm, group_m);
       } else {
@@ -2031,7 +2031,7 @@ template <typename T> static int launch_pp_splitk(const GemmArgs& g, int S, hipS
   static const int group_m = WSEG_KNOB_INT("WSEG_GEMM_GROUP_M", 4);
   const int ntm = cdiv(g.M, 256), ntiles = ntm * (g.N / 256) * S, n_cu = device_cu_count();
   int grid = ntiles < n_cu ? ntiles : n_cu;
-  grid = grid < 8 ? 8 : (grid & ~7);
+  grid = (grid + 7) & ~7;      // (a multiple of 8: one share per XCD; workgroups beyond the tile count return at once)
   EpiParams ep;
   ep.out_f32 = g.splitk_ws; ep.ldc = g.N;
   hipLaunchKernelGGL((gemm_h16_pp_kernel<T, EPI_F32, true>), dim3(grid), dim3(512), 0, s, (const HT*)g.A, g.lda, (const HT*)g.W, g.ldw,

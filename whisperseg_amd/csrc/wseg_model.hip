@@ -680,7 +680,11 @@ static int generate_windows(wseg_model* m, const float* feats, int n_windows, co
         EpiParams e;
         e.bias = m->dec[l].ckv_b; e.k = q.ck + l * cross_stride; e.v = q.cv + l * cross_stride;
         e.d_model = d; e.t_len = Tk; e.n_heads = H; e.slot_map = q.adm_slots + off + c0; e.kv24 = kv24;
-        WSEG_TRY(gemm(m, EPI_KV_CROSS, enc_rows, d, m->dec[l].ckv_w, d, nc * Tk, 2 * d, d, e, &q, s));
+        // planned for a full encoder chunk whatever the admission holds: below ~5 windows the launcher would otherwise pick the stream
+        // family with a split-K count that follows the row count — a window's cross K / V (and through their block-floating-point
+        // rounding its tokens on a near-tie) would depend on how many windows were admitted with it.  The un-split large-tile
+        // families compute every output element as the same K-ordered MFMA chain (r06, with GemmArgs::plan_m for the pass).
+        WSEG_TRY(gemm(m, EPI_KV_CROSS, enc_rows, d, m->dec[l].ckv_w, d, nc * Tk, 2 * d, d, e, &q, s, nullptr, ENC_CHUNK * Tk));
       }
       WSEG_TRY(timing_event(ln, s, &e2));
       ln.ev_enc.push_back(e0); ln.ev_enc.push_back(e1); ln.ev_ckv.push_back(e1); ln.ev_ckv.push_back(e2);

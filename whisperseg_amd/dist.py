@@ -72,7 +72,9 @@ def broadcast_weights(weights, src=0):
     large bf16 = 3.08 GB: one pipelined ring broadcast is bounded by a single xGMI link (~153 GB/s)."""
     if not _single():
         for name in sorted(weights):
-            dist.broadcast(weights[name], src)
+            # as BYTES: the operand rows of the split-precision modes are int16 tensors, a dtype RCCL / NCCL has no name for
+            # (ProcessGroupNCCL maps int8 / uint8 / int32 / int64 / half / float / double / bfloat16 only); a broadcast is a copy
+            dist.broadcast(weights[name].view(torch.uint8), src)
     return weights
 
 
