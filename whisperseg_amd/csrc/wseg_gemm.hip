@@ -17,282 +17,9 @@
 #include <type_traits>
 
 #include <vector>
-#include "wseg_kernels.h"
+#include "wseg_gemm_epi.h"
 
 namespace wseg {
-
-// ------------------------------------------------------------------------------------------------
-// Epilogue: 4 consecutive columns n0..n0+3 of row m.
-// ------------------------------------------------------------------------------------------------
-template <typename T> struct Vec4 {      // 16-bit element types
-  static __device__ __forceinline__ void ld(const T* p, float v[4]) {
-    const uint2 t = *(const uint2*)p;
-    v[0] = H16<T>::lo(t.x); v[1] = H16<T>::hi(t.x);
-    v[2] = H16<T>::lo(t.y); v[3] = H16<T>::hi(t.y);
-  }
-  static __device__ __forceinline__ void st(T* p, const float v[4]) {
-    uint2 t;
-    t.x = H16<T>::pack(v[0], v[1]);
-    t.y = H16<T>::pack(v[2], v[3]);
-    *(uint2*)p = t;
-  }
-};
-template <> struct Vec4<float> {
-  static __device__ __forceinline__ void ld(const float* p, float v[4]) {
-    const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-  }
-  static __device__ __forceinline__ void st(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
-};
-
-// Cross K / V as block floating point (EpiParams::kv24 == 2): the NL lanes that hold the 64 columns of one (position, head) row — 8
-// consecutive lanes with 8 columns each (LDS-staged epilogues) or 16 with 4 each (split-K reduction) — agree on the row's power-of-two
-// scale by DPP (the smallest 2^s with max|v| <= 2^15 * 2^s ... so that |v / 2^s| <= 32767 after the clamp), every lane stores its columns
-// as int16 (round to nearest even) and the first lane the scale.  blk: the (slot, head) block [t_len][64] int16 + [t_len] float.
-template <int NC>
-__device__ __forceinline__ void st_bfp16_row(unsigned char* blk, int t_len, int t, int e, const float (&v)[NC], bool first_lane) {
-  static_assert(NC == 4 || NC == 8, "4 or 8 columns per lane");
-  float am = 0.f;
-#pragma unroll
-  for (int i = 0; i < NC; ++i) am = fmaxf(am, fabsf(v[i]));
-  am = fmaxf(am, lane_xor<1>(am));
-  am = fmaxf(am, lane_xor<2>(am));
-  am = fmaxf(am, lane_xor<4>(am));
-  if constexpr (NC == 4) am = fmaxf(am, lane_xor<8>(am));
-  const unsigned bits = __float_as_uint(am);
-  int ex = (int)(bits >> 23) - 127 + ((bits & 0x7fffffu) ? 1 : 0) - 15;      // ceil(log2 max) - 15
-  ex = max(-110, min(ex, 110));
-  const float inv = __uint_as_float((unsigned)(127 - ex) << 23), scl = __uint_as_float((unsigned)(127 + ex) << 23);
-  int q[NC];
-#pragma unroll
-  for (int i = 0; i < NC; ++i) q[i] = max(-32767, min(32767, (int)__builtin_rintf(v[i] * inv)));
-  unsigned w[NC / 2];
-#pragma unroll
-  for (int i = 0; i < NC / 2; ++i) w[i] = ((unsigned)q[2 * i] & 0xffffu) | ((unsigned)q[2 * i + 1] << 16);
-  unsigned char* dst = blk + (size_t)t * 128 + e * 2;
-  if constexpr (NC == 8) *(uint4*)dst = make_uint4(w[0], w[1], w[2], w[3]);
-  else *(uint2*)dst = make_uint2(w[0], w[1]);
-  if (first_lane) *(float*)(blk + (size_t)t_len * 128 + (size_t)t * 4) = scl;
-}
-
-// T: element-type tag of the mode (float | bf16_t | f16_t | X3<HT>); PT: its plain parameter type (bias, positional table,
-// q / k / v storage: float in the split-precision modes).  Outputs that are the NEXT GEMM's operand (EPI_STORE, EPI_GELU) go
-// through op_st*, i.e. as hi | lo pairs in the split-precision modes.
-template <int EPI, typename T>
-__device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, float v[4]) {
-  typedef typename IO<T>::P PT;
-  if (ep.bias) {
-    float b[4];
-    Vec4<PT>::ld((const PT*)ep.bias + n0, b);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] += b[i];
-  }
-  if constexpr (EPI == EPI_STORE) {
-    op_st4<T>(ep.out, (size_t)m, ep.ldc, n0, v);
-  } else if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = gelu_for<T>(v[i]);
-    op_st4<T>(ep.out, (size_t)m, ep.ldc, n0, v);
-  } else if constexpr (EPI == EPI_RESID) {      // the residual stream is fp32 in every mode
-    float r[4];
-    Vec4<float>::ld((const float*)ep.resid + (size_t)m * ep.ldc + n0, r);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = r[i] + v[i];
-    Vec4<float>::st((float*)ep.out + (size_t)m * ep.ldc + n0, v);
-  } else if constexpr (EPI == EPI_GELU_POS) {   // conv2 -> residual stream (fp32)
-    float p[4];
-    Vec4<PT>::ld((const PT*)ep.pos + (size_t)(m % ep.pos_rows) * ep.ldc + n0, p);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = gelu_for<T>(v[i]) + p[i];
-    Vec4<float>::st((float*)ep.out + (size_t)m * ep.ldc + n0, v);
-  } else if constexpr (EPI == EPI_QKV_ENC) {
-    const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
-    const int b = m / ep.t_len, t = m - b * ep.t_len;
-    const size_t bh = (size_t)b * ep.n_heads + h;
-    if (sec == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] *= ep.scale;
-    }
-    auto put = [&](auto* base, size_t plane, const float* x) {
-      typedef std::remove_pointer_t<decltype(base)> QT;
-      if (sec == 0) Vec4<QT>::st((QT*)ep.q + plane + (bh * ep.t_pad + t) * 64 + e, x);
-      else if (sec == 1) Vec4<QT>::st((QT*)ep.k + plane + (bh * ep.t_pad + t) * 64 + e, x);
-      else if (ep.vt_tiled) {
-        QT* vt = (QT*)ep.v + plane + bh * 64 * ep.t_pad;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) El<QT>::st(vt + vt_tiled_index(e + i, t), x[i]);
-      } else {
-        QT* vt = (QT*)ep.v + plane + (bh * 64 + e) * ep.t_pad + t;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) El<QT>::st(vt + (size_t)i * ep.t_pad, x[i]);
-      }
-    };
-    typedef typename IO<T>::A AT;
-    if (IO<T>::split && ep.qkv_mode == 1) put((float*)nullptr, 0, v);
-    else {
-      if constexpr (IO<T>::split) {                // the encoder attention's Q / K / V^T are IEEE-half planes in BOTH split modes:
-#pragma unroll                                     // saturate like every other split operand (inf - inf = NaN in the lo plane otherwise)
-        for (int i = 0; i < 4; ++i) v[i] = H16<AT>::sat(v[i]);
-      }
-      put((AT*)nullptr, 0, v);
-      if (IO<T>::split && ep.qkv_mode == 2) {      // lo plane: x - rn(x)
-        float lo[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) lo[i] = v[i] - El<AT>::rnd(v[i]);
-        put((AT*)nullptr, ep.qkv_plane, lo);
-      }
-    }
-  } else if constexpr (EPI == EPI_KV_CROSS) {
-    const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
-    const int b = m / ep.t_len, t = m - b * ep.t_len;
-    const int bs = ep.slot_map ? ep.slot_map[b] : b;
-    if (IO<T>::split && ep.kv24 == 2) {      // (reached from the split-K reduction only: 16 consecutive threads hold one row)
-      unsigned char* blk = (unsigned char*)(sec == 0 ? ep.k : ep.v) + ((size_t)bs * ep.n_heads + h) * ep.t_len * 132;
-      st_bfp16_row<4>(blk, ep.t_len, t, e, *(const float(*)[4])v, e == 0);
-    } else if (IO<T>::split && ep.kv24) {
-      unsigned char* blk = (unsigned char*)(sec == 0 ? ep.k : ep.v) + ((size_t)bs * ep.n_heads + h) * ep.t_len * 192;
-      unsigned w[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) w[i] = __float_as_uint(v[i]) + 0x80u;        // round to 24 bits (half up in magnitude)
-      *(uint2*)(blk + (size_t)t * 128 + e * 2) = make_uint2((w[0] >> 16) | (w[1] & 0xffff0000u), (w[2] >> 16) | (w[3] & 0xffff0000u));
-      *(unsigned*)(blk + (size_t)ep.t_len * 128 + (size_t)t * 64 + e) =
-          ((w[0] >> 8) & 0xffu) | (w[1] & 0xff00u) | ((w[2] << 8) & 0xff0000u) | ((w[3] << 16) & 0xff000000u);
-    } else {
-      PT* dst = (PT*)(sec == 0 ? ep.k : ep.v) + (((size_t)bs * ep.n_heads + h) * ep.t_len + t) * 64 + e;
-      Vec4<PT>::st(dst, v);
-    }
-  } else if constexpr (EPI == EPI_F32) {
-    *(float4*)(ep.out_f32 + (size_t)m * ep.ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
-  } else if constexpr (EPI == EPI_QKV_DEC) {
-    const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
-    if (sec == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] *= ep.scale;
-      Vec4<PT>::st((PT*)ep.q + (size_t)m * d + nn, v);
-    } else {
-      const int slot = m / ep.pos_div, beam = m - slot * ep.pos_div;
-      if (ep.idle_ptr[slot]) return;
-      const int pos = ep.pos_ptr[slot];
-      const int unit = ep.kv_pt[(size_t)slot * ep.kv_npg + pos / KV_PAGE];
-      PT* dst = (PT*)(sec == 1 ? ep.k : ep.v) +
-                ((((size_t)unit * ep.pos_div + beam) * ep.n_heads + h) * KV_PAGE + (pos % KV_PAGE)) * 64 + e;
-      Vec4<PT>::st(dst, v);
-    }
-  } else if constexpr (EPI == EPI_SCALE) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] *= ep.scale;
-    Vec4<PT>::st((PT*)ep.out + (size_t)m * ep.ldc + n0, v);
-  }
-}
-
-// 8 consecutive columns n0..n0+7 of row m (MFMA paths, LDS-staged epilogue): 16-byte loads / stores.
-template <typename PT> __device__ __forceinline__ void ld8_h(const PT* p, float v[8]) {
-  if constexpr (sizeof(PT) == 4) {
-    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-  } else {
-    unpack8<PT>(*(const uint4*)p, v);
-  }
-}
-template <typename PT> __device__ __forceinline__ void st8_h(PT* p, const float v[8]) {
-  if constexpr (sizeof(PT) == 4) {
-    *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
-    *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
-  } else {
-    *(uint4*)p = pack8<PT>(v);
-  }
-}
-
-template <int EPI, typename T>
-__device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, float v[8]) {
-  typedef typename IO<T>::P PT;
-  if (ep.bias) {
-    float b[8];
-    ld8_h<PT>((const PT*)ep.bias + n0, b);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] += b[i];
-  }
-  if constexpr (EPI == EPI_STORE) {
-    op_st8<T>(ep.out, (size_t)m, ep.ldc, n0, v);
-  } else if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = gelu_for<T>(v[i]);
-    op_st8<T>(ep.out, (size_t)m, ep.ldc, n0, v);
-  } else if constexpr (EPI == EPI_RESID) {      // the residual stream is fp32 in every mode
-    const float* rp = (const float*)ep.resid + (size_t)m * ep.ldc + n0;
-    const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
-    float* o = (float*)ep.out + (size_t)m * ep.ldc + n0;
-    *(float4*)o = make_float4(r0.x + v[0], r0.y + v[1], r0.z + v[2], r0.w + v[3]);
-    *(float4*)(o + 4) = make_float4(r1.x + v[4], r1.y + v[5], r1.z + v[6], r1.w + v[7]);
-  } else if constexpr (EPI == EPI_GELU_POS) {   // conv2 -> residual stream (fp32)
-    float p[8];
-    ld8_h<PT>((const PT*)ep.pos + (size_t)(m % ep.pos_rows) * ep.ldc + n0, p);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = gelu_for<T>(v[i]) + p[i];
-    float* o = (float*)ep.out + (size_t)m * ep.ldc + n0;
-    *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-    *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-  } else if constexpr (EPI == EPI_QKV_ENC) {
-    const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
-    const int b = m / ep.t_len, t = m - b * ep.t_len;
-    const size_t bh = (size_t)b * ep.n_heads + h;
-    if (sec == 0) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] *= ep.scale;
-    }
-    auto put = [&](auto* base, size_t plane, const float* x) {
-      typedef std::remove_pointer_t<decltype(base)> QT;
-      if (sec == 0) st8_h<QT>((QT*)ep.q + plane + (bh * ep.t_pad + t) * 64 + e, x);
-      else if (sec == 1) st8_h<QT>((QT*)ep.k + plane + (bh * ep.t_pad + t) * 64 + e, x);
-      else if (ep.vt_tiled) {
-        QT* vt = (QT*)ep.v + plane + bh * 64 * ep.t_pad;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) El<QT>::st(vt + vt_tiled_index(e + i, t), x[i]);
-      } else {
-        QT* vt = (QT*)ep.v + plane + (bh * 64 + e) * ep.t_pad + t;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) El<QT>::st(vt + (size_t)i * ep.t_pad, x[i]);
-      }
-    };
-    typedef typename IO<T>::A AT;
-    if (IO<T>::split && ep.qkv_mode == 1) put((float*)nullptr, 0, v);
-    else {
-      if constexpr (IO<T>::split) {                // IEEE-half planes in both split modes: saturate (see epi_apply)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = H16<AT>::sat(v[i]);
-      }
-      put((AT*)nullptr, 0, v);
-      if (IO<T>::split && ep.qkv_mode == 2) {      // lo plane: x - rn(x)
-        float lo[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) lo[i] = v[i] - El<AT>::rnd(v[i]);
-        put((AT*)nullptr, ep.qkv_plane, lo);
-      }
-    }
-  } else if constexpr (EPI == EPI_KV_CROSS) {
-    const int d = ep.d_model, sec = n0 / d, nn = n0 - sec * d, h = nn >> 6, e = nn & 63;
-    const int b = m / ep.t_len, t = m - b * ep.t_len;
-    const int bs = ep.slot_map ? ep.slot_map[b] : b;
-    if (IO<T>::split && ep.kv24 == 2) {      // the 8 lanes of the row (LDS-staged epilogues: lane & 7 = column group)
-      unsigned char* blk = (unsigned char*)(sec == 0 ? ep.k : ep.v) + ((size_t)bs * ep.n_heads + h) * ep.t_len * 132;
-      st_bfp16_row<8>(blk, ep.t_len, t, e, *(const float(*)[8])v, e == 0);
-    } else if (IO<T>::split && ep.kv24) {
-      EpiParams e2 = ep;                        // the bias has been added above
-      e2.bias = nullptr;
-      epi_apply<EPI, T>(e2, m, n0, v);
-      epi_apply<EPI, T>(e2, m, n0 + 4, v + 4);
-    } else {
-      PT* dst = (PT*)(sec == 0 ? ep.k : ep.v) + (((size_t)bs * ep.n_heads + h) * ep.t_len + t) * 64 + e;
-      st8_h<PT>(dst, v);
-    }
-  } else if constexpr (EPI == EPI_F32) {
-    float* o = ep.out_f32 + (size_t)m * ep.ldc + n0;
-    *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-    *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-  } else {
-    epi_apply<EPI, T>(ep, m, n0, v);
-    epi_apply<EPI, T>(ep, m, n0 + 4, v + 4);
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // bf16 MFMA kernel
@@ -1358,228 +1085,6 @@ __global__ __launch_bounds__(256) void splitk_reduce8_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// f32 exact kernel: 64x64 tile, 4x4 micro-tile per thread, sequential-k fmaf chain.
-// ------------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
-                                                       int M, int N, int K, EpiParams ep) {
-  __shared__ float sA[16][68];
-  __shared__ float sW[16][68];
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  const int lr = tid >> 2, lq = (tid & 3) * 4;
-  float acc[4][4] = {};
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    const float4 av = *(const float4*)(A + (size_t)(m0 + lr) * lda + k0 + lq);
-    const float4 wv = *(const float4*)(W + (size_t)(n0 + lr) * ldw + k0 + lq);
-    sA[lq + 0][lr] = av.x; sA[lq + 1][lr] = av.y; sA[lq + 2][lr] = av.z; sA[lq + 3][lr] = av.w;
-    sW[lq + 0][lr] = wv.x; sW[lq + 1][lr] = wv.y; sW[lq + 2][lr] = wv.z; sW[lq + 3][lr] = wv.w;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      float a[4], w[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { a[i] = sA[k][ty * 4 + i]; w[i] = sW[k][tx * 4 + i]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], w[j], acc[i][j]);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty * 4 + i;
-    if (m < M) epi_apply<EPI, float>(ep, m, n0 + tx * 4, acc[i]);
-  }
-}
-
-// f32 exact kernel for large problems: 128x128 tile, 8x8 micro-tile per thread (twice the FMAs per LDS float of the 64x64
-// kernel, which is LDS-bound at ~30 % of the fp32 VALU peak), next K slab prefetched into registers under the FMAs.  Every
-// output element is still ONE fmaf chain over k = 0, 1, 2, ... — bit-identical to gemm_f32_kernel, whatever the tiling.
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_f32_big_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
-                                                              int M, int N, int K, EpiParams ep) {
-  constexpr int BK = 16, LD = 128 + 4;
-  __shared__ float sA[2][BK][LD];
-  __shared__ float sW[2][BK][LD];
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
-  // loads: 128 rows x 16 k per operand = 512 float4, two per thread: rows lr and lr + 64, k offset lq
-  const int lr = tid >> 2, lq = (tid & 3) * 4;
-  const float* ap = A + (size_t)(m0 + lr) * lda + lq;
-  const float* wp = W + (size_t)(n0 + lr) * ldw + lq;
-  const size_t a64 = (size_t)64 * lda, w64 = (size_t)64 * ldw;
-  float4 ra0 = *(const float4*)ap, ra1 = *(const float4*)(ap + a64);
-  float4 rw0 = *(const float4*)wp, rw1 = *(const float4*)(wp + w64);
-  auto stage = [&](int b) {
-    sA[b][lq + 0][lr] = ra0.x; sA[b][lq + 1][lr] = ra0.y; sA[b][lq + 2][lr] = ra0.z; sA[b][lq + 3][lr] = ra0.w;
-    sA[b][lq + 0][lr + 64] = ra1.x; sA[b][lq + 1][lr + 64] = ra1.y; sA[b][lq + 2][lr + 64] = ra1.z; sA[b][lq + 3][lr + 64] = ra1.w;
-    sW[b][lq + 0][lr] = rw0.x; sW[b][lq + 1][lr] = rw0.y; sW[b][lq + 2][lr] = rw0.z; sW[b][lq + 3][lr] = rw0.w;
-    sW[b][lq + 0][lr + 64] = rw1.x; sW[b][lq + 1][lr + 64] = rw1.y; sW[b][lq + 2][lr + 64] = rw1.z; sW[b][lq + 3][lr + 64] = rw1.w;
-  };
-  stage(0);
-  __syncthreads();
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  f2 acc2[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc2[i][j] = (f2){0.f, 0.f};
-  const int nk = K / BK;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int b = kt & 1;
-    if (kt + 1 < nk) {
-      ra0 = *(const float4*)(ap + (kt + 1) * BK); ra1 = *(const float4*)(ap + a64 + (kt + 1) * BK);
-      rw0 = *(const float4*)(wp + (kt + 1) * BK); rw1 = *(const float4*)(wp + w64 + (kt + 1) * BK);
-    }
-#pragma unroll 2
-    for (int k = 0; k < BK; ++k) {          // (a full unroll hoists all 64 LDS reads and spills)
-      // rows ty*4 + {0..3} and 64 + ty*4 + {0..3}; columns tx*4 + {0..3} and 64 + tx*4 + {0..3}: 16-byte LDS reads
-      const float4 a0 = *(const float4*)&sA[b][k][ty * 4], a1 = *(const float4*)&sA[b][k][64 + ty * 4];
-      const float4 w0 = *(const float4*)&sW[b][k][tx * 4], w1 = *(const float4*)&sW[b][k][64 + tx * 4];
-      const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-      const f2 w2[4] = {{w0.x, w0.y}, {w0.z, w0.w}, {w1.x, w1.y}, {w1.z, w1.w}};
-      // two columns per v_pk_fma_f32 (each half is an IEEE fma: same bits as fmaf)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const f2 aa = {a[i], a[i]};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc2[i][j] = __builtin_elementwise_fma(aa, w2[j], acc2[i][j]);
-      }
-    }
-    if (kt + 1 < nk) stage(b ^ 1);          // the other buffer was last read before the barrier that closed slab kt - 1
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + (i >> 2) * 64 + ty * 4 + (i & 3);
-    if (m < M) {
-      float v0[4] = {acc2[i][0][0], acc2[i][0][1], acc2[i][1][0], acc2[i][1][1]};
-      float v1[4] = {acc2[i][2][0], acc2[i][2][1], acc2[i][3][0], acc2[i][3][1]};
-      epi_apply<EPI, float>(ep, m, n0 + tx * 4, v0);
-      epi_apply<EPI, float>(ep, m, n0 + 64 + tx * 4, v1);
-    }
-  }
-}
-
-// f32 exact kernels on the fp32 matrix cores: v_mfma_f32_32x32x2_f32 is bit for bit a k-ordered fmaf chain (one rounding per
-// product, no wider accumulation; MI355X_MICROARCH.md), so these produce exactly the bits of gemm_f32_kernel at the f32 VECTOR
-// rate but with two LDS dwords per 4096 FMAs instead of one per two.  2 x 2 waves, wave tile (32 TI) x (32 TJ); the weight
-// rows are the MFMA's A operand and the activation rows its B operand, so a lane ends up with 4 consecutive output columns.
-template <int EPI, int TI, int TJ>
-__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
-                                                            int M, int N, int K, EpiParams ep) {
-  constexpr int BM = 64 * TI, BN = 64 * TJ, BK = 16, LDA = BM + 4, LDW = BN + 4;
-  __shared__ float sA[2][BK][LDA];
-  __shared__ float sW[2][BK][LDW];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int lr = tid >> 2, lq = (tid & 3) * 4;          // global loads: row lr (+ 64 i), k offset lq, 16 bytes each
-  const float* ap = A + (size_t)(m0 + lr) * lda + lq;
-  const float* wp = W + (size_t)(n0 + lr) * ldw + lq;
-  float4 ra[TI], rw[TJ];
-  auto fetch = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < TI; ++i) ra[i] = *(const float4*)(ap + (size_t)(64 * i) * lda + kt * BK);
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) rw[j] = *(const float4*)(wp + (size_t)(64 * j) * ldw + kt * BK);
-  };
-  auto stage = [&](int b) {
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-      sA[b][lq + 0][lr + 64 * i] = ra[i].x; sA[b][lq + 1][lr + 64 * i] = ra[i].y;
-      sA[b][lq + 2][lr + 64 * i] = ra[i].z; sA[b][lq + 3][lr + 64 * i] = ra[i].w;
-    }
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-      sW[b][lq + 0][lr + 64 * j] = rw[j].x; sW[b][lq + 1][lr + 64 * j] = rw[j].y;
-      sW[b][lq + 2][lr + 64 * j] = rw[j].z; sW[b][lq + 3][lr + 64 * j] = rw[j].w;
-    }
-  };
-  f32x16 acc[TI][TJ];
-#pragma unroll
-  for (int i = 0; i < TI; ++i)
-#pragma unroll
-    for (int j = 0; j < TJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  fetch(0);
-  stage(0);
-  __syncthreads();
-  const int nk = K / BK, fi = lane & 31, fk = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int b = kt & 1;
-    if (kt + 1 < nk) fetch(kt + 1);
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {                 // lanes 0-31 carry k = kk, lanes 32-63 k = kk + 1: ascending k
-      float af[TI], wf[TJ];
-#pragma unroll
-      for (int i = 0; i < TI; ++i) af[i] = sA[b][kk + fk][wm * 32 * TI + i * 32 + fi];
-#pragma unroll
-      for (int j = 0; j < TJ; ++j) wf[j] = sW[b][kk + fk][wn * 32 * TJ + j * 32 + fi];
-#pragma unroll
-      for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j], af[i], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) stage(b ^ 1);
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < TI; ++i) {
-    const int m = m0 + wm * 32 * TI + i * 32 + fi;
-    if (m >= M) continue;
-#pragma unroll
-    for (int j = 0; j < TJ; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        epi_apply<EPI, float>(ep, m, n0 + wn * 32 * TJ + j * 32 + 8 * q + 4 * fk, v);
-      }
-  }
-}
-
-// The same for problems whose 64x64 tiles would not fill the chip (decoder steps, small encoders): 32x32 tile, 2 x 2 waves of
-// one v_mfma_f32_16x16x4_f32 accumulator each (also a k-ordered fmaf chain: same bits again).
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_mfma16_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
-                                                              int M, int N, int K, EpiParams ep) {
-  constexpr int BK = 16, LD = 32 + 4;
-  __shared__ float sA[2][BK][LD];
-  __shared__ float sW[2][BK][LD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-  // loads: 32 rows x 16 k per operand = 128 float4: threads 0-127 fetch A, 128-255 fetch W
-  const bool isw = tid >= 128;
-  const int lt = tid & 127, lr = lt >> 2, lq = (lt & 3) * 4;
-  const float* src = isw ? W + (size_t)(n0 + lr) * ldw + lq : A + (size_t)(m0 + lr) * lda + lq;
-  float4 rg = *(const float4*)src;
-  auto stage = [&](int b) {
-    float (*dst)[LD] = isw ? sW[b] : sA[b];
-    dst[lq + 0][lr] = rg.x; dst[lq + 1][lr] = rg.y; dst[lq + 2][lr] = rg.z; dst[lq + 3][lr] = rg.w;
-  };
-  stage(0);
-  __syncthreads();
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const int nk = K / BK, fi = lane & 15, fk = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int b = kt & 1;
-    if (kt + 1 < nk) rg = *(const float4*)(src + (kt + 1) * BK);
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 4)                   // lane group fk carries k = kk + fk: ascending k inside the instruction
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sW[b][kk + fk][wn * 16 + fi], sA[b][kk + fk][wm * 16 + fi], acc, 0, 0, 0);
-    if (kt + 1 < nk) stage(b ^ 1);
-    __syncthreads();
-  }
-  const int m = m0 + wm * 16 + fi;
-  if (m < M) {
-    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-    epi_apply<EPI, float>(ep, m, n0 + wn * 16 + 4 * fk, v);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Live profiler of the dominant kernel (wseg_profile_begin / wseg_profile_end)
 // ------------------------------------------------------------------------------------------------
 // Process-wide and meant for ONE measuring thread (bench.py's roofline leg); a mutex keeps concurrent device threads from
@@ -1601,7 +1106,7 @@ static GemmProfiler g_prof;
 // Launchers
 // ------------------------------------------------------------------------------------------------
 // CU count of the CURRENT device, cached per device (thread-per-device mode drives several devices from one process).
-static int device_cu_count() {
+int device_cu_count() {
   static int cached[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
@@ -1918,46 +1423,13 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
 }
 
 template <int EPI>
-static int launch_f32(const GemmArgs& g, hipStream_t s) {
-  if (g.K % 16 || g.N % 64) { set_error("gemm f32: K %d / N %d not tile multiples", g.K, g.N); return WSEG_ERR_INVALID; }
-  // WSEG_F32_GEMM = valu64 | valu128 | mfma64 | mfma (default): test knob; all four compute the same bits
-  static const char* mode_env = getenv("WSEG_F32_GEMM");
-  static const int mode = !mode_env ? 3 : (!strcmp(mode_env, "valu64") ? 0 : !strcmp(mode_env, "valu128") ? 1 : !strcmp(mode_env, "mfma64") ? 2 : 3);
-  const bool big = g.N % 128 == 0 && (long)cdiv(g.M, 128) * (g.N / 128) >= 2L * device_cu_count();
-  if (mode == 1 && big) {
-    dim3 gridb(g.N / 128, cdiv(g.M, 128));
-    hipLaunchKernelGGL((gemm_f32_big_kernel<EPI>), gridb, dim3(256), 0, s, (const float*)g.A, g.lda, (const float*)g.W, g.ldw, g.M, g.N, g.K, g.ep);
-    WSEG_LAUNCH_CHECK();
-    return WSEG_OK;
-  }
-  if (mode >= 2) {
-    if (mode == 3 && big) {
-      dim3 gridb(g.N / 128, cdiv(g.M, 128));
-      hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, 2, 2>), gridb, dim3(256), 0, s, (const float*)g.A, g.lda, (const float*)g.W, g.ldw, g.M, g.N, g.K, g.ep);
-    } else if (mode == 3 && (long)cdiv(g.M, 64) * (g.N / 64) < device_cu_count()) {
-      dim3 gridt(g.N / 32, cdiv(g.M, 32));
-      hipLaunchKernelGGL((gemm_f32_mfma16_kernel<EPI>), gridt, dim3(256), 0, s, (const float*)g.A, g.lda, (const float*)g.W, g.ldw, g.M, g.N, g.K, g.ep);
-    } else {
-      dim3 grids(g.N / 64, cdiv(g.M, 64));
-      hipLaunchKernelGGL((gemm_f32_mfma_kernel<EPI, 1, 1>), grids, dim3(256), 0, s, (const float*)g.A, g.lda, (const float*)g.W, g.ldw, g.M, g.N, g.K, g.ep);
-    }
-    WSEG_LAUNCH_CHECK();
-    return WSEG_OK;
-  }
-  dim3 grid(g.N / 64, cdiv(g.M, 64));
-  hipLaunchKernelGGL((gemm_f32_kernel<EPI>), grid, dim3(256), 0, s, (const float*)g.A, g.lda, (const float*)g.W, g.ldw, g.M, g.N, g.K, g.ep);
-  WSEG_LAUNCH_CHECK();
-  return WSEG_OK;
-}
-
-template <int EPI>
 static int launch_any(int dtype, const GemmArgs& g, hipStream_t s) {
   if (dtype == WSEG_BF16) return launch_h16<EPI, bf16_t>(g, s);
   if (dtype == WSEG_F16) return launch_h16<EPI, f16_t>(g, s);
   if (dtype == WSEG_BF16X3) return launch_h16<EPI, X3<bf16_t>>(g, s);
   if (dtype == WSEG_F16X3) return launch_h16<EPI, X3<f16_t>>(g, s);
   if (dtype == WSEG_F16M6) return launch_h16<EPI, M6>(g, s);
-  return launch_f32<EPI>(g, s);
+  return launch_gemm_f32((EpiKind)EPI, g, s);      // exact-parity kernels: wseg_gemm_f32.hip
 }
 
 template <typename T>

@@ -80,6 +80,10 @@ struct GemmArgs {
 // M may be any value as long as A has round_up(M,256) readable rows; N % 128 == 0 rows of W readable; K % 64 == 0
 // (K % 32 == 0 in the split-precision modes).
 int launch_gemm(int dtype, EpiKind epi, const GemmArgs& g, hipStream_t s);
+// the exact-parity fp32 kernels (wseg_gemm_f32.hip; reached through launch_gemm with WSEG_F32)
+int launch_gemm_f32(EpiKind epi, const GemmArgs& g, hipStream_t s);
+// CU count of the CURRENT device, cached per device
+int device_cu_count();
 // WSEG_F16M6: does an EPI_STORE / EPI_GELU launch of this (logical) shape write M6 rows (true) or hi | lo rows (false)?
 // splitk_ws_bytes: the split-K workspace the launch will be given (0: none) — the skinny family writes M6 rows when it splits K
 // (M: the rows the PLAN is chosen for — GemmArgs::plan_m when the launch sets it)
