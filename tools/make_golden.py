@@ -313,9 +313,24 @@ def make_sweep2(ref_audio, ref_model):
     "tiny2" — d 256, 4 heads, 3 + 3 layers, another init seed, another data stream and signal family, full-mantissa fp32 weights).
     Every precision format of r03-r05 (fp6 cross terms, block-floating-point cross K / V, 24-bit rows, fp32 self-attention cache, ...)
     was chosen on tiny_sweep.json; nothing was tuned on this file: the formats were frozen (commit before this one) when it was recorded."""
+    torch.set_num_threads(1)      # one thread: the recorded rows must not depend on how the CPU GEMMs were partitioned (serial run == parallel parts)
     hf, segm, captured = load_fixture_segmenter(ref_model, os.path.join(OUT, "tiny_model2"))
     sweep = []
-    for seed in range(5000, 5250):
+    # SWEEP2_PART="lo:hi" records seeds [lo, hi) into tiny2_sweep.part_<lo>.json (parallel workers, each OMP_NUM_THREADS=2: one serial pass
+    # takes ~2 h on the build container); SWEEP2_MERGE=1 concatenates the parts in seed order into tiny2_sweep.json and records the logits
+    part = os.environ.get("SWEEP2_PART")
+    lo, hi = (int(v) for v in part.split(":")) if part else (5000, 5250)
+    if os.environ.get("SWEEP2_MERGE"):
+        import glob
+        parts = sorted(glob.glob(os.path.join(OUT, "tiny2_sweep.part_*.json")))
+        for pth in parts:
+            with open(pth) as f:
+                sweep += json.load(f)
+        assert [r["seed"] for r in sweep[::4]] == list(range(5000, 5250)), "parts do not cover seeds 5000..5249 once"
+        for pth in parts:
+            os.remove(pth)
+        lo = hi = 0
+    for seed in range(lo, hi):
         nw = 1 + seed % 3
         audio = GI.tiny_recording(seed, nw, variant="tiny2")
         for trials in (1, 3):
@@ -323,6 +338,10 @@ def make_sweep2(ref_audio, ref_model):
                 kw = dict(num_beams=beams, num_trials=trials, batch_size=8)
                 sweep.append(dict(seed=seed, n_windows=nw, kwargs=kw, expected=segm.segment(audio, TM.SR, **kw)))
         print("sweep2 seed", seed, [len(r["expected"]["onset"]) for r in sweep[-4:]], flush=True)
+    if part:
+        with open(os.path.join(OUT, "tiny2_sweep.part_%d.json" % lo), "w") as f:
+            json.dump(sweep, f)
+        return
     with open(os.path.join(OUT, "tiny2_sweep.json"), "w") as f:
         json.dump(sweep, f)
     # first-step logits of 4 windows (pins the oracle / the engines on this model's geometry as G6 does for the first model)
