@@ -26,7 +26,7 @@ def test_bench_dist_configs_with_live_rccl_at_world_1(gpu_lib):
     assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["world_size"] == 1 and out["collectives"].startswith("RCCL") and out["rccl_ranks_seen"] == 1
-    assert out["check"]["ok"] and out["dtype"] == "f16m6"
+    assert out["check"]["ok"] and out["dtype"] == "f16x3"      # the default mode: int16 operand rows go through the byte-wise weight broadcast
     c3, c4 = out["dist_configs"]
     assert c3["entry_point"].endswith("segment_distributed") and c3["windows"] == 21 and c3["windows_per_rank"] == [21]
     assert c4["entry_point"].endswith("segment_batch_distributed") and c4["windows"] == 24 and c4["windows_per_rank"] == [24]

@@ -1,7 +1,11 @@
-"""North-star parity over 200 recordings (tests/golden/tiny_sweep.json, rows recorded from the reference's own segment()
-on HF fp32): the exact mode f32 and the split-precision modes — f16m6 (the product default), f16x3, bf16x3 — must reproduce EVERY
-row (0 recordings beyond +-1 mel frame, clusters bit-exact); the plain 16-bit modes f16 / bf16 are outside the north-star tolerance
-and are characterised: they must stay inside the measured envelope committed in profiles/ (scored with tools/parity_sweep.py)."""
+"""North-star parity over THREE sweeps of rows recorded from the reference's own segment() on HF fp32 (tools/make_golden.py):
+sweep 1 — 200 recordings of the first fixture model, the set every precision format of r03-r05 was chosen on; sweep 2 — 1 000 held-out
+recordings of a second, independently trained model (formats frozen before it was recorded); sweep 3 — 1 000 further recordings
+recorded after sweep 2 had been looked at (the fresh test of the default that sweep 2 led to).  The exact mode f32 and the
+split-precision modes f16x3 (the product default since r06) and bf16x3 must reproduce EVERY row of all three (0 recordings beyond +-1
+mel frame, clusters bit-exact).  f16m6 (the default of r04-r05) reproduces sweep 1 and is OUTSIDE the tolerance on 2 / 3 of the 1 000
+recordings of sweeps 2 / 3: it is characterised, like the plain 16-bit modes f16 / bf16 — they must stay inside the measured envelope
+committed in profiles/r06_parity_sweeps.json (scored with tools/parity_sweep.py)."""
 import json
 import os
 
@@ -35,8 +39,10 @@ def test_f32_mode_reproduces_every_row(gpu_lib, sweep):
 
 @pytest.mark.parametrize("dtype", ["bf16x3", "f16x3", "f16m6"])
 def test_split_precision_modes_meet_the_north_star_tolerance(gpu_lib, sweep, dtype):
-    """The fast parity modes: GEMM operands as hi + lo 16-bit pairs, three MFMAs per product (f16x3 / bf16x3) or hi*hi on the
-    half matrix cores + both cross terms on the fp6 MX matrix cores (f16m6), fp32 everywhere else.  North star: clusters exact, boundaries within +-1 mel frame — on EVERY recording of the sweep."""
+    """Sweep 1.  The split-precision modes: GEMM operands as hi + lo 16-bit pairs, three MFMAs per product (f16x3 / bf16x3) or hi*hi on
+    the half matrix cores + both cross terms on the fp6 MX matrix cores (f16m6: its formats were chosen ON this sweep, which it
+    reproduces; the held-out sweeps below put it outside the tolerance), fp32 everywhere else.  North star: clusters exact, boundaries
+    within +-1 mel frame — on EVERY recording of the sweep."""
     from tools.parity_sweep import score
     from whisperseg_amd.model import WhisperSegmenter
     res = score(WhisperSegmenter(MODEL_DIR, device="cuda", device_ids=[0], dtype=dtype), sweep)
@@ -60,41 +66,65 @@ def test_16_bit_modes_stay_inside_their_measured_envelope(gpu_lib, sweep, dtype)
     assert res["cluster_mismatch_rows"] == 0
 
 
-# ---- the HELD-OUT sweep (r06) -------------------------------------------------------------------------------------
-# 1 000 recordings (250 new seeds x trials {1, 3} x beams {1, 4}) of a second, independently trained fixture model of another shape with
-# full-mantissa fp32 weights (tests/golden/tiny_model2, tools/tiny_model.py variant "tiny2"), rows recorded from the reference by
-# tools/make_golden.py --only sweep2.  No precision format was chosen on it: they were frozen before it was recorded.
+# ---- the HELD-OUT sweeps (r06) ------------------------------------------------------------------------------------
+# sweep 2: 1 000 recordings (250 new seeds x trials {1, 3} x beams {1, 4}) of a second, independently trained fixture model of another
+# shape with full-mantissa fp32 weights (tests/golden/tiny_model2, tools/tiny_model.py variant "tiny2"), rows recorded from the reference
+# by tools/make_golden.py --only sweep2.  No precision format was chosen on it: they were frozen before it was recorded.  It put f16m6,
+# the default of r04-r05, outside the tolerance on 2 of its recordings; the pre-registered fallback (f16m6 with 24-bit cross K / V rows,
+# then f16x3) was evaluated on it, and sweep 3 (--only sweep3: 1 000 further recordings, seeds 7000..7249) is the fresh test of the
+# outcome: f16m6 with 24-bit rows failed it too (2 recordings; profiles/r06_fallback_f16m6_k24.json), f16x3 / bf16x3 reproduce every row.
 MODEL2_DIR = os.path.join(GOLDEN, "tiny_model2")
+HELDOUT = {"sweep2": "tiny2_sweep.json", "sweep3": "tiny2_sweep3.json"}
 
 
-@pytest.fixture(scope="module")
-def sweep2():
-    with open(os.path.join(GOLDEN, "tiny2_sweep.json")) as f:
-        return json.load(f)
+@pytest.fixture(scope="module", params=sorted(HELDOUT))
+def heldout(request):
+    with open(os.path.join(GOLDEN, HELDOUT[request.param])) as f:
+        return request.param, json.load(f)
 
 
-def test_heldout_sweep_is_big_enough(sweep2):
-    assert len(sweep2) == 1000
-    assert sum(len(r["expected"]["onset"]) for r in sweep2) >= 4000
-    assert len([r for r in sweep2 if r["kwargs"]["num_trials"] == 3 and r["expected"]["onset"]]) >= 250
+def test_heldout_sweeps_are_big_enough(heldout):
+    name, sweep = heldout
+    assert len(sweep) == 1000
+    assert sum(len(r["expected"]["onset"]) for r in sweep) >= 5000
+    assert len([r for r in sweep if r["kwargs"]["num_trials"] == 3 and r["expected"]["onset"]]) >= 400
 
 
-def test_heldout_f32_mode_reproduces_every_row(gpu_lib, sweep2):
+@pytest.mark.parametrize("dtype", ["f32", "f16x3", "bf16x3"])
+def test_heldout_exact_and_split_precision_modes_reproduce_every_row(gpu_lib, heldout, dtype):
+    if dtype == "f32" and heldout[0] == "sweep3":
+        pytest.skip("f32 is exact by construction: sweep 2 (and profiles/r06_parity_sweeps.json for sweep 3) carry it; ~50 s per 1 000 recordings")
+    """f32: exact by construction.  f16x3 (the default) / bf16x3: every row of both held-out sweeps identical to the reference's —
+    asserted as the north-star tolerance (clusters exact, boundaries within +-1 frame on EVERY recording) AND as bit-identical rows."""
     from tools.parity_sweep import score
     from whisperseg_amd.model import WhisperSegmenter
-    res = score(WhisperSegmenter(MODEL2_DIR, device="cuda", device_ids=[0], dtype="f32"), sweep2, "tiny2")
-    assert res["exact_runs"] == len(sweep2), (res["structure_mismatch_runs"][:3], res["beyond_one_frame_runs"][:3])
-
-
-@pytest.mark.parametrize("dtype", ["f16m6", "f16x3", "bf16x3"])
-def test_heldout_split_precision_modes_meet_the_north_star_tolerance(gpu_lib, sweep2, dtype):
-    from tools.parity_sweep import score
-    from whisperseg_amd.model import WhisperSegmenter
-    res = score(WhisperSegmenter(MODEL2_DIR, device="cuda", device_ids=[0], dtype=dtype), sweep2, "tiny2")
-    print(dtype, json.dumps({k: v for k, v in res.items() if not k.endswith("_runs") or isinstance(v, int)}))
+    name, sweep = heldout
+    res = score(WhisperSegmenter(MODEL2_DIR, device="cuda", device_ids=[0], dtype=dtype), sweep, "tiny2")
+    print(name, dtype, json.dumps({k: v for k, v in res.items() if not k.endswith("_runs") or isinstance(v, int)}))
     assert res["structure_mismatch_runs"] == [] and res["beyond_one_frame_runs"] == [], (res["structure_mismatch_runs"][:3], res["beyond_one_frame_runs"][:3])
-    assert res["cluster_mismatch_rows"] == 0
-    assert res["within_tolerance_runs"] == len(sweep2)
+    assert res["cluster_mismatch_rows"] == 0 and res["within_tolerance_runs"] == len(sweep)
+    assert res["exact_runs"] == len(sweep)
+
+
+def test_default_mode_is_a_mode_that_reproduces_the_heldout_sweeps():
+    from whisperseg_amd.model import DEFAULT_DTYPE
+    assert DEFAULT_DTYPE == "f16x3"
+
+
+@pytest.mark.parametrize("dtype", ["f16m6", "f16", "bf16"])
+def test_heldout_faster_modes_stay_inside_their_measured_envelope(gpu_lib, heldout, dtype):
+    """CHARACTERISATION of the modes that are faster and outside the tolerance: recordings (of 1 000) with a row-count / cluster
+    difference or a boundary more than one mel frame off must not exceed the committed measurement (f16m6 2 / 3, f16 14 / 15, bf16
+    95 / 91 on sweeps 2 / 3) plus box-to-box slack; a cluster label may differ only inside such a recording."""
+    from tools.parity_sweep import score
+    from whisperseg_amd.model import WhisperSegmenter
+    name, sweep = heldout
+    if dtype != "f16m6" and name == "sweep3":
+        pytest.skip("the plain 16-bit modes are characterised on sweep 2 (profiles/r06_parity_sweeps.json has all three sweeps)")
+    res = score(WhisperSegmenter(MODEL2_DIR, device="cuda", device_ids=[0], dtype=dtype), sweep, "tiny2")
+    print(name, dtype, json.dumps({k: v for k, v in res.items() if not k.endswith("_runs") or isinstance(v, int)}))
+    bad = res["structure_mismatch_runs"] + res["beyond_one_frame_runs"]
+    assert len(bad) <= {"f16m6": 8, "f16": 30, "bf16": 130}[dtype], bad[:5]
 
 
 # runs (of 200) allowed outside "clusters exact, boundaries within +-1 frame"; set from the measured sweeps

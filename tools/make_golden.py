@@ -1,7 +1,7 @@
 """Generate tests/golden/* by running the REFERENCE itself (imported read-only from /root/reference,
 tools/ref_import.py) and its HuggingFace backend in the build container.
 
-    python tools/make_golden.py [--only frontend|windows|parse|tiny|sweep2]
+    python tools/make_golden.py [--only frontend|windows|parse|tiny|sweep2|sweep3]
 
 Only inputs (seeds, parameters, hand-written generated texts) and expected outputs are stored — never
 reference source.  The tests regenerate the inputs from tests/golden_inputs.py.
@@ -307,7 +307,7 @@ def make_tiny(ref_audio, ref_model):
         json.dump(meta, f)
 
 
-def make_sweep2(ref_audio, ref_model):
+def make_sweep2(ref_audio, ref_model, first_seed=5000, out_name="tiny2_sweep.json", with_logits=True):
     """G9, the HELD-OUT parity sweep (r06): the reference's segment() rows for 1 000 recordings — 250 NEW seeds x
     trials {1, 3} x beams {1, 4} — of a SECOND, independently trained fixture model (tests/golden/tiny_model2: tools/tiny_model.py variant
     "tiny2" — d 256, 4 heads, 3 + 3 layers, another init seed, another data stream and signal family, full-mantissa fp32 weights).
@@ -319,14 +319,14 @@ def make_sweep2(ref_audio, ref_model):
     # SWEEP2_PART="lo:hi" records seeds [lo, hi) into tiny2_sweep.part_<lo>.json (parallel workers, each OMP_NUM_THREADS=2: one serial pass
     # takes ~2 h on the build container); SWEEP2_MERGE=1 concatenates the parts in seed order into tiny2_sweep.json and records the logits
     part = os.environ.get("SWEEP2_PART")
-    lo, hi = (int(v) for v in part.split(":")) if part else (5000, 5250)
+    lo, hi = (int(v) for v in part.split(":")) if part else (first_seed, first_seed + 250)
     if os.environ.get("SWEEP2_MERGE"):
         import glob
-        parts = sorted(glob.glob(os.path.join(OUT, "tiny2_sweep.part_*.json")))
+        parts = sorted(glob.glob(os.path.join(OUT, out_name[:-5] + ".part_*.json")))
         for pth in parts:
             with open(pth) as f:
                 sweep += json.load(f)
-        assert [r["seed"] for r in sweep[::4]] == list(range(5000, 5250)), "parts do not cover seeds 5000..5249 once"
+        assert [r["seed"] for r in sweep[::4]] == list(range(first_seed, first_seed + 250)), "parts do not cover the 250 seeds once"
         for pth in parts:
             os.remove(pth)
         lo = hi = 0
@@ -339,11 +339,13 @@ def make_sweep2(ref_audio, ref_model):
                 sweep.append(dict(seed=seed, n_windows=nw, kwargs=kw, expected=segm.segment(audio, TM.SR, **kw)))
         print("sweep2 seed", seed, [len(r["expected"]["onset"]) for r in sweep[-4:]], flush=True)
     if part:
-        with open(os.path.join(OUT, "tiny2_sweep.part_%d.json" % lo), "w") as f:
+        with open(os.path.join(OUT, out_name[:-5] + ".part_%d.json" % lo), "w") as f:
             json.dump(sweep, f)
         return
-    with open(os.path.join(OUT, "tiny2_sweep.json"), "w") as f:
+    with open(os.path.join(OUT, out_name), "w") as f:
         json.dump(sweep, f)
+    if not with_logits:
+        return
     # first-step logits of 4 windows (pins the oracle / the engines on this model's geometry as G6 does for the first model)
     audio = GI.tiny_recording(5000, 3, variant="tiny2")
     sliced = segm.get_sliced_audios_features(audio, TM.SR, 0, TM.STS, 1)
@@ -352,6 +354,13 @@ def make_sweep2(ref_audio, ref_model):
         enc = hf.model.encoder(feats).last_hidden_state
         logits = hf(input_features=feats, decoder_input_ids=torch.tensor([TM.PROMPT] * feats.shape[0])).logits[:, -1]
     np.savez_compressed(os.path.join(OUT, "tiny2_generate.npz"), enc_out_sample=enc.numpy()[:, ::25, :], first_logits=logits.numpy())
+
+
+def make_sweep3(ref_audio, ref_model):
+    """G10 (r06): a THIRD sweep — 1 000 further recordings (seeds 7000..7249 x trials {1, 3} x beams {1, 4}) of the second fixture model,
+    recorded AFTER the held-out sweep had shown the default mode `f16m6` outside the tolerance on 2 of its 1 000 recordings and the
+    pre-registered fallback (24-bit cross K / V rows, then f16x3) had been evaluated on it: the fresh test of whatever that fallback chose."""
+    make_sweep2(ref_audio, ref_model, first_seed=7000, out_name="tiny2_sweep3.json", with_logits=False)
 
 
 def make_wav():
@@ -375,7 +384,7 @@ def main():
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     ref_audio, ref_model = import_reference()
-    steps = dict(frontend=make_frontend, windows=make_windows, parse=make_parse, tiny=make_tiny, sweep2=make_sweep2)
+    steps = dict(frontend=make_frontend, windows=make_windows, parse=make_parse, tiny=make_tiny, sweep2=make_sweep2, sweep3=make_sweep3)
     for name, fn in steps.items():
         if args.only in (None, name):
             print("==", name)

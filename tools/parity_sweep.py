@@ -24,7 +24,9 @@ from tools import tiny_model as TM  # noqa: E402
 
 MODEL_DIR = os.path.join(ROOT, "tests", "golden", "tiny_model")
 # name -> (rows recorded from the reference, fixture model directory, signal family of its recordings)
-SWEEPS = {"sweep1": ("tiny_sweep.json", "tiny_model", "tiny"), "sweep2_heldout": ("tiny2_sweep.json", "tiny_model2", "tiny2")}
+SWEEPS = {"sweep1": ("tiny_sweep.json", "tiny_model", "tiny"), "sweep2_heldout": ("tiny2_sweep.json", "tiny_model2", "tiny2"),
+          # 1 000 further recordings of the second model, recorded after sweep 2 had been looked at (tools/make_golden.py --only sweep3)
+          "sweep3_fresh": ("tiny2_sweep3.json", "tiny_model2", "tiny2")}
 
 
 def score(seg, sweep, variant="tiny"):
@@ -84,7 +86,10 @@ def summary(r):
 def both_sweeps(dest, modes):
     from whisperseg_amd.model import WhisperSegmenter
     res = {}
+    only = os.environ.get("SWEEP_ONLY")      # e.g. SWEEP_ONLY=sweep3_fresh
     for name, (rows, mdir, variant) in SWEEPS.items():
+        if (only and name != only) or not os.path.exists(os.path.join(ROOT, "tests", "golden", rows)):
+            continue
         with open(os.path.join(ROOT, "tests", "golden", rows)) as f:
             sweep = json.load(f)
         for dtype in modes:
