@@ -29,37 +29,72 @@ SWEEPS = {"sweep1": ("tiny_sweep.json", "tiny_model", "tiny"), "sweep2_heldout":
           "sweep3_fresh": ("tiny2_sweep3.json", "tiny_model2", "tiny2")}
 
 
+def _new_tally(n):
+    return dict(runs=n, rows_expected=0, rows_compared=0, exact_runs=0, within_tolerance_runs=0, structure_mismatch_runs=[],
+                beyond_one_frame_runs=[], cluster_mismatch_rows=0, frame_hist={"0": 0, "<=0.5": 0, "<=1": 0, "<=2": 0, ">2": 0}, max_dev_frames=0.0)
+
+
+def _tally(out, idx, run, got):
+    """Score one recording's rows `got` against the reference's (run["expected"]) into the tally `out`."""
+    hist = out["frame_hist"]
+    want = run["expected"]
+    out["rows_expected"] += len(want["onset"])
+    if got == want:
+        out["exact_runs"] += 1
+    if len(got["onset"]) != len(want["onset"]) or got["cluster"] != want["cluster"]:
+        out["structure_mismatch_runs"].append(dict(index=idx, seed=run["seed"], kwargs=run["kwargs"], got_rows=len(got["onset"]),
+                                                   want_rows=len(want["onset"])))
+        if len(got["onset"]) == len(want["onset"]):
+            out["cluster_mismatch_rows"] += sum(a != b for a, b in zip(got["cluster"], want["cluster"]))
+        return
+    dev = np.abs(np.array(got["onset"] + got["offset"]) - np.array(want["onset"] + want["offset"])) / TM.STS
+    out["rows_compared"] += len(want["onset"])
+    for d in dev:
+        k = "0" if d < 1e-6 else ("<=0.5" if d <= 0.5 + 1e-6 else ("<=1" if d <= 1 + 1e-6 else ("<=2" if d <= 2 + 1e-6 else ">2")))
+        hist[k] += 1
+    mx = float(dev.max()) if len(dev) else 0.0
+    out["max_dev_frames"] = max(out["max_dev_frames"], mx)
+    if mx <= 1 + 1e-6:
+        out["within_tolerance_runs"] += 1
+    else:
+        out["beyond_one_frame_runs"].append(dict(index=idx, seed=run["seed"], kwargs=run["kwargs"], max_dev_frames=mx))
+
+
 def score(seg, sweep, variant="tiny"):
-    hist = {"0": 0, "<=0.5": 0, "<=1": 0, "<=2": 0, ">2": 0}
-    out = dict(runs=len(sweep), rows_expected=0, rows_compared=0, exact_runs=0, within_tolerance_runs=0,
-               structure_mismatch_runs=[], beyond_one_frame_runs=[], cluster_mismatch_rows=0, frame_hist=hist, max_dev_frames=0.0)
+    """Every recording through its own segment() call (what the reference's rows were recorded with)."""
+    out = _new_tally(len(sweep))
     audio_cache = {}
     for idx, run in enumerate(sweep):
         key = (run["seed"], run["n_windows"])
         if key not in audio_cache:
             audio_cache[key] = GI.tiny_recording(*key, variant=variant)
-        got = seg.segment(audio_cache[key], TM.SR, **run["kwargs"])
-        want = run["expected"]
-        out["rows_expected"] += len(want["onset"])
-        if got == want:
-            out["exact_runs"] += 1
-        if len(got["onset"]) != len(want["onset"]) or got["cluster"] != want["cluster"]:
-            out["structure_mismatch_runs"].append(dict(index=idx, seed=run["seed"], kwargs=run["kwargs"], got_rows=len(got["onset"]),
-                                                       want_rows=len(want["onset"])))
-            if len(got["onset"]) == len(want["onset"]):
-                out["cluster_mismatch_rows"] += sum(a != b for a, b in zip(got["cluster"], want["cluster"]))
-            continue
-        dev = np.abs(np.array(got["onset"] + got["offset"]) - np.array(want["onset"] + want["offset"])) / TM.STS
-        out["rows_compared"] += len(want["onset"])
-        for d in dev:
-            k = "0" if d < 1e-6 else ("<=0.5" if d <= 0.5 + 1e-6 else ("<=1" if d <= 1 + 1e-6 else ("<=2" if d <= 2 + 1e-6 else ">2")))
-            hist[k] += 1
-        mx = float(dev.max()) if len(dev) else 0.0
-        out["max_dev_frames"] = max(out["max_dev_frames"], mx)
-        if mx <= 1 + 1e-6:
-            out["within_tolerance_runs"] += 1
-        else:
-            out["beyond_one_frame_runs"].append(dict(index=idx, seed=run["seed"], kwargs=run["kwargs"], max_dev_frames=mx))
+        _tally(out, idx, run, seg.segment(audio_cache[key], TM.SR, **run["kwargs"]))
+    return out
+
+
+def score_pooled(seg, sweep, variant="tiny"):
+    """The same recordings through the product's POOLED path: one segment_batch() call per beam count (the decode parameter that is per
+    call), with each recording's own num_trials — all windows of ~500 recordings share the engine's slots, are admitted in whatever groups
+    the scheduler forms and finish at their own lengths.  Scored exactly like score(): every row must still be the reference's."""
+    out = _new_tally(len(sweep))
+    audio_cache = {}
+    by_beams = {}
+    for idx, run in enumerate(sweep):
+        by_beams.setdefault(run["kwargs"]["num_beams"], []).append(idx)
+    for beams, idxs in sorted(by_beams.items()):
+        audios, trials = [], []
+        for idx in idxs:
+            run = sweep[idx]
+            key = (run["seed"], run["n_windows"])
+            if key not in audio_cache:
+                audio_cache[key] = GI.tiny_recording(*key, variant=variant)
+            audios.append(audio_cache[key])
+            trials.append(run["kwargs"]["num_trials"])
+            extra = {k: v for k, v in run["kwargs"].items() if k not in ("num_beams", "num_trials", "batch_size")}
+            assert not extra, extra      # the sweeps vary trials and beams only
+        preds = seg.segment_batch(audios, TM.SR, num_trials=trials, num_beams=beams, batch_size=8)
+        for idx, got in zip(idxs, preds):
+            _tally(out, idx, sweep[idx], got)
     return out
 
 
