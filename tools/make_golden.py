@@ -386,6 +386,11 @@ def main():
     ref_audio, ref_model = import_reference()
     steps = dict(frontend=make_frontend, windows=make_windows, parse=make_parse, tiny=make_tiny, sweep2=make_sweep2, sweep3=make_sweep3)
     for name, fn in steps.items():
+        if args.only is None and name in ("sweep2", "sweep3"):
+            # 1 000 recordings each through HF on ONE thread (so that the rows cannot depend on how the CPU GEMMs were partitioned):
+            # ~2 h serially — recorded in parallel parts by tools/record_sweep.sh (5 workers, ~25 min), never by the default run
+            print("== %s: skipped by the default run; use  tools/record_sweep.sh %s" % (name, name))
+            continue
         if args.only in (None, name):
             print("==", name)
             fn(ref_audio, ref_model)
