@@ -1,7 +1,7 @@
 """Generate tests/golden/* by running the REFERENCE itself (imported read-only from /root/reference,
 tools/ref_import.py) and its HuggingFace backend in the build container.
 
-    python tools/make_golden.py [--only frontend|windows|parse|tiny|sweep2|sweep3]
+    python tools/make_golden.py [--only frontend|windows|parse|tiny|sweep2|sweep3|sweep4]
 
 Only inputs (seeds, parameters, hand-written generated texts) and expected outputs are stored — never
 reference source.  The tests regenerate the inputs from tests/golden_inputs.py.
@@ -363,6 +363,12 @@ def make_sweep3(ref_audio, ref_model):
     make_sweep2(ref_audio, ref_model, first_seed=7000, out_name="tiny2_sweep3.json", with_logits=False)
 
 
+def make_sweep4(ref_audio, ref_model):
+    """G11 (r06): 1 000 more recordings of the second fixture model (seeds 9000..9249), recorded after the default had moved to f16x3 —
+    more of the same evidence (the GPU side decodes a whole sweep in seconds through the pooled path; recording the reference is the cost)."""
+    make_sweep2(ref_audio, ref_model, first_seed=9000, out_name="tiny2_sweep4.json", with_logits=False)
+
+
 def make_wav():
     import struct
     src = "/root/reference/data/example_subset/Meerkat/test/VALP007_AL_6_15DEC2022_MF_ML.wav"
@@ -384,9 +390,9 @@ def main():
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     ref_audio, ref_model = import_reference()
-    steps = dict(frontend=make_frontend, windows=make_windows, parse=make_parse, tiny=make_tiny, sweep2=make_sweep2, sweep3=make_sweep3)
+    steps = dict(frontend=make_frontend, windows=make_windows, parse=make_parse, tiny=make_tiny, sweep2=make_sweep2, sweep3=make_sweep3, sweep4=make_sweep4)
     for name, fn in steps.items():
-        if args.only is None and name in ("sweep2", "sweep3"):
+        if args.only is None and name in ("sweep2", "sweep3", "sweep4"):
             # 1 000 recordings each through HF on ONE thread (so that the rows cannot depend on how the CPU GEMMs were partitioned):
             # ~2 h serially — recorded in parallel parts by tools/record_sweep.sh (5 workers, ~25 min), never by the default run
             print("== %s: skipped by the default run; use  tools/record_sweep.sh %s" % (name, name))
