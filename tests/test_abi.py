@@ -102,6 +102,6 @@ def test_workspace_sizing_is_host_arithmetic_and_fits_the_default_api_call():
             lib.wseg_model_destroy(h)
     weights_x3 = 6.2e9
     assert out["f16x3"][0] + weights_x3 <= 0.8 * 288e9, out          # the API default call keeps 1 024 slots in the split modes
-    assert out["f16m6"][0] + weights_x3 + 0.3e9 <= 0.8 * 288e9, out  # ... incl. the default mode (M6 operand scratch, fp32 embedding copy)
+    assert out["f16m6"][0] + weights_x3 + 0.3e9 <= 0.8 * 288e9, out  # ... and in f16m6 (M6 operand scratch, fp32 embedding copy)
     assert out["f16x3"][1] > 288e9                                    # ... which a fully provisioned cache could never do
     assert out["bf16"][0] < 0.5 * 288e9

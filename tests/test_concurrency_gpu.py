@@ -26,7 +26,7 @@ SHAPES = [  # name, M, N, K, epilogue (0 store, 1 GELU, 2 fp32 residual)
 @pytest.mark.parametrize("dtype_id,td", [(1, torch.bfloat16), (2, torch.float16), (5, None)], ids=["bf16", "f16", "f16m6"])
 @pytest.mark.parametrize("name,m,n,k,epi", SHAPES, ids=[s[0] for s in SHAPES])
 def test_gemm_is_bit_stable_under_a_hog_stream(gpu_lib, dtype_id, td, name, m, n, k, epi):
-    """dtype 5 = f16m6, the product default: its 256x256 kernel interleaves compiler-scheduled half MFMAs with inline-assembly MX
+    """dtype 5 = f16m6 (the default of r04-r05): its 256x256 kernel interleaves compiler-scheduled half MFMAs with inline-assembly MX
     MFMAs (wseg_gemm.hip, mfma_mx6_asm) on M6 operand rows."""
     from whisperseg_amd import _lib
     lib = gpu_lib

@@ -287,7 +287,7 @@ RESID_LN_SHAPES = [  # M, N, K: skinny split-K + fused reduction (<= 1024 rows),
 @pytest.mark.parametrize("dtype", ["bf16", "f16", "f16x3", "f16m6", "f32"])
 def test_gemm_resid_layernorm_step(gpu_lib, M, N, K, dtype):
     """The decoder's fused step x += A W^T + b; y = LayerNorm(x) through every kernel family the row count selects (f16m6, the
-    product default: operands and the LayerNorm output are M6 rows)."""
+    default of r04-r05: operands and the LayerNorm output are M6 rows)."""
     from whisperseg_amd import _lib
     from whisperseg_amd.engine import DTYPES, SPLIT_BASE, split_operand, unsplit_m6, unsplit_operand
     if dtype == "f32" and M * N * K > 3e9:

@@ -139,7 +139,7 @@ def test_two_layer_256_windows_1024_rows_vs_oracle(gpu_lib, two_layer):
     # first generated token: bf16 may flip near-ties of these random-weight logits, but not often
     agree = float((t16.cpu()[:, 3] == t32.cpu()[:, 3]).float().mean())
     assert agree >= 0.9, agree
-    # split-precision modes (the product default and the bench headline) at the same row counts: logits of ALL 1024 rows within
+    # split-precision modes (f16x3 = the product default and the bench headline) at the same row counts: logits of ALL 1024 rows within
     # 1e-3 of the logit scale of the f32 mode (measured ~1e-5 / ~1e-4) and of the oracle on its subset, every first token equal
     scale = max(1.0, want_logits.abs().max().item())
     for dt, rel in (("f16x3", 1e-4), ("bf16x3", 1e-3), ("f16m6", 1e-3)):
@@ -271,7 +271,7 @@ def full_large_f32():
 
 @pytest.mark.parametrize("dt,rel", [("f16x3", 1e-4), ("bf16x3", 5e-4), ("f16m6", 5e-4)])
 def test_full_large_split_precision_vs_f32_mode(gpu_lib, full_large_f32, dt, rel):
-    """32 + 32 layers, 16 windows: the split-precision modes (product default f16m6; f16x3, bf16x3) against the exact-parity f32 mode on the
+    """32 + 32 layers, 16 windows: the split-precision modes (product default f16x3; bf16x3; f16m6) against the exact-parity f32 mode on the
     same fp32 weights.  Encoder output and first-step logits within rel x scale (measured 2.8e-5 / 1.1e-4 / 3.0e-4 of the logit scale).
     WHOLE beam-search results (12 positions, 4 beams): identical to the f32 mode's, or — these are random weights, their distributions are
     flat and hypotheses whose total scores tie to ~1e-4 exist — a hypothesis the CPU ORACLE scores the same as the f32 mode's choice to

@@ -103,7 +103,7 @@ def test_generate_tokens_f32_random_weights(gpu_lib, nb, ml, dtype):
 @pytest.mark.parametrize("nb", [5, 8])
 def test_five_to_eight_beams(gpu_lib, nb, dtype):
     """num_beams 5..8 (MAX_BEAMS = 8): the 24-bit cross-K/V kernel exists for up to 4 beams, above that cross-attention runs the
-    general fp32-K/V kernel — in the product default f16m6 its hi | lo output rows are converted to M6 rows for the co-proj GEMM
+    general fp32-K/V kernel — in f16m6 (the default of r04-r05) its hi | lo output rows are converted to M6 rows for the co-proj GEMM
     (the default mode used to reject these calls after the encoder had already run).  Token-exact vs the oracle."""
     cfg = hf_cfg()
     rc, sd, eng = make(cfg, dtype)
@@ -165,13 +165,15 @@ def test_base_geometry_bf16(gpu_lib):
     assert lens.tolist() == [5, 5]
 
 
-def test_base_geometry_32_windows_default_mode(gpu_lib):
-    """BASELINE configs[1] as the product runs it: whisperseg-base geometry x 32 windows x 4 beams in the default mode f16m6.
+@pytest.mark.parametrize("mode", ["f16x3", "f16m6"])
+def test_base_geometry_32_windows_default_mode(gpu_lib, mode):
+    """BASELINE configs[1] as the product runs it: whisperseg-base geometry x 32 windows x 4 beams in the default mode f16x3 (and in f16m6,
+    the default of r04-r05).
     The oracle (torch-CPU fp32) is run on a subset of the windows (windows are independent): encoder output and first-step
     logits within the split modes' bound, beam sequences token-exact; the other windows through the size-independent
     properties (beams equal at step 1, the same window gives the same tokens wherever it sits in the batch)."""
     cfg = hf_cfg(d=512, heads=8, layers=6, ffn=2048, vocab=51865)
-    rc, sd, eng = make(cfg, "f16m6", seed=11)
+    rc, sd, eng = make(cfg, mode, seed=11)
     x = feats(32, seed=17)
     sub = [0, 13, 31]
     prompt, eos = [50258, 50259, 50363], 50257

@@ -63,8 +63,8 @@ def test_slot_refill_gives_the_same_tokens(gpu_lib, dtype, nb):
         assert st["n_windows"] == 23 and st["n_slots"] == slots and st["n_admissions"] >= -(-23 // slots)
         assert 0 < st["occupancy"] <= 1.0
         if dtype in ("f32", "f16x3", "bf16x3", "f16m6"):
-            # f32: every dot product is one k-ordered chain whatever the plan -> bit-identical.  Split-precision modes (the
-            # product default): split-K plans follow the row count, which moves logits by fp32 summation-order noise (~1e-7 of
+            # f32: every dot product is one k-ordered chain whatever the plan -> bit-identical.  Split-precision modes (f16x3 is
+            # the product default): split-K plans follow the row count, which moves logits by fp32 summation-order noise (~1e-7 of
             # their scale) — four orders of magnitude below the smallest top-1 / top-2 margin of the parity sweep (1e-5,
             # profiles/history/r03_precision_study.json "margins") — so the TOKENS must not depend on the slot count 1 / 5 / 8 / 23
             assert torch.equal(l, ref_l) and torch.equal(t, ref_t), (dtype, slots, refill)
@@ -306,7 +306,7 @@ def test_paged_kv_default_pool_equals_full_pool(gpu_lib, dtype):
 def test_paged_kv_short_pool_preempts_and_still_gives_the_same_tokens(gpu_lib, nb, dtype):
     """A pool far too small for the windows in flight: the scheduler preempts the youngest slot (device-side abort, window
     re-queued, decoded again from scratch later) instead of failing, the oldest window always progresses, and every window
-    still gets exactly the tokens of the uncontended run (f32 mode: bit-exact whatever the slot history; the product default
+    still gets exactly the tokens of the uncontended run (f32 mode: bit-exact whatever the slot history; the fast mode
     f16m6: abort + re-admission run through the M6-row operand writers, tokens asserted equal as in the refill test)."""
     eng = tiny_engine(dtype)
     x = tiny_feats(23)
