@@ -301,7 +301,7 @@ def test_paged_kv_default_pool_equals_full_pool(gpu_lib, dtype):
     assert _units(eng, 23, 4, 448, 0) == _units(eng, 23, 4, 448, 64) >= _units(eng, 23, 4, 64, 0)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f16m6"])
+@pytest.mark.parametrize("dtype", ["f32", "f16x3", "f16m6"])
 @pytest.mark.parametrize("nb", [1, 4])
 def test_paged_kv_short_pool_preempts_and_still_gives_the_same_tokens(gpu_lib, nb, dtype):
     """A pool far too small for the windows in flight: the scheduler preempts the youngest slot (device-side abort, window
@@ -389,11 +389,12 @@ def test_prompt_pass_equals_stepping_through_the_prompt(gpu_lib, dtype, nb, monk
             assert eng.last_stats()["n_steps"] == res["step", 23][2] - (len(TM.PROMPT) - 1)
 
 
+@pytest.mark.parametrize("mode", ["f16x3", "f16m6"])
 @pytest.mark.parametrize("plen", [1, 2, 6, 8])
-def test_prompt_pass_with_other_prompt_lengths(gpu_lib, plen, monkeypatch):
+def test_prompt_pass_with_other_prompt_lengths(gpu_lib, plen, mode, monkeypatch):
     """The C-ABI takes prompts of 1..8 tokens: P <= 4: the pass covers the whole prompt and the first generated step; longer prompts: the
     first 4 positions, the rest is stepped through; same tokens as stepping through all of it."""
-    eng = tiny_engine("f16m6")
+    eng = tiny_engine(mode)
     x = tiny_feats(7)
     prompt = (TM.PROMPT + [TM.PROMPT[1], TM.PROMPT[2]] * 3)[:plen]
 
@@ -410,12 +411,13 @@ def test_prompt_pass_with_other_prompt_lengths(gpu_lib, plen, monkeypatch):
     assert (t1[:, :plen] == torch.tensor(prompt)).all()
 
 
+@pytest.mark.parametrize("mode", ["f16x3", "f16m6"])
 @pytest.mark.parametrize("nb", [1, 4])
-def test_first_step_in_the_pass_with_windows_that_end_there(gpu_lib, nb, monkeypatch):
+def test_first_step_in_the_pass_with_windows_that_end_there(gpu_lib, nb, mode, monkeypatch):
     """Per-window caps of P + 1 .. P + 3: some windows are finished by the first generated step, which the admission's pass runs itself
     (one row per window) — they must retire with exactly that one token, refills included; same tokens as stepping through everything,
     also when the call's max_length leaves no step after the first (the merge is then off by construction)."""
-    eng = tiny_engine("f16m6")
+    eng = tiny_engine(mode)
     x = tiny_feats(17)
     P = len(TM.PROMPT)
     caps = [P + 1 + (i % 3) for i in range(17)]
