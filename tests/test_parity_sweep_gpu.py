@@ -1,10 +1,10 @@
-"""North-star parity over THREE sweeps of rows recorded from the reference's own segment() on HF fp32 (tools/make_golden.py):
+"""North-star parity over FOUR sweeps of rows recorded from the reference's own segment() on HF fp32 (tools/make_golden.py):
 sweep 1 — 200 recordings of the first fixture model, the set every precision format of r03-r05 was chosen on; sweep 2 — 1 000 held-out
 recordings of a second, independently trained model (formats frozen before it was recorded); sweep 3 — 1 000 further recordings
-recorded after sweep 2 had been looked at (the fresh test of the default that sweep 2 led to).  The exact mode f32 and the
-split-precision modes f16x3 (the product default since r06) and bf16x3 must reproduce EVERY row of all three (0 recordings beyond +-1
-mel frame, clusters bit-exact).  f16m6 (the default of r04-r05) reproduces sweep 1 and is OUTSIDE the tolerance on 2 / 3 of the 1 000
-recordings of sweeps 2 / 3: it is characterised, like the plain 16-bit modes f16 / bf16 — they must stay inside the measured envelope
+recorded after sweep 2 had been looked at (the fresh test of the default that sweep 2 led to); sweep 4 — 1 000 more.  The exact mode f32 and the
+split-precision modes f16x3 (the product default since r06) and bf16x3 must reproduce EVERY row of all four (0 recordings beyond +-1
+mel frame, clusters bit-exact).  f16m6 (the default of r04-r05) reproduces sweep 1 and is OUTSIDE the tolerance on 2 / 3 / 1 of the 1 000
+recordings of sweeps 2 / 3 / 4: it is characterised, like the plain 16-bit modes f16 / bf16 — they must stay inside the measured envelope
 committed in profiles/r06_parity_sweeps.json (scored with tools/parity_sweep.py)."""
 import json
 import os
@@ -74,7 +74,7 @@ def test_16_bit_modes_stay_inside_their_measured_envelope(gpu_lib, sweep, dtype)
 # then f16x3) was evaluated on it, and sweep 3 (--only sweep3: 1 000 further recordings, seeds 7000..7249) is the fresh test of the
 # outcome: f16m6 with 24-bit rows failed it too (2 recordings; profiles/r06_fallback_f16m6_k24.json), f16x3 / bf16x3 reproduce every row.
 MODEL2_DIR = os.path.join(GOLDEN, "tiny_model2")
-HELDOUT = {"sweep2": "tiny2_sweep.json", "sweep3": "tiny2_sweep3.json"}
+HELDOUT = {"sweep2": "tiny2_sweep.json", "sweep3": "tiny2_sweep3.json", "sweep4": "tiny2_sweep4.json"}      # sweep 4: 1 000 more (seeds 9000..9249)
 
 
 @pytest.fixture(scope="module", params=sorted(HELDOUT))
@@ -94,9 +94,9 @@ def test_heldout_sweeps_are_big_enough(heldout):
 def test_heldout_exact_and_split_precision_modes_reproduce_every_row(gpu_lib, heldout, dtype):
     """f32: exact by construction.  f16x3 (the default) / bf16x3: every row of both held-out sweeps identical to the reference's —
     asserted as the north-star tolerance (clusters exact, boundaries within +-1 frame on EVERY recording) AND as bit-identical rows.
-    Sweep 2: every recording through its own segment() call, as the rows were recorded (~50 s per mode).  Sweep 3: the POOLED path —
+    Sweep 2: every recording through its own segment() call, as the rows were recorded (~50 s per mode).  Sweeps 3 and 4: the POOLED path —
     two segment_batch() calls, ~1 900 windows sharing the engine's slots, admitted in whatever groups the scheduler forms — the rows
-    must be the reference's either way.  profiles/r06_parity_sweeps.json holds the per-file record of all three sweeps in every mode."""
+    must be the reference's either way.  profiles/r06_parity_sweeps.json holds the per-file record of all four sweeps in every mode."""
     from tools.parity_sweep import score, score_pooled
     from whisperseg_amd.model import WhisperSegmenter
     name, sweep = heldout
@@ -116,8 +116,8 @@ def test_default_mode_is_a_mode_that_reproduces_the_heldout_sweeps():
 @pytest.mark.parametrize("dtype", ["f16m6", "f16", "bf16"])
 def test_heldout_faster_modes_stay_inside_their_measured_envelope(gpu_lib, heldout, dtype):
     """CHARACTERISATION of the modes that are faster and outside the tolerance: recordings (of 1 000) with a row-count / cluster
-    difference or a boundary more than one mel frame off must not exceed the committed per-file measurement (f16m6 2 / 3, f16 14 / 15,
-    bf16 95 / 91 on sweeps 2 / 3, profiles/r06_parity_sweeps.json) plus slack for the pooled path used here (other neighbours, other
+    difference or a boundary more than one mel frame off must not exceed the committed per-file measurement (f16m6 2 / 3 / 1, f16 14 / 15 / 26,
+    bf16 95 / 91 / 91 on sweeps 2 / 3 / 4, profiles/r06_parity_sweeps.json) plus slack for the pooled path used here (other neighbours, other
     near-tie resolutions) and box-to-box differences."""
     from tools.parity_sweep import score_pooled
     from whisperseg_amd.model import WhisperSegmenter
@@ -125,7 +125,7 @@ def test_heldout_faster_modes_stay_inside_their_measured_envelope(gpu_lib, heldo
     res = score_pooled(WhisperSegmenter(MODEL2_DIR, device="cuda", device_ids=[0], dtype=dtype), sweep, "tiny2")
     print(name, dtype, json.dumps({k: v for k, v in res.items() if not k.endswith("_runs") or isinstance(v, int)}))
     bad = res["structure_mismatch_runs"] + res["beyond_one_frame_runs"]
-    assert len(bad) <= {"f16m6": 8, "f16": 30, "bf16": 130}[dtype], bad[:5]
+    assert len(bad) <= {"f16m6": 8, "f16": 45, "bf16": 130}[dtype], bad[:5]
 
 
 # runs (of 200) allowed outside "clusters exact, boundaries within +-1 frame"; set from the measured sweeps

@@ -26,7 +26,9 @@ MODEL_DIR = os.path.join(ROOT, "tests", "golden", "tiny_model")
 # name -> (rows recorded from the reference, fixture model directory, signal family of its recordings)
 SWEEPS = {"sweep1": ("tiny_sweep.json", "tiny_model", "tiny"), "sweep2_heldout": ("tiny2_sweep.json", "tiny_model2", "tiny2"),
           # 1 000 further recordings of the second model, recorded after sweep 2 had been looked at (tools/make_golden.py --only sweep3)
-          "sweep3_fresh": ("tiny2_sweep3.json", "tiny_model2", "tiny2")}
+          "sweep3_fresh": ("tiny2_sweep3.json", "tiny_model2", "tiny2"),
+          # 1 000 more, recorded after the default had moved to f16x3 (tools/record_sweep.sh sweep4)
+          "sweep4_more": ("tiny2_sweep4.json", "tiny_model2", "tiny2")}
 
 
 def _new_tally(n):
