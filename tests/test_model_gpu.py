@@ -288,3 +288,27 @@ def test_f32_encoder_attention_kernels_are_bit_identical(gpu_lib, tmp_path):
         outs.append(torch.load(out))
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("positions", [251, 384])
+@pytest.mark.parametrize("dtype,tol", [("f32", 5e-4), ("f16x3", 5e-4), ("f16m6", 5e-4), ("bf16", 6e-2)])
+def test_other_window_lengths(gpu_lib, dtype, tol, positions):
+    """Encoder positions other than 500 (r06: the V^T of the encoder attention is written in MFMA operand order by the q | k | v epilogue —
+    4 consecutive positions per 8-byte store when the window length is a multiple of 4, element by element otherwise — and read by LDS-DMA
+    in 64-key tiles): 251 positions (odd: the element-wise writer, a ragged last key tile, windows starting at odd GEMM rows) and 384 (a
+    whole number of key tiles), 3 windows, encoder output and greedy tokens against the oracle."""
+    cfg = dict(hf_cfg(), max_source_positions=positions)
+    rc, sd, eng = make(cfg, dtype, seed=23)
+    g = torch.Generator().manual_seed(positions)
+    x = torch.randn(3, 80, 2 * positions, generator=g) * 0.5
+    want = R.encoder_forward(sd, rc, x)
+    got = eng.encode(x.cuda()).float().cpu()
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+    if dtype != "bf16":
+        gp = R.GenParams(prompt=PROMPT, eos_token_id=EOS, pad_token_id=EOS, max_length=10, num_beams=1)
+        want_t = R.generate(sd, rc, x, gp)
+        toks, lens = eng.generate(x.cuda(), PROMPT, EOS, EOS, max_length=10, num_beams=1)
+        toks, lens = toks.cpu(), lens.cpu()
+        for i in range(3):
+            assert R.canonical(toks[i, :lens[i]].tolist(), 3, EOS, PROMPT) == R.canonical(want_t[i].tolist(), 3, EOS, PROMPT), (dtype, positions, i)
