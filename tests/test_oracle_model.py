@@ -115,3 +115,32 @@ def test_oracle_reproduces_heldout_rows(tiny2, golden_dir):
     for run in sweep[0:8] + sweep[500:504]:
         got = seg.segment(GI.tiny_recording(run["seed"], run["n_windows"], variant="tiny2"), TM.SR, **run["kwargs"])
         assert got == run["expected"], (run["seed"], run["kwargs"])
+
+
+# ---- the third fixture model (d 128, 2 heads, 4 + 4 layers, ffn 640, fp32 weights) ---------------------------------------------------
+def test_third_fixture_encoder_logits_and_rows(golden_dir):
+    """oracle vs HF on the third model's geometry (tools/make_golden.py --only sweep5): encoder output, first-step logits, and 8 of its
+    1 000 sweep recordings end to end through the oracle + the product's host epilogue"""
+    from safetensors.torch import load_file
+    from tools.precision_study import OracleSegmenter, Policy
+    mdir = os.path.join(golden_dir, "tiny_model3")
+    sd = {k: v.float() for k, v in load_file(os.path.join(mdir, "model.safetensors")).items()}
+    with open(os.path.join(mdir, "config.json")) as f:
+        rc = W.RefConfig.from_hf_dict(json.load(f))
+    assert (rc.d_model, rc.encoder_layers, rc.decoder_layers) == (128, 4, 4)
+    z = np.load(os.path.join(golden_dir, "tiny3_generate.npz"))
+    with open(os.path.join(golden_dir, "tiny3_sweep.json")) as f:
+        sweep = json.load(f)
+    assert len(sweep) == 1000 and {r["seed"] for r in sweep} == set(range(11000, 11250))
+    audio = GI.tiny_recording(11000, 3, variant="tiny3")
+    sliced = F.sliced_audio_features(audio, TM.SR, 0, TM.STS, 1)
+    feats = torch.from_numpy(np.stack([s[2] for s in sliced]))
+    enc = W.encoder_forward(sd, rc, feats)
+    assert np.max(np.abs(enc.numpy()[:, ::25, :] - z["enc_out_sample"])) <= 5e-4
+    gp = W.GenParams(prompt=TM.PROMPT, eos_token_id=TM.EOT, pad_token_id=TM.EOT, max_length=8, num_beams=1)
+    _, logits = W.generate(sd, rc, feats, gp, return_first_logits=True)
+    assert np.max(np.abs(logits.numpy() - z["first_logits"])) <= 3e-3
+    seg = OracleSegmenter(Policy(""), model_dir=mdir)
+    for run in sweep[0:4] + sweep[600:604]:
+        got = seg.segment(GI.tiny_recording(run["seed"], run["n_windows"], variant="tiny3"), TM.SR, **run["kwargs"])
+        assert got == run["expected"], (run["seed"], run["kwargs"])

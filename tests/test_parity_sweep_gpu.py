@@ -73,18 +73,21 @@ def test_16_bit_modes_stay_inside_their_measured_envelope(gpu_lib, sweep, dtype)
 # the default of r04-r05, outside the tolerance on 2 of its recordings; the pre-registered fallback (f16m6 with 24-bit cross K / V rows,
 # then f16x3) was evaluated on it, and sweep 3 (--only sweep3: 1 000 further recordings, seeds 7000..7249) is the fresh test of the
 # outcome: f16m6 with 24-bit rows failed it too (2 recordings; profiles/r06_fallback_f16m6_k24.json), f16x3 / bf16x3 reproduce every row.
-MODEL2_DIR = os.path.join(GOLDEN, "tiny_model2")
-HELDOUT = {"sweep2": "tiny2_sweep.json", "sweep3": "tiny2_sweep3.json", "sweep4": "tiny2_sweep4.json"}      # sweep 4: 1 000 more (seeds 9000..9249)
+# name -> (rows, fixture model, signal family).  sweep 4: 1 000 more of the second model (seeds 9000..9249); sweep 5: 1 000 recordings of
+# a THIRD model (d 128, 4 + 4 layers, fp32 weights: tests/golden/tiny_model3) — the same question on another architecture.
+HELDOUT = {"sweep2": ("tiny2_sweep.json", "tiny_model2", "tiny2"), "sweep3": ("tiny2_sweep3.json", "tiny_model2", "tiny2"),
+           "sweep4": ("tiny2_sweep4.json", "tiny_model2", "tiny2"), "sweep5": ("tiny3_sweep.json", "tiny_model3", "tiny3")}
 
 
 @pytest.fixture(scope="module", params=sorted(HELDOUT))
 def heldout(request):
-    with open(os.path.join(GOLDEN, HELDOUT[request.param])) as f:
-        return request.param, json.load(f)
+    rows, model, variant = HELDOUT[request.param]
+    with open(os.path.join(GOLDEN, rows)) as f:
+        return request.param, json.load(f), os.path.join(GOLDEN, model), variant
 
 
 def test_heldout_sweeps_are_big_enough(heldout):
-    name, sweep = heldout
+    name, sweep, _, _ = heldout
     assert len(sweep) == 1000
     assert sum(len(r["expected"]["onset"]) for r in sweep) >= 5000
     assert len([r for r in sweep if r["kwargs"]["num_trials"] == 3 and r["expected"]["onset"]]) >= 400
@@ -99,9 +102,9 @@ def test_heldout_exact_and_split_precision_modes_reproduce_every_row(gpu_lib, he
     must be the reference's either way.  profiles/r06_parity_sweeps.json holds the per-file record of all four sweeps in every mode."""
     from tools.parity_sweep import score, score_pooled
     from whisperseg_amd.model import WhisperSegmenter
-    name, sweep = heldout
-    seg = WhisperSegmenter(MODEL2_DIR, device="cuda", device_ids=[0], dtype=dtype)
-    res = score(seg, sweep, "tiny2") if name == "sweep2" else score_pooled(seg, sweep, "tiny2")
+    name, sweep, model_dir, variant = heldout
+    seg = WhisperSegmenter(model_dir, device="cuda", device_ids=[0], dtype=dtype)
+    res = score(seg, sweep, variant) if name == "sweep2" else score_pooled(seg, sweep, variant)
     print(name, dtype, json.dumps({k: v for k, v in res.items() if not k.endswith("_runs") or isinstance(v, int)}))
     assert res["structure_mismatch_runs"] == [] and res["beyond_one_frame_runs"] == [], (res["structure_mismatch_runs"][:3], res["beyond_one_frame_runs"][:3])
     assert res["cluster_mismatch_rows"] == 0 and res["within_tolerance_runs"] == len(sweep)
@@ -121,8 +124,8 @@ def test_heldout_faster_modes_stay_inside_their_measured_envelope(gpu_lib, heldo
     near-tie resolutions) and box-to-box differences."""
     from tools.parity_sweep import score_pooled
     from whisperseg_amd.model import WhisperSegmenter
-    name, sweep = heldout
-    res = score_pooled(WhisperSegmenter(MODEL2_DIR, device="cuda", device_ids=[0], dtype=dtype), sweep, "tiny2")
+    name, sweep, model_dir, variant = heldout
+    res = score_pooled(WhisperSegmenter(model_dir, device="cuda", device_ids=[0], dtype=dtype), sweep, variant)
     print(name, dtype, json.dumps({k: v for k, v in res.items() if not k.endswith("_runs") or isinstance(v, int)}))
     bad = res["structure_mismatch_runs"] + res["beyond_one_frame_runs"]
     assert len(bad) <= {"f16m6": 8, "f16": 45, "bf16": 130}[dtype], bad[:5]

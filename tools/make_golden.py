@@ -1,7 +1,7 @@
 """Generate tests/golden/* by running the REFERENCE itself (imported read-only from /root/reference,
 tools/ref_import.py) and its HuggingFace backend in the build container.
 
-    python tools/make_golden.py [--only frontend|windows|parse|tiny|sweep2|sweep3|sweep4]
+    python tools/make_golden.py [--only frontend|windows|parse|tiny|sweep2|sweep3|sweep4|sweep5]
 
 Only inputs (seeds, parameters, hand-written generated texts) and expected outputs are stored — never
 reference source.  The tests regenerate the inputs from tests/golden_inputs.py.
@@ -307,14 +307,15 @@ def make_tiny(ref_audio, ref_model):
         json.dump(meta, f)
 
 
-def make_sweep2(ref_audio, ref_model, first_seed=5000, out_name="tiny2_sweep.json", with_logits=True):
+def make_sweep2(ref_audio, ref_model, first_seed=5000, out_name="tiny2_sweep.json", with_logits=True, model="tiny_model2", variant="tiny2",
+                logits_name="tiny2_generate.npz"):
     """G9, the HELD-OUT parity sweep (r06): the reference's segment() rows for 1 000 recordings — 250 NEW seeds x
     trials {1, 3} x beams {1, 4} — of a SECOND, independently trained fixture model (tests/golden/tiny_model2: tools/tiny_model.py variant
     "tiny2" — d 256, 4 heads, 3 + 3 layers, another init seed, another data stream and signal family, full-mantissa fp32 weights).
     Every precision format of r03-r05 (fp6 cross terms, block-floating-point cross K / V, 24-bit rows, fp32 self-attention cache, ...)
     was chosen on tiny_sweep.json; nothing was tuned on this file: the formats were frozen (commit before this one) when it was recorded."""
     torch.set_num_threads(1)      # one thread: the recorded rows must not depend on how the CPU GEMMs were partitioned (serial run == parallel parts)
-    hf, segm, captured = load_fixture_segmenter(ref_model, os.path.join(OUT, "tiny_model2"))
+    hf, segm, captured = load_fixture_segmenter(ref_model, os.path.join(OUT, model))
     sweep = []
     # SWEEP2_PART="lo:hi" records seeds [lo, hi) into tiny2_sweep.part_<lo>.json (parallel workers, each OMP_NUM_THREADS=2: one serial pass
     # takes ~2 h on the build container); SWEEP2_MERGE=1 concatenates the parts in seed order into tiny2_sweep.json and records the logits
@@ -332,7 +333,7 @@ def make_sweep2(ref_audio, ref_model, first_seed=5000, out_name="tiny2_sweep.jso
         lo = hi = 0
     for seed in range(lo, hi):
         nw = 1 + seed % 3
-        audio = GI.tiny_recording(seed, nw, variant="tiny2")
+        audio = GI.tiny_recording(seed, nw, variant=variant)
         for trials in (1, 3):
             for beams in (1, 4):
                 kw = dict(num_beams=beams, num_trials=trials, batch_size=8)
@@ -347,13 +348,13 @@ def make_sweep2(ref_audio, ref_model, first_seed=5000, out_name="tiny2_sweep.jso
     if not with_logits:
         return
     # first-step logits of 4 windows (pins the oracle / the engines on this model's geometry as G6 does for the first model)
-    audio = GI.tiny_recording(5000, 3, variant="tiny2")
+    audio = GI.tiny_recording(first_seed, 3, variant=variant)
     sliced = segm.get_sliced_audios_features(audio, TM.SR, 0, TM.STS, 1)
     feats = torch.from_numpy(np.asarray([s[2] for s in sliced]))
     with torch.no_grad():
         enc = hf.model.encoder(feats).last_hidden_state
         logits = hf(input_features=feats, decoder_input_ids=torch.tensor([TM.PROMPT] * feats.shape[0])).logits[:, -1]
-    np.savez_compressed(os.path.join(OUT, "tiny2_generate.npz"), enc_out_sample=enc.numpy()[:, ::25, :], first_logits=logits.numpy())
+    np.savez_compressed(os.path.join(OUT, logits_name), enc_out_sample=enc.numpy()[:, ::25, :], first_logits=logits.numpy())
 
 
 def make_sweep3(ref_audio, ref_model):
@@ -367,6 +368,14 @@ def make_sweep4(ref_audio, ref_model):
     """G11 (r06): 1 000 more recordings of the second fixture model (seeds 9000..9249), recorded after the default had moved to f16x3 —
     more of the same evidence (the GPU side decodes a whole sweep in seconds through the pooled path; recording the reference is the cost)."""
     make_sweep2(ref_audio, ref_model, first_seed=9000, out_name="tiny2_sweep4.json", with_logits=False)
+
+
+def make_sweep5(ref_audio, ref_model):
+    """G12 (r06): 1 000 recordings (seeds 11000..11249) of a THIRD fixture model — deeper and narrower (tests/golden/tiny_model3: d 128,
+    2 heads, 4 + 4 layers, ffn 640, fp32 weights; tools/tiny_model.py variant "tiny3") — + its encoder output and first-step logits:
+    the same question (which modes reproduce the reference's rows?) on another architecture."""
+    make_sweep2(ref_audio, ref_model, first_seed=11000, out_name="tiny3_sweep.json", model="tiny_model3", variant="tiny3",
+                logits_name="tiny3_generate.npz")
 
 
 def make_wav():
@@ -390,9 +399,9 @@ def main():
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     ref_audio, ref_model = import_reference()
-    steps = dict(frontend=make_frontend, windows=make_windows, parse=make_parse, tiny=make_tiny, sweep2=make_sweep2, sweep3=make_sweep3, sweep4=make_sweep4)
+    steps = dict(frontend=make_frontend, windows=make_windows, parse=make_parse, tiny=make_tiny, sweep2=make_sweep2, sweep3=make_sweep3, sweep4=make_sweep4, sweep5=make_sweep5)
     for name, fn in steps.items():
-        if args.only is None and name in ("sweep2", "sweep3", "sweep4"):
+        if args.only is None and name in ("sweep2", "sweep3", "sweep4", "sweep5"):
             # 1 000 recordings each through HF on ONE thread (so that the rows cannot depend on how the CPU GEMMs were partitioned):
             # ~2 h serially — recorded in parallel parts by tools/record_sweep.sh (5 workers, ~25 min), never by the default run
             print("== %s: skipped by the default run; use  tools/record_sweep.sh %s" % (name, name))

@@ -28,7 +28,9 @@ SWEEPS = {"sweep1": ("tiny_sweep.json", "tiny_model", "tiny"), "sweep2_heldout":
           # 1 000 further recordings of the second model, recorded after sweep 2 had been looked at (tools/make_golden.py --only sweep3)
           "sweep3_fresh": ("tiny2_sweep3.json", "tiny_model2", "tiny2"),
           # 1 000 more, recorded after the default had moved to f16x3 (tools/record_sweep.sh sweep4)
-          "sweep4_more": ("tiny2_sweep4.json", "tiny_model2", "tiny2")}
+          "sweep4_more": ("tiny2_sweep4.json", "tiny_model2", "tiny2"),
+          # 1 000 recordings of a third model (d 128, 4 + 4 layers; tools/record_sweep.sh sweep5)
+          "sweep5_third_model": ("tiny3_sweep.json", "tiny_model3", "tiny3")}
 
 
 def _new_tally(n):

@@ -39,6 +39,10 @@ VARIANTS = {
                  init_seed=0, data_seed=1234, round_bf16=True),
     "tiny2": dict(d_model=256, heads=4, enc_layers=3, dec_layers=3, ffn=768, tones=[700.0, 2100.0, 4200.0], amp=(0.05, 0.35),
                   noise=0.008, init_seed=1, data_seed=987654, round_bf16=False),
+    # "tiny3" (r06): a THIRD model — deeper and narrower (d 128, 2 heads, 4 + 4 layers, ffn 640), its own seeds and signal family, fp32
+    # weights — for one more held-out sweep on another architecture (tests/golden/tiny_model3, tiny3_sweep.json)
+    "tiny3": dict(d_model=128, heads=2, enc_layers=4, dec_layers=4, ffn=640, tones=[600.0, 1800.0, 3600.0], amp=(0.08, 0.3),
+                  noise=0.006, init_seed=2, data_seed=424242, round_bf16=False),
 }
 
 

@@ -7,6 +7,7 @@ that beam-search parity (oracle vs HF, HIP engine vs oracle) is exercised on mea
 Weights are rounded to bf16 before saving so that the fp32 oracle and the bf16 engine share them exactly.
 
     python tools/train_tiny.py [--steps 2500]
+    python tools/train_tiny.py --variant tiny3 --lr 1e-3 --threads 6 --steps 7000 --out tests/golden/tiny_model3   (r06: the third model; final loss 0.02-0.03)
     python tools/train_tiny.py --variant tiny2 --lr 7e-4 --threads 3 --out tests/golden/tiny_model2
                                       (r06: the held-out fixture model, fp32 weights; the committed one was trained with exactly this line —
                                        at the first model's lr 2e-3 the d 256 model was still at loss 2.7 after 1 150 steps, at 7e-4 it reached
