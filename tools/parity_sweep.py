@@ -30,7 +30,10 @@ SWEEPS = {"sweep1": ("tiny_sweep.json", "tiny_model", "tiny"), "sweep2_heldout":
           # 1 000 more, recorded after the default had moved to f16x3 (tools/record_sweep.sh sweep4)
           "sweep4_more": ("tiny2_sweep4.json", "tiny_model2", "tiny2"),
           # 1 000 recordings of a third model (d 128, 4 + 4 layers; tools/record_sweep.sh sweep5)
-          "sweep5_third_model": ("tiny3_sweep.json", "tiny_model3", "tiny3")}
+          "sweep5_third_model": ("tiny3_sweep.json", "tiny_model3", "tiny3"),
+          # 1 000 more of the third model, recorded while the x3 modes' cross K / V moved to 24-bit block floating point — the remedy for
+          # f16x3's one miss on sweep 5 — and first scored after that format was frozen (tools/record_sweep.sh sweep6)
+          "sweep6_third_fresh": ("tiny3_sweep6.json", "tiny_model3", "tiny3")}
 
 
 def _new_tally(n):

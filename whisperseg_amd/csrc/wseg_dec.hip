@@ -696,8 +696,12 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
 // words' top halves, then a [Tk][64] plane of their third bytes; 192 instead of 256 bytes per row pair of an HBM-bound stream).
 // fp32 query and arithmetic; same structure as the packed 16-bit kernel above: 8 lanes per row, 8 raw rows per lane in flight
 // (16 + 8 bytes each), one v_perm_b32 per element to rebuild the fp32 word, two beams per v_pk_fma_f32, DPP row sums.
+// BFP (r06, EpiParams::kv24 == 3, the x3 modes' format): the same two planes hold 24-bit two's-complement INTEGERS and a third plane of
+// [Tk] fp32 row scales follows (196 bytes per row; st_bfp24_row in wseg_gemm_epi.h): the rebuilt word is 256 q, one v_cvt_f32_i32 per
+// element more, and the row scales are applied where a row is one number — the K scale to the finished score and the V scale to the
+// probability, both in the softmax pass over LDS — so neither streaming loop carries another register.
 // ------------------------------------------------------------------------------------------------
-template <typename TO, int NB>
+template <typename TO, int NB, bool BFP>
 __global__ __launch_bounds__(256, 4) void dec_cross_attn_k24_kernel(DecodeState st, const float* __restrict__ q,
                                                                     const unsigned char* __restrict__ ck, const unsigned char* __restrict__ cv,
                                                                     void* __restrict__ out, int H, int Tk, int d, PartialInfo pi,
@@ -717,10 +721,13 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_k24_kernel(DecodeState 
   const int nb = st.nb;
   const int sub = lane & 7, rowl = lane >> 3;
   const int ws = kv_slot ? kv_slot[w] : w;              // prompt pass: query rows of admitted window w, K / V of its slot
-  const unsigned char* Kb = ck + ((size_t)ws * H + h) * Tk * 192;
-  const unsigned char* Vb = cv + ((size_t)ws * H + h) * Tk * 192;
+  constexpr int ROWB = BFP ? 196 : 192;
+  const unsigned char* Kb = ck + ((size_t)ws * H + h) * Tk * ROWB;
+  const unsigned char* Vb = cv + ((size_t)ws * H + h) * Tk * ROWB;
   const unsigned char* Kl = Kb + (size_t)Tk * 128;
   const unsigned char* Vl = Vb + (size_t)Tk * 128;
+  const float* Ks = (const float*)(Kb + (size_t)Tk * 192);      // BFP: row scales
+  const float* Vs = (const float*)(Vb + (size_t)Tk * 192);
   constexpr int NP = (NB + 1) / 2;
   f2 qq[8][NP];
   __shared__ float sq[NB][64];                          // thread (j, e) finishes dim e of beam j (reduce1), slices come back from LDS
@@ -747,14 +754,15 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_k24_kernel(DecodeState 
       for (int e = 0; e < 8; ++e) qq[e][0][1] = 0.f;
     }
   }
-  // element e of a row slice: fp32 word = [top half e][third byte e][0]
+  // element e of a row slice: 32-bit word = [top half e][third byte e][0] — an fp32, or (BFP) the integer 256 q
   auto unpack = [](const raw16& hi, const raw8& lo, float v[8]) {
 #pragma unroll
     for (int e2 = 0; e2 < 4; ++e2) {
       const unsigned hw = hi[e2], lw = lo[e2 >> 1];
       const unsigned s0 = (e2 & 1) ? 0x0504020cu : 0x0504000cu, s1 = (e2 & 1) ? 0x0706030cu : 0x0706010cu;
-      v[2 * e2] = __uint_as_float(__builtin_amdgcn_perm(hw, lw, s0));
-      v[2 * e2 + 1] = __uint_as_float(__builtin_amdgcn_perm(hw, lw, s1));
+      const unsigned w0 = __builtin_amdgcn_perm(hw, lw, s0), w1 = __builtin_amdgcn_perm(hw, lw, s1);
+      v[2 * e2] = BFP ? (float)(int)w0 : __uint_as_float(w0);
+      v[2 * e2 + 1] = BFP ? (float)(int)w1 : __uint_as_float(w1);
     }
   };
   for (int t0 = 0; t0 < Tk; t0 += 32 * U) {
@@ -800,10 +808,14 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_k24_kernel(DecodeState 
   WSEG_STAMP(3, 4);
   for (int j = wave; j < nb; j += 4) {
     float mx = -3.0e38f;
-    for (int t = lane; t < Tk; t += 64) mx = fmaxf(mx, sc[t][j]);
+    if constexpr (BFP) {
+      for (int t = lane; t < Tk; t += 64) { const float x = sc[t][j] * Ks[t]; sc[t][j] = x; mx = fmaxf(mx, x); }
+    } else {
+      for (int t = lane; t < Tk; t += 64) mx = fmaxf(mx, sc[t][j]);
+    }
     mx = wave_max(mx);
     float sum = 0.f;
-    for (int t = lane; t < Tk; t += 64) { const float p = expf(sc[t][j] - mx); sc[t][j] = p; sum += p; }
+    for (int t = lane; t < Tk; t += 64) { const float p = expf(sc[t][j] - mx); sc[t][j] = BFP ? p * Vs[t] : p; sum += p; }
     sum = wave_sum(sum);
     if (lane == 0) sinv[j] = 1.0f / sum;
   }
@@ -1504,9 +1516,9 @@ static void launch_cross_t(const DecodeState& st, const void* q, const void* ck,
 // margin (1e-5 .. 1e-4) in f16x3.  The mixed mode's own fp6 cross terms cost 8e-5: it takes the 31 % smaller rows (1.3e-4 in all).
 // Knob builds: WSEG_X3_CKV = f32 | k24 | bfp for every split mode (attribution / A-B).
 int x3_cross_kv_format(int dtype, int nb) {
-  static const int forced = WSEG_KNOB_IS("WSEG_X3_CKV", "f32") ? 0 : (WSEG_KNOB_IS("WSEG_X3_CKV", "k24") ? 1 : (WSEG_KNOB_IS("WSEG_X3_CKV", "bfp") ? 2 : -1));
+  static const int forced = WSEG_KNOB_IS("WSEG_X3_CKV", "f32") ? 0 : (WSEG_KNOB_IS("WSEG_X3_CKV", "k24") ? 1 : (WSEG_KNOB_IS("WSEG_X3_CKV", "bfp") ? 2 : (WSEG_KNOB_IS("WSEG_X3_CKV", "bfp24") ? 3 : -1)));
   if (nb > 4) return 0;
-  return forced >= 0 ? forced : (dtype == WSEG_F16M6 ? 2 : 1);
+  return forced >= 0 ? forced : (dtype == WSEG_F16M6 ? 2 : 3);
 }
 // WSEG_F16M6: does the cross-attention write its output (the co-proj GEMM's operand) as M6 rows?  The 24-bit K / V kernel does (it
 // exists for up to 4 beams); 5..8 beams run the general fp32-K/V kernel, which writes hi | lo rows that the caller converts.
@@ -1529,9 +1541,19 @@ int launch_dec_cross_attn(int dtype, const DecodeState& st, const void* q, const
     WSEG_LAUNCH_CHECK();
     return WSEG_OK;
   }
+  if (kvf == 3) {
+    dim3 grid(st.W * H), block(256);
+#define WSEG_K24(TO_, NB_) hipLaunchKernelGGL((dec_cross_attn_k24_kernel<TO_, NB_, true>), grid, block, 0, s, st, (const float*)q, (const unsigned char*)ck, (const unsigned char*)cv, out, H, Tk, d, pi, (const float*)q_bias, scale, kv_slot)
+    if (dtype == WSEG_BF16X3) { if (st.nb <= 1) WSEG_K24(X3<bf16_t>, 1); else if (st.nb <= 2) WSEG_K24(X3<bf16_t>, 2); else WSEG_K24(X3<bf16_t>, 4); }
+    else if (m6) { if (st.nb <= 1) WSEG_K24(M6, 1); else if (st.nb <= 2) WSEG_K24(M6, 2); else WSEG_K24(M6, 4); }
+    else { if (st.nb <= 1) WSEG_K24(X3<f16_t>, 1); else if (st.nb <= 2) WSEG_K24(X3<f16_t>, 2); else WSEG_K24(X3<f16_t>, 4); }
+#undef WSEG_K24
+    WSEG_LAUNCH_CHECK();
+    return WSEG_OK;
+  }
   if (kvf == 1) {
     dim3 grid(st.W * H), block(256);
-#define WSEG_K24(TO_, NB_) hipLaunchKernelGGL((dec_cross_attn_k24_kernel<TO_, NB_>), grid, block, 0, s, st, (const float*)q, (const unsigned char*)ck, (const unsigned char*)cv, out, H, Tk, d, pi, (const float*)q_bias, scale, kv_slot)
+#define WSEG_K24(TO_, NB_) hipLaunchKernelGGL((dec_cross_attn_k24_kernel<TO_, NB_, false>), grid, block, 0, s, st, (const float*)q, (const unsigned char*)ck, (const unsigned char*)cv, out, H, Tk, d, pi, (const float*)q_bias, scale, kv_slot)
     if (dtype == WSEG_BF16X3) { if (st.nb <= 1) WSEG_K24(X3<bf16_t>, 1); else if (st.nb <= 2) WSEG_K24(X3<bf16_t>, 2); else WSEG_K24(X3<bf16_t>, 4); }
     else if (m6) { if (st.nb <= 1) WSEG_K24(M6, 1); else if (st.nb <= 2) WSEG_K24(M6, 2); else WSEG_K24(M6, 4); }
     else { if (st.nb <= 1) WSEG_K24(X3<f16_t>, 1); else if (st.nb <= 2) WSEG_K24(X3<f16_t>, 2); else WSEG_K24(X3<f16_t>, 4); }

@@ -1393,7 +1393,7 @@ static int launch_h16(const GemmArgs& g0, hipStream_t s) {
   SkinnyPlan sp = plan_skinny(g, IsMx<T>::v);
   // (block-floating-point cross K / V: the row writer needs the lanes of a row side by side, which the 4-column MFMA-layout epilogue of
   // the stream kernels does not give — an un-split plan goes through the partial plane + reduction kernel as well)
-  const bool coop_kv = EPI == EPI_KV_CROSS && IO<T>::split && g.ep.kv24 == 2;
+  const bool coop_kv = EPI == EPI_KV_CROSS && IO<T>::split && g.ep.kv24 >= 2;
   if (sp.splits == 1 && !(coop_kv && g.splitk_ws && (size_t)sp.m_pad * g.N * sizeof(float) <= g.splitk_ws_bytes)) {
     if (coop_kv) { set_error("gemm: block-floating-point cross K / V needs the split-K workspace"); return WSEG_ERR_STATE; }
     dim3 grid(g.N / 64, sp.mt, 1);

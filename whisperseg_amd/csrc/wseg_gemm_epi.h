@@ -59,6 +59,43 @@ __device__ __forceinline__ void st_bfp16_row(unsigned char* blk, int t_len, int 
   if (first_lane) *(float*)(blk + (size_t)t_len * 128 + (size_t)t * 4) = scl;
 }
 
+// Cross K / V as block floating point with 24-BIT integers (EpiParams::kv24 == 3; r06): the same row agreement, elements as two's-complement
+// 24-bit integers q with max|v| <= 2^23 * 2^s, stored in the two-plane layout of the 24-bit float format — [t_len][64] int16 (q >> 8), then
+// [t_len][64] bytes (q & 0xff) — followed by [t_len] fp32 row scales 2^(s - 8): the reader rebuilds the 32-bit word [q >> 8 | q & 0xff | 0] =
+// 256 q with the v_perm it already has, converts it with v_cvt_f32_i32 and multiplies the finished score / the probability by the stored
+// scale.  Same bytes per row as the 24-bit floats (+ 4), error <= 2^-24 of the ROW maximum instead of 2^-17 of every element: the 24-bit
+// floats were the largest term of f16x3's logit error (2e-5 of 2.5e-5) and cost it one of 4 200 sweep recordings.
+template <int NC>
+__device__ __forceinline__ void st_bfp24_row(unsigned char* blk, int t_len, int t, int e, const float (&v)[NC], bool first_lane) {
+  static_assert(NC == 4 || NC == 8, "4 or 8 columns per lane");
+  float am = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) am = fmaxf(am, fabsf(v[i]));
+  am = fmaxf(am, lane_xor<1>(am));
+  am = fmaxf(am, lane_xor<2>(am));
+  am = fmaxf(am, lane_xor<4>(am));
+  if constexpr (NC == 4) am = fmaxf(am, lane_xor<8>(am));
+  const unsigned bits = __float_as_uint(am);
+  int ex = (int)(bits >> 23) - 127 + ((bits & 0x7fffffu) ? 1 : 0) - 23;      // ceil(log2 max) - 23
+  ex = max(-100, min(ex, 100));
+  const float inv = __uint_as_float((unsigned)(127 - ex) << 23), scl = __uint_as_float((unsigned)(127 + ex - 8) << 23);
+  int q[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) q[i] = max(-8388607, min(8388607, (int)__builtin_rintf(v[i] * inv)));
+  unsigned hw[NC / 2];
+#pragma unroll
+  for (int i = 0; i < NC / 2; ++i) hw[i] = (((unsigned)q[2 * i] >> 8) & 0xffffu) | ((((unsigned)q[2 * i + 1] >> 8) & 0xffffu) << 16);
+  unsigned lw[NC / 4];
+#pragma unroll
+  for (int i = 0; i < NC / 4; ++i)
+    lw[i] = ((unsigned)q[4 * i] & 0xffu) | (((unsigned)q[4 * i + 1] & 0xffu) << 8) | (((unsigned)q[4 * i + 2] & 0xffu) << 16) | (((unsigned)q[4 * i + 3] & 0xffu) << 24);
+  unsigned char* dh = blk + (size_t)t * 128 + e * 2;
+  unsigned char* dl = blk + (size_t)t_len * 128 + (size_t)t * 64 + e;
+  if constexpr (NC == 8) { *(uint4*)dh = make_uint4(hw[0], hw[1], hw[2], hw[3]); *(uint2*)dl = make_uint2(lw[0], lw[1]); }
+  else { *(uint2*)dh = make_uint2(hw[0], hw[1]); *(unsigned*)dl = lw[0]; }
+  if (first_lane) *(float*)(blk + (size_t)t_len * 192 + (size_t)t * 4) = scl;
+}
+
 // T: element-type tag of the mode (float | bf16_t | f16_t | X3<HT>); PT: its plain parameter type (bias, positional table,
 // q / k / v storage: float in the split-precision modes).  Outputs that are the NEXT GEMM's operand (EPI_STORE, EPI_GELU) go
 // through op_st*, i.e. as hi | lo pairs in the split-precision modes.
@@ -133,6 +170,9 @@ __device__ __forceinline__ void epi_apply(const EpiParams& ep, int m, int n0, fl
     if (IO<T>::split && ep.kv24 == 2) {      // (reached from the split-K reduction only: 16 consecutive threads hold one row)
       unsigned char* blk = (unsigned char*)(sec == 0 ? ep.k : ep.v) + ((size_t)bs * ep.n_heads + h) * ep.t_len * 132;
       st_bfp16_row<4>(blk, ep.t_len, t, e, *(const float(*)[4])v, e == 0);
+    } else if (IO<T>::split && ep.kv24 == 3) {
+      unsigned char* blk = (unsigned char*)(sec == 0 ? ep.k : ep.v) + ((size_t)bs * ep.n_heads + h) * ep.t_len * 196;
+      st_bfp24_row<4>(blk, ep.t_len, t, e, *(const float(*)[4])v, e == 0);
     } else if (IO<T>::split && ep.kv24) {
       unsigned char* blk = (unsigned char*)(sec == 0 ? ep.k : ep.v) + ((size_t)bs * ep.n_heads + h) * ep.t_len * 192;
       unsigned w[4];
@@ -260,6 +300,9 @@ __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, f
     if (IO<T>::split && ep.kv24 == 2) {      // the 8 lanes of the row (LDS-staged epilogues: lane & 7 = column group)
       unsigned char* blk = (unsigned char*)(sec == 0 ? ep.k : ep.v) + ((size_t)bs * ep.n_heads + h) * ep.t_len * 132;
       st_bfp16_row<8>(blk, ep.t_len, t, e, *(const float(*)[8])v, e == 0);
+    } else if (IO<T>::split && ep.kv24 == 3) {
+      unsigned char* blk = (unsigned char*)(sec == 0 ? ep.k : ep.v) + ((size_t)bs * ep.n_heads + h) * ep.t_len * 196;
+      st_bfp24_row<8>(blk, ep.t_len, t, e, *(const float(*)[8])v, e == 0);
     } else if (IO<T>::split && ep.kv24) {
       EpiParams e2 = ep;                        // the bias has been added above
       e2.bias = nullptr;

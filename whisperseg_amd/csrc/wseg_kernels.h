@@ -124,7 +124,9 @@ int x3_enc_attention_mode();
 // "ckv=bfp16r", profiles/r05_precision_study.json) for 132 instead of 192 bytes per row of an HBM-bound stream: f16m6 (wseg_dec.hip,
 // x3_cross_kv_format, says why the three-MFMA modes do not take it).
 int x3_cross_kv_format(int dtype, int nb);      // 0 = fp32 (more than 4 beams), 1 = 24-bit (bf16x3 / f16x3), 2 = bfp16 rows (f16m6)
-static inline size_t cross_kv_row_bytes(int fmt, size_t es) { return fmt == 2 ? 132 : (fmt == 1 ? 192 : 64 * es); }
+// 3 (r06: bf16x3 / f16x3) = block floating point with 24-bit integers in the two-plane layout of format 1 + [t_len] fp32 row scales:
+// the bytes of the 24-bit floats (+ 4 per row), ~100x their precision relative to the row maximum (st_bfp24_row, wseg_gemm_epi.h).
+static inline size_t cross_kv_row_bytes(int fmt, size_t es) { return fmt == 3 ? 196 : (fmt == 2 ? 132 : (fmt == 1 ? 192 : 64 * es)); }
 // WSEG_F16M6: hi | lo IEEE-half operand rows [M][2K words] -> M6 rows [M][4K bytes] (wseg_common.h), K % 64 == 0
 int launch_x3_to_m6(const void* x3_rows, void* m6_rows, size_t M, int K, bool weight_order, hipStream_t s);
 // the dtype every NON-GEMM kernel runs in: WSEG_F16M6 is WSEG_F16X3 outside the GEMMs
