@@ -141,6 +141,9 @@ def test_third_fixture_encoder_logits_and_rows(golden_dir):
     _, logits = W.generate(sd, rc, feats, gp, return_first_logits=True)
     assert np.max(np.abs(logits.numpy() - z["first_logits"])) <= 3e-3
     seg = OracleSegmenter(Policy(""), model_dir=mdir)
-    for run in sweep[0:4] + sweep[600:604]:
+    with open(os.path.join(golden_dir, "tiny3_sweep6.json")) as f:      # sweep 6: 1 000 more of the same model (tools/record_sweep.sh sweep6)
+        sweep6 = json.load(f)
+    assert len(sweep6) == 1000 and {r["seed"] for r in sweep6} == set(range(13000, 13250))
+    for run in sweep[0:4] + sweep[600:604] + sweep6[0:4] + sweep6[700:702]:
         got = seg.segment(GI.tiny_recording(run["seed"], run["n_windows"], variant="tiny3"), TM.SR, **run["kwargs"])
         assert got == run["expected"], (run["seed"], run["kwargs"])

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Record a held-out parity sweep (tests/golden/tiny2_sweep.json = sweep2, tiny2_sweep3.json = sweep3, tiny2_sweep4.json = sweep4, tiny3_sweep.json = sweep5 on the third model) from the reference in parallel parts:
+# Record a held-out parity sweep (tests/golden/tiny2_sweep.json = sweep2, tiny2_sweep3.json = sweep3, tiny2_sweep4.json = sweep4, tiny3_sweep.json = sweep5 and tiny3_sweep6.json = sweep6 on the third model) from the reference in parallel parts:
 #   tools/record_sweep.sh sweep2|sweep3|sweep4|sweep5|sweep6 [workers=5]
 # Every worker runs tools/make_golden.py on ONE thread over its share of the 250 seeds (SWEEP2_PART=lo:hi), the parts are merged in seed
 # order (SWEEP2_MERGE=1).  The result is byte-identical to a serial  python tools/make_golden.py --only <sweep>  (same single-thread arithmetic).
