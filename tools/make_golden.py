@@ -1,7 +1,7 @@
 """Generate tests/golden/* by running the REFERENCE itself (imported read-only from /root/reference,
 tools/ref_import.py) and its HuggingFace backend in the build container.
 
-    python tools/make_golden.py [--only frontend|windows|parse|tiny|sweep2|sweep3|sweep4|sweep5|sweep6]
+    python tools/make_golden.py [--only frontend|windows|parse|tiny|sweep2|sweep3|sweep4|sweep5|sweep6|sweep7]
 
 Only inputs (seeds, parameters, hand-written generated texts) and expected outputs are stored — never
 reference source.  The tests regenerate the inputs from tests/golden_inputs.py.
@@ -384,6 +384,12 @@ def make_sweep6(ref_audio, ref_model):
     make_sweep2(ref_audio, ref_model, first_seed=13000, out_name="tiny3_sweep6.json", with_logits=False, model="tiny_model3", variant="tiny3")
 
 
+def make_sweep7(ref_audio, ref_model):
+    """G14 (r06): 1 000 more of the third model (seeds 15000..15249), recorded after the x3 modes' 24-bit block-floating-point rows had been
+    frozen and scored on sweep 6: a second fresh sample of the model that had cost the default its one miss."""
+    make_sweep2(ref_audio, ref_model, first_seed=15000, out_name="tiny3_sweep7.json", with_logits=False, model="tiny_model3", variant="tiny3")
+
+
 def make_wav():
     import struct
     src = "/root/reference/data/example_subset/Meerkat/test/VALP007_AL_6_15DEC2022_MF_ML.wav"
@@ -405,9 +411,9 @@ def main():
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     ref_audio, ref_model = import_reference()
-    steps = dict(frontend=make_frontend, windows=make_windows, parse=make_parse, tiny=make_tiny, sweep2=make_sweep2, sweep3=make_sweep3, sweep4=make_sweep4, sweep5=make_sweep5, sweep6=make_sweep6)
+    steps = dict(frontend=make_frontend, windows=make_windows, parse=make_parse, tiny=make_tiny, sweep2=make_sweep2, sweep3=make_sweep3, sweep4=make_sweep4, sweep5=make_sweep5, sweep6=make_sweep6, sweep7=make_sweep7)
     for name, fn in steps.items():
-        if args.only is None and name in ("sweep2", "sweep3", "sweep4", "sweep5", "sweep6"):
+        if args.only is None and name in ("sweep2", "sweep3", "sweep4", "sweep5", "sweep6", "sweep7"):
             # 1 000 recordings each through HF on ONE thread (so that the rows cannot depend on how the CPU GEMMs were partitioned):
             # ~2 h serially — recorded in parallel parts by tools/record_sweep.sh (5 workers, ~25 min), never by the default run
             print("== %s: skipped by the default run; use  tools/record_sweep.sh %s" % (name, name))

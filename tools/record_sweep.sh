@@ -1,13 +1,13 @@
 #!/bin/bash
-# Record a held-out parity sweep (tests/golden/tiny2_sweep.json = sweep2, tiny2_sweep3.json = sweep3, tiny2_sweep4.json = sweep4, tiny3_sweep.json = sweep5 and tiny3_sweep6.json = sweep6 on the third model) from the reference in parallel parts:
-#   tools/record_sweep.sh sweep2|sweep3|sweep4|sweep5|sweep6 [workers=5]
+# Record a held-out parity sweep (tests/golden/tiny2_sweep.json = sweep2, tiny2_sweep3.json = sweep3, tiny2_sweep4.json = sweep4, tiny3_sweep.json = sweep5 and tiny3_sweep6.json = sweep6, tiny3_sweep7.json = sweep7 on the third model) from the reference in parallel parts:
+#   tools/record_sweep.sh sweep2|sweep3|sweep4|sweep5|sweep6|sweep7 [workers=5]
 # Every worker runs tools/make_golden.py on ONE thread over its share of the 250 seeds (SWEEP2_PART=lo:hi), the parts are merged in seed
 # order (SWEEP2_MERGE=1).  The result is byte-identical to a serial  python tools/make_golden.py --only <sweep>  (same single-thread arithmetic).
 set -eu
 cd "$(dirname "$0")/.."
 NAME=${1:?sweep2 or sweep3}
 W=${2:-5}
-case $NAME in sweep2) FIRST=5000;; sweep3) FIRST=7000;; sweep4) FIRST=9000;; sweep5) FIRST=11000;; sweep6) FIRST=13000;; *) echo "unknown sweep $NAME"; exit 2;; esac
+case $NAME in sweep2) FIRST=5000;; sweep3) FIRST=7000;; sweep4) FIRST=9000;; sweep5) FIRST=11000;; sweep6) FIRST=13000;; sweep7) FIRST=15000;; *) echo "unknown sweep $NAME"; exit 2;; esac
 STEP=$(( (250 + W - 1) / W ))
 pids=()
 for ((i = 0; i < W; i++)); do
