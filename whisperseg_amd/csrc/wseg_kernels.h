@@ -57,9 +57,11 @@ struct EpiParams {
   int vt_tiled = 0;              // EPI_QKV_ENC: V^T in the MFMA operand order of the 16-bit attention kernel (vt_tiled_index, wseg_common.h)
                                  // instead of plain [b][h][64][t_pad] rows (the fp32 attention kernels): enc_attention_vt_tiled(dtype)
   int kv24 = 0;                  // split-precision modes, EPI_KV_CROSS storage of the cross K / V (x3_cross_kv_format): 0 = fp32;
-                                 // 1 = 24-bit values in two planes per (slot, head): [t_len][64] top halves (16 bits) then [t_len][64]
-                                 // third bytes (bf16x3 / f16x3); 2 (f16m6, r05) = block floating point, one block per (position, head) row:
-                                 // [t_len][64] int16 then [t_len] fp32 powers of two, value = int16 * scale (132 bytes per row)
+                                 // 1 = 24-bit FLOATS in two planes per (slot, head): [t_len][64] top halves (16 bits) then [t_len][64]
+                                 // third bytes (knob builds; bf16x3 / f16x3 until mid r06); 2 (f16m6, r05) = block floating point, one block
+                                 // per (position, head) row: [t_len][64] int16 then [t_len] fp32 powers of two, value = int16 * scale (132
+                                 // bytes per row); 3 (bf16x3 / f16x3, r06) = block floating point with 24-bit integers in the two planes
+                                 // of format 1, then [t_len] fp32 powers of two (196 bytes per row)
 };
 
 struct GemmArgs {
@@ -118,7 +120,7 @@ int launch_enc_attention(int dtype, const void* q, const void* k, const void* vt
 int x3_enc_attention_mode();
 // Storage format of the cross-attention K / V in the split-precision modes (EpiParams::kv24) and its bytes per (position, head) row.
 // 1 = fp32 words rounded to their top 24 bits (sign, exponent, 15 + 1 mantissa bits — the ">= 16 bits" the precision study asks of the
-// cross K; 3 instead of 4 bytes per element of an HBM-bound stream): bf16x3 / f16x3.
+// cross K; 3 instead of 4 bytes per element of an HBM-bound stream): bf16x3 / f16x3 until mid r06, now a knob-build format.
 // 2 = per-row block floating point (r05): the 200-recording sweep through the CPU oracle with K and V so quantised is 200 / 200 and the
 // first-step logit error stays at the mixed mode's own 1.5e-4 (24-bit: 1.5e-4; plain half: 7.5e-4, 196 / 200; tools/precision_study.py
 // "ckv=bfp16r", profiles/r05_precision_study.json) for 132 instead of 192 bytes per row of an HBM-bound stream: f16m6 (wseg_dec.hip,
