@@ -33,7 +33,9 @@ SWEEPS = {"sweep1": ("tiny_sweep.json", "tiny_model", "tiny"), "sweep2_heldout":
           "sweep5_third_model": ("tiny3_sweep.json", "tiny_model3", "tiny3"),
           # 1 000 more of the third model, recorded while the x3 modes' cross K / V moved to 24-bit block floating point — the remedy for
           # f16x3's one miss on sweep 5 — and first scored after that format was frozen (tools/record_sweep.sh sweep6)
-          "sweep6_third_fresh": ("tiny3_sweep6.json", "tiny_model3", "tiny3")}
+          "sweep6_third_fresh": ("tiny3_sweep6.json", "tiny_model3", "tiny3"),
+          # ... and 1 000 more, recorded after that format had been frozen and scored on sweep 6 (tools/record_sweep.sh sweep7)
+          "sweep7_third_fresh2": ("tiny3_sweep7.json", "tiny_model3", "tiny3")}
 
 
 def _new_tally(n):
