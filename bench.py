@@ -11,10 +11,10 @@ resident in HBM -> log-mel kernels -> Whisper encoder -> cross-K/V -> beam-searc
 token ids to the host -> detokenise + regex parse (the CPU epilogue).  Workload (BASELINE.json metric):
 whisperseg-large geometry (1550 M), 30 s windows, in the split-precision mode `f16x3` (the product default since r06) — GEMM operands as
 hi + lo IEEE-half pairs, every product as hi x hi + hi x lo + lo x hi on the f16 MFMA tiles, fp32 everywhere else: a mode whose rows are
-identical to the reference's on all 5 200 recordings of the six parity sweeps (profiles/r06_parity_sweeps.json; `bf16x3`: 5 198, under
+identical to the reference's on all 6 200 recordings of the seven parity sweeps (profiles/r06_parity_sweeps.json; `bf16x3`: 6 198, under
 `extra.other_tolerance_meeting_modes`; the exact mode f32 reproduces them by construction).  The r04-r05 headline mode `f16m6` (cross terms
 on the fp6 MX matrix cores, 27 % faster) was
-found OUTSIDE the north-star tolerance on 9 of the 5 000 held-out recordings of r06 and is reported, labelled so,
+found OUTSIDE the north-star tolerance on 10 of the 6 000 held-out recordings of r06 and is reported, labelled so,
 under `extra.faster_modes_outside_the_tolerance` beside plain bf16 / f16 —
 (spec_time_step 0.03 @ 16 kHz, 480 000 samples,
 SURVEY §8d), by default 1024 concurrent windows (8 h 32 min of audio) per GPU per step — the engine's default slot count,
@@ -88,8 +88,8 @@ def parity_note(dtype):
     GPU by tools/parity_sweep.py --sweeps; the same rows are asserted by tests/test_parity_sweep_gpu.py): recordings whose rows are inside
     the north-star tolerance (clusters exact, every boundary within +-1 mel frame) / identical to the reference's, in total and per sweep
     — sweep1 = the 200 recordings of the first fixture model (every precision format of r03-r05 was chosen on it), sweeps 2-4 = 3 x 1 000
-    held-out recordings of a second, independently trained model, sweeps 5-6 = 2 x 1 000 recordings of a third one (sweep 6 recorded
-    and first scored after the last format change of r06, the 24-bit block-floating-point cross K / V rows of the x3 modes)."""
+    held-out recordings of a second, independently trained model, sweeps 5-7 = 3 x 1 000 recordings of a third one (sweeps 6 and 7
+    first scored after the last format change of r06, the 24-bit block-floating-point cross K / V rows of the x3 modes)."""
     path = os.path.join(ROOT, "profiles", "r06_parity_sweeps.json")
     try:
         with open(path) as f:
@@ -421,9 +421,9 @@ def main(argv=None, backend=make_backend):
     ap.add_argument("--spec-time-step", type=float, default=0.03)
     ap.add_argument("--dtype", default="f16x3", choices=["bf16", "f16", "f32", "bf16x3", "f16x3", "f16m6"],
                     help="engine mode of the timed step.  f16x3 (default, the segmenter's default since r06): split precision, GEMM operands "
-                         "as hi + lo IEEE-half pairs and three MFMAs per product — rows identical to the reference's on all 5 200 recordings of "
-                         "the six parity sweeps; bf16x3: the same with bfloat16 pairs (5 198); f16m6: hi*hi on the half matrix cores "
-                         "and both cross terms on the fp6 MX matrix cores — 27 %% faster and outside the tolerance on 9 of 5 000 held-out "
+                         "as hi + lo IEEE-half pairs and three MFMAs per product — rows identical to the reference's on all 6 200 recordings of "
+                         "the seven parity sweeps; bf16x3: the same with bfloat16 pairs (6 198); f16m6: hi*hi on the half matrix cores "
+                         "and both cross terms on the fp6 MX matrix cores — 27 %% faster and outside the tolerance on 10 of 6 000 held-out "
                          "recordings; bf16 / f16: plain 16-bit modes (outside it on 9 %% / 1.5 %%); f32: exact-parity mode")
     ap.add_argument("--cpu-windows", type=int, default=4, help="windows of the CPU baseline sample (4 x 30 s: ~25 s of CPU work for the HF model and the port together)")
     ap.add_argument("--check-windows", type=int, default=4, help="windows re-decoded in f32 mode for the self-check")
@@ -869,7 +869,7 @@ def extra_lines(args, eng, step, main_in, make_extractor, device, W, slots):
         out["other_tolerance_meeting_modes"] = others
         # the modes that are FASTER AND OUTSIDE THE TOLERANCE (labelled; never the headline).  f16m6: half MFMA tiles + both cross terms on
         # the fp6 MX matrix cores — the default and the headline of r04-r05, which the held-out sweeps of r06 put outside the tolerance
-        # on 9 of 5 000 recordings (profiles/r06_parity_sweeps.json); bf16 is the dtype BASELINE.json names; f16 is what the
+        # on 10 of 6 000 recordings (profiles/r06_parity_sweeps.json); bf16 is the dtype BASELINE.json names; f16 is what the
         # reference's own CT2 fast path computes in (model.py:691).  W windows, and the full step workload (W_step windows through
         # W_step slots; the main engine's workspace is handed back first)
         plain = {}

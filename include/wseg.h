@@ -54,8 +54,8 @@ typedef enum {
    * two cross terms hi*lo + lo*hi on the block-scaled MX matrix cores (fp6 e2m3 operands with per-32-element e8m0 scales, 4x the
    * 16-bit rate): 3.25 instead of 6 matrix-core issue units per 64 logical columns at a ~2^-15 operand error.  Weight
    * matrices are attached as "M6 rows" produced by wseg_convert_operand from the WSEG_F16X3 rows.  PARITY (r06): rows
-   * identical to the reference's on the 200 recordings the mode was designed on, OUTSIDE the north-star tolerance on 9 of 5 000
-   * held-out recordings — a fast mode; the Python layer defaults to WSEG_F16X3 (all 5 200 sweep recordings identical, like WSEG_F32). */
+   * identical to the reference's on the 200 recordings the mode was designed on, OUTSIDE the north-star tolerance on 10 of 6 000
+   * held-out recordings — a fast mode; the Python layer defaults to WSEG_F16X3 (all 6 200 sweep recordings identical, like WSEG_F32). */
   WSEG_F16M6 = 5
 } wseg_dtype;
 

@@ -144,6 +144,9 @@ def test_third_fixture_encoder_logits_and_rows(golden_dir):
     with open(os.path.join(golden_dir, "tiny3_sweep6.json")) as f:      # sweep 6: 1 000 more of the same model (tools/record_sweep.sh sweep6)
         sweep6 = json.load(f)
     assert len(sweep6) == 1000 and {r["seed"] for r in sweep6} == set(range(13000, 13250))
-    for run in sweep[0:4] + sweep[600:604] + sweep6[0:4] + sweep6[700:702]:
+    with open(os.path.join(golden_dir, "tiny3_sweep7.json")) as f:      # sweep 7: and 1 000 more (tools/record_sweep.sh sweep7)
+        sweep7 = json.load(f)
+    assert len(sweep7) == 1000 and {r["seed"] for r in sweep7} == set(range(15000, 15250))
+    for run in sweep[0:4] + sweep[600:604] + sweep6[0:4] + sweep6[700:702] + sweep7[300:302]:
         got = seg.segment(GI.tiny_recording(run["seed"], run["n_windows"], variant="tiny3"), TM.SR, **run["kwargs"])
         assert got == run["expected"], (run["seed"], run["kwargs"])

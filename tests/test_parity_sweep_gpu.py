@@ -1,16 +1,16 @@
-"""North-star parity over SIX sweeps (5 200 recordings, three fixture models) of rows recorded from the reference's own segment() on HF
+"""North-star parity over SEVEN sweeps (6 200 recordings, three fixture models) of rows recorded from the reference's own segment() on HF
 fp32 (tools/make_golden.py):
 sweep 1 — 200 recordings of the first fixture model, the set every precision format of r03-r05 was chosen on; sweep 2 — 1 000 held-out
 recordings of a second, independently trained model (formats frozen before it was recorded); sweep 3 — 1 000 further recordings
 recorded after sweep 2 had been looked at (the fresh test of the default that sweep 2 led to); sweep 4 — 1 000 more; sweep 5 — 1 000
 recordings of a THIRD model (deeper and narrower); sweep 6 — 1 000 more of the third model, first scored after the last format change
-of r06.  The exact mode f32 must reproduce EVERY row of all six.  The product default f16x3 does too (asserted: 0 recordings beyond
-+-1 mel frame, clusters bit-exact, rows identical, on all 5 200) — since its cross K / V rows became 24-bit block floating point: with
+of r06; sweep 7 — 1 000 more, recorded after sweep 6 had been scored.  The exact mode f32 must reproduce EVERY row of all seven.  The product default f16x3 does too (asserted: 0 recordings beyond
++-1 mel frame, clusters bit-exact, rows identical, on all 6 200) — since its cross K / V rows became 24-bit block floating point: with
 the 24-bit FLOAT rows of r03 - mid r06 it missed ONE recording of sweep 5 (a greedy decision whose top-1 / top-2 margin in the fp32
-oracle is 2.8e-5; profiles/r06_parity_sweeps_x3_k24rows.json), which is what that change was made for, and sweep 6 is the fresh test of
-it.  bf16x3 reproduces sweeps 1-4 and 6 and misses two recordings of sweep 5 (its GEMM error, not the rows).  No 16-bit-operand mode is
-exact by construction; the measured rates are 0 / 2 / 9 of 5 200 (f16x3 / bf16x3 / f16m6; profiles/r06_parity_sweeps.json).  f16m6 (the
-default of r04-r05) reproduces sweeps 1 and 6 and is OUTSIDE the tolerance on 2 / 3 / 1 / 3 of the 1 000 recordings of sweeps 2 / 3 / 4 / 5:
+oracle is 2.8e-5; profiles/r06_parity_sweeps_x3_k24rows.json), which is what that change was made for, and sweeps 6 and 7 are the fresh
+tests of it.  bf16x3 reproduces sweeps 1-4, 6 and 7 and misses two recordings of sweep 5 (its GEMM error, not the rows).  No 16-bit-operand mode is
+exact by construction; the measured rates are 0 / 2 / 10 of 6 200 (f16x3 / bf16x3 / f16m6; profiles/r06_parity_sweeps.json).  f16m6 (the
+default of r04-r05) reproduces sweeps 1 and 6 and is OUTSIDE the tolerance on 2 / 3 / 1 / 3 / 1 of the 1 000 recordings of sweeps 2 / 3 / 4 / 5 / 7:
 it is characterised, like the plain 16-bit modes f16 / bf16 — they must stay inside the measured envelope committed in
 profiles/r06_parity_sweeps.json (scored with tools/parity_sweep.py)."""
 import json
@@ -83,10 +83,11 @@ def test_16_bit_modes_stay_inside_their_measured_envelope(gpu_lib, sweep, dtype)
 # name -> (rows, fixture model, signal family).  sweep 4: 1 000 more of the second model (seeds 9000..9249); sweep 5: 1 000 recordings of
 # a THIRD model (d 128, 4 + 4 layers, fp32 weights: tests/golden/tiny_model3) — the same question on another architecture; sweep 6: 1 000
 # more of the third model (seeds 13000..13249), recorded while the x3 modes' cross K / V rows moved from 24-bit floats to 24-bit block
-# floating point (the remedy for f16x3's one miss on sweep 5) and first scored with that format frozen.
+# floating point (the remedy for f16x3's one miss on sweep 5) and first scored with that format frozen; sweep 7: 1 000 more (seeds
+# 15000..15249), recorded after sweep 6 had been scored.
 HELDOUT = {"sweep2": ("tiny2_sweep.json", "tiny_model2", "tiny2"), "sweep3": ("tiny2_sweep3.json", "tiny_model2", "tiny2"),
            "sweep4": ("tiny2_sweep4.json", "tiny_model2", "tiny2"), "sweep5": ("tiny3_sweep.json", "tiny_model3", "tiny3"),
-           "sweep6": ("tiny3_sweep6.json", "tiny_model3", "tiny3")}
+           "sweep6": ("tiny3_sweep6.json", "tiny_model3", "tiny3"), "sweep7": ("tiny3_sweep7.json", "tiny_model3", "tiny3")}
 
 
 @pytest.fixture(scope="module", params=sorted(HELDOUT))
@@ -105,12 +106,12 @@ def test_heldout_sweeps_are_big_enough(heldout):
 
 @pytest.mark.parametrize("dtype", ["f32", "f16x3", "bf16x3"])
 def test_heldout_exact_and_split_precision_modes_reproduce_every_row(gpu_lib, heldout, dtype):
-    """f32: exact by construction, on every sweep.  f16x3 (the default): every row of the held-out sweeps 2-6 identical to the
+    """f32: exact by construction, on every sweep.  f16x3 (the default): every row of the held-out sweeps 2-7 identical to the
     reference's — asserted as the north-star tolerance (clusters exact, boundaries within +-1 frame on EVERY recording) AND as
-    bit-identical rows.  bf16x3: the same on sweeps 2-4 and 6; on sweep 5 (the third model) it misses 2 recordings (see below).
-    Sweep 2: every recording through its own segment() call, as the rows were recorded (~50 s per mode).  Sweeps 3-6: the POOLED path —
+    bit-identical rows.  bf16x3: the same on sweeps 2-4, 6 and 7; on sweep 5 (the third model) it misses 2 recordings (see below).
+    Sweep 2: every recording through its own segment() call, as the rows were recorded (~50 s per mode).  Sweeps 3-7: the POOLED path —
     two segment_batch() calls, ~1 900 windows sharing the engine's slots, admitted in whatever groups the scheduler forms — the rows
-    must be the reference's either way.  profiles/r06_parity_sweeps.json holds the per-file record of all six sweeps in every mode."""
+    must be the reference's either way.  profiles/r06_parity_sweeps.json holds the per-file record of all seven sweeps in every mode."""
     from tools.parity_sweep import score, score_pooled
     from whisperseg_amd.model import WhisperSegmenter
     name, sweep, model_dir, variant = heldout
@@ -123,7 +124,7 @@ def test_heldout_exact_and_split_precision_modes_reproduce_every_row(gpu_lib, he
         # time token of one window, top-1 / top-2 margin 2.8e-5 in the fp32 oracle) and ONE more — 577 (seed 11144) with the 24-bit
         # float cross K / V rows of mid r06, 957 (seed 11239) with the 24-bit block-floating-point rows it ships with: its GEMM error
         # (bfloat16 pairs, 1.3e-5 of the logit scale) is the cause, the rows only move which near-tie falls.  This is a
-        # characterisation set from that measurement, not a tolerance: the claim for bf16x3 is "5 198 of 5 200"; f16x3 and f32
+        # characterisation set from that measurement, not a tolerance: the claim for bf16x3 is "6 198 of 6 200"; f16x3 and f32
         # (asserted below on every sweep) reproduce everything.
         assert len(bad) <= 2, bad[:5]
         assert {b["seed"] for b in bad} <= {11116, 11239}, bad
@@ -142,8 +143,8 @@ def test_default_mode_is_the_split_mode_that_reproduces_every_sweep():
 @pytest.mark.parametrize("dtype", ["f16m6", "f16", "bf16"])
 def test_heldout_faster_modes_stay_inside_their_measured_envelope(gpu_lib, heldout, dtype):
     """CHARACTERISATION of the modes that are faster and outside the tolerance: recordings (of 1 000) with a row-count / cluster
-    difference or a boundary more than one mel frame off must not exceed the committed per-file measurement (f16m6 2 / 3 / 1 / 3 / 0, f16 14 /
-    15 / 26 / 28 / 12, bf16 95 / 91 / 91 / 104 / 103 on sweeps 2 / 3 / 4 / 5 / 6, profiles/r06_parity_sweeps.json) plus slack for the pooled path used here (other neighbours, other
+    difference or a boundary more than one mel frame off must not exceed the committed per-file measurement (f16m6 2 / 3 / 1 / 3 / 0 / 1, f16 14 /
+    15 / 26 / 28 / 12 / 17, bf16 95 / 91 / 91 / 104 / 103 / 81 on sweeps 2 / 3 / 4 / 5 / 6 / 7, profiles/r06_parity_sweeps.json) plus slack for the pooled path used here (other neighbours, other
     near-tie resolutions) and box-to-box differences."""
     from tools.parity_sweep import score_pooled
     from whisperseg_amd.model import WhisperSegmenter

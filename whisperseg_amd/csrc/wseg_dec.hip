@@ -1514,7 +1514,7 @@ static void launch_cross_t(const DecodeState& st, const void* q, const void* ck,
 // wseg_kernels.h.  The three-MFMA modes' GEMMs are exact to ~6e-6 of a logit on the parity sweeps' models; the 24-bit FLOAT rows of
 // r03 - mid r06 (format 1) added 2e-5 — which cost f16x3 one of 4 200 sweep recordings (a greedy decision with a margin of 2.8e-5;
 // fp32 rows reproduce it) —, 16-bit block-floating-point rows 6e-5: since r06 these modes store 24-bit block floating point (format 3:
-// the bytes of format 1 + 4 per row, error <= 2^-24 of the row maximum), with which f16x3 reproduces all 5 200 recordings of the six
+// the bytes of format 1 + 4 per row, error <= 2^-24 of the row maximum), with which f16x3 reproduces all 6 200 recordings of the seven
 // sweeps.  The mixed mode's own fp6 cross terms cost 8e-5: it takes the 31 % smaller 16-bit rows (1.3e-4 in all).
 // Knob builds: WSEG_X3_CKV = f32 | k24 | bfp | bfp24 for every split mode (attribution / A-B).
 int x3_cross_kv_format(int dtype, int nb) {

@@ -28,14 +28,14 @@ PROMPT_TOKENS = ["<|startoftranscript|>", "<|en|>", "<|notimestamps|>"]   # refe
 # Engine mode when neither the constructor nor $WHISPERSEG_AMD_DTYPE names one: "f16x3", split precision — the reference computes in
 # fp32 (model.py:655-666); here GEMM operands (activations AND weights) travel as hi + lo IEEE-half pairs and every product is taken as
 # hi*hi + hi*lo + lo*hi on the half matrix cores with fp32 accumulation, fp32 everywhere else; first-step logits within 3.3e-6 of the logit
-# scale of the exact mode at 32 + 32 layers.  Its rows are identical to the reference's on all 5 200 recordings of the six parity
-# sweeps (200 + 3 x 1 000 + 2 x 1 000 recordings of three fixture models; profiles/r06_parity_sweeps.json — measured, not structural:
-# "f32" is the mode that reproduces the reference by construction), "bf16x3" on 5 198 (bfloat16 pairs: 1.3e-5; no
+# scale of the exact mode at 32 + 32 layers.  Its rows are identical to the reference's on all 6 200 recordings of the seven parity
+# sweeps (200 + 3 x 1 000 + 3 x 1 000 recordings of three fixture models; profiles/r06_parity_sweeps.json — measured, not structural:
+# "f32" is the mode that reproduces the reference by construction), "bf16x3" on 6 198 (bfloat16 pairs: 1.3e-5; no
 # fp16 range limit on the GEMM operands — the encoder attention's Q / K / V^T are IEEE-half pairs in every split mode and saturate at
 # +-65 504).  "f16m6" — hi*hi on the half matrix cores, both cross terms on the block-scaled fp6 MX matrix cores, 27 % faster — was the
 # default of r04-r05: it reproduces the 200 recordings its formats were chosen on, and the held-out sweeps of r06 found it outside the
-# north-star tolerance (clusters exact, boundaries within +-1 mel frame) on 9 of 5 000 held-out recordings: a fast mode, like "f16" / "bf16"
-# (plain 16-bit: 2x faster, 98 % / 90 % of the held-out recordings inside the tolerance).  "f32" is the exact-parity mode.
+# north-star tolerance (clusters exact, boundaries within +-1 mel frame) on 10 of 6 000 held-out recordings: a fast mode, like "f16" / "bf16"
+# (plain 16-bit: 2x faster, 98 % / 91 % of the held-out recordings inside the tolerance).  "f32" is the exact-parity mode.
 DEFAULT_DTYPE = "f16x3"
 POOL_WINDOWS = 8192      # windows per engine call / per pooled group of files (2.6 GB of log-mel features)
 
@@ -390,7 +390,7 @@ class WhisperSegmenterFast(WhisperSegmenter):
     """reference model.py:678-746 is the CTranslate2 backend (float16 on a GPU, model.py:691), which the reference's CLI and
     evaluation try first (scripts/segment.py:34-37, evaluate.py:62-65).  Here it is the same MI355X engine as WhisperSegmenter and
     — because those call sites make it the DEFAULT path of the CLI — it defaults to the same split-precision mode ("f16x3": rows
-    identical to the reference's on all 5 200 sweep recordings).  `dtype="f16"` (or $WHISPERSEG_AMD_DTYPE=f16) selects what CT2
+    identical to the reference's on all 6 200 sweep recordings).  `dtype="f16"` (or $WHISPERSEG_AMD_DTYPE=f16) selects what CT2
     computes in: plain IEEE half, 1.9x faster, 98 % of the held-out recordings within +-1 mel frame.  A CTranslate2-converted
     directory (binary `model.bin` + `hf_model/` without HF weights) cannot be read and raises, which makes the try-Fast-then-
     fallback idiom behave as it does upstream when ctranslate2 is missing."""
