@@ -701,6 +701,12 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
 // element more, and the row scales are applied where a row is one number — the K scale to the finished score and the V scale to the
 // probability, both in the softmax pass over LDS — so neither streaming loop carries another register.
 // ------------------------------------------------------------------------------------------------
+#ifndef WSEG_CA_PREFETCH
+#define WSEG_CA_PREFETCH 1      // first V rows requested in front of the softmax pass, row scales parked in LDS (A/B: build --variant nopf -DWSEG_CA_PREFETCH=0)
+#endif
+#ifndef WSEG_CA_PREFETCH_K
+#define WSEG_CA_PREFETCH_K 0    // first K rows in front of the query reduction: 8 rows x 6 registers live across it spill at 128 registers (r06: 8-24 VGPRs)
+#endif
 template <typename TO, int NB, bool BFP>
 __global__ __launch_bounds__(256, 4) void dec_cross_attn_k24_kernel(DecodeState st, const float* __restrict__ q,
                                                                     const unsigned char* __restrict__ ck, const unsigned char* __restrict__ cv,
@@ -728,9 +734,26 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_k24_kernel(DecodeState 
   const unsigned char* Vl = Vb + (size_t)Tk * 128;
   const float* Ks = (const float*)(Kb + (size_t)Tk * 192);      // BFP: row scales
   const float* Vs = (const float*)(Vb + (size_t)Tk * 192);
+  // BFP: the row scales wait in LDS for the softmax pass (read from global there, each wave's first access paid an HBM round trip with no
+  // stream in flight); visible behind the barrier that closes the score pass
+  __shared__ float sks[BFP && WSEG_CA_PREFETCH ? 512 : 1], svs[BFP && WSEG_CA_PREFETCH ? 512 : 1];
+  if constexpr (BFP && WSEG_CA_PREFETCH) {
+    for (int t = tid; t < Tk; t += 256) { sks[t] = Ks[t]; svs[t] = Vs[t]; }
+  }
   constexpr int NP = (NB + 1) / 2;
   f2 qq[8][NP];
   __shared__ float sq[NB][64];                          // thread (j, e) finishes dim e of beam j (reduce1), slices come back from LDS
+  raw16 kh[U];
+  raw8 kl[U];
+  auto load_k = [&](int t0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = min(t0 + u * 32 + wave * 8 + rowl, Tk - 1);      // clamped: out-of-range rows are discarded below
+      kh[u] = __builtin_nontemporal_load((const raw16*)(Kb + (size_t)t * 128 + sub * 16));
+      kl[u] = __builtin_nontemporal_load((const raw8*)(Kl + (size_t)t * 64 + sub * 8));
+    }
+  };
+  if constexpr (WSEG_CA_PREFETCH_K) load_k(0);          // the stream starts under the query's split-K reduction
   if (pi.part != nullptr) {
     if (tid < NB * 64) sq[tid >> 6][tid & 63] = reduce1<float>(pi, w * nb + min(tid >> 6, nb - 1), h * 64 + (tid & 63), q_bias) * scale;
     __syncthreads();
@@ -766,14 +789,7 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_k24_kernel(DecodeState 
     }
   };
   for (int t0 = 0; t0 < Tk; t0 += 32 * U) {
-    raw16 kh[U];
-    raw8 kl[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int t = min(t0 + u * 32 + wave * 8 + rowl, Tk - 1);      // clamped: out-of-range rows are discarded below
-      kh[u] = __builtin_nontemporal_load((const raw16*)(Kb + (size_t)t * 128 + sub * 16));
-      kl[u] = __builtin_nontemporal_load((const raw8*)(Kl + (size_t)t * 64 + sub * 8));
-    }
+    if (!WSEG_CA_PREFETCH_K || t0 > 0) load_k(t0);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int t = t0 + u * 32 + wave * 8 + rowl;
@@ -804,18 +820,31 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_k24_kernel(DecodeState 
     }
   }
   WSEG_STAMP(3, 3);                                 // scores
+  // The first V rows are requested HERE, in front of the softmax pass (the K registers are dead: no register is added), so the stream does
+  // not stop between the two passes: their HBM round trip runs under the softmax instead of behind it.
+  raw16 vh[U];
+  raw8 vl[U];
+  auto load_v = [&](int t0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = min(t0 + u * 32 + wave * 8 + rowl, Tk - 1);
+      vh[u] = __builtin_nontemporal_load((const raw16*)(Vb + (size_t)t * 128 + sub * 16));
+      vl[u] = __builtin_nontemporal_load((const raw8*)(Vl + (size_t)t * 64 + sub * 8));
+    }
+  };
+  if constexpr (WSEG_CA_PREFETCH) load_v(0);
   __syncthreads();
   WSEG_STAMP(3, 4);
   for (int j = wave; j < nb; j += 4) {
     float mx = -3.0e38f;
     if constexpr (BFP) {
-      for (int t = lane; t < Tk; t += 64) { const float x = sc[t][j] * Ks[t]; sc[t][j] = x; mx = fmaxf(mx, x); }
+      for (int t = lane; t < Tk; t += 64) { const float x = sc[t][j] * (WSEG_CA_PREFETCH ? sks[t] : Ks[t]); sc[t][j] = x; mx = fmaxf(mx, x); }
     } else {
       for (int t = lane; t < Tk; t += 64) mx = fmaxf(mx, sc[t][j]);
     }
     mx = wave_max(mx);
     float sum = 0.f;
-    for (int t = lane; t < Tk; t += 64) { const float p = expf(sc[t][j] - mx); sc[t][j] = BFP ? p * Vs[t] : p; sum += p; }
+    for (int t = lane; t < Tk; t += 64) { const float p = expf(sc[t][j] - mx); sc[t][j] = BFP ? p * (WSEG_CA_PREFETCH ? svs[t] : Vs[t]) : p; sum += p; }
     sum = wave_sum(sum);
     if (lane == 0) sinv[j] = 1.0f / sum;
   }
@@ -828,14 +857,7 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_k24_kernel(DecodeState 
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[j][e] = (f2){0.f, 0.f};
   for (int t0 = 0; t0 < Tk; t0 += 32 * U) {
-    raw16 vh[U];
-    raw8 vl[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int t = min(t0 + u * 32 + wave * 8 + rowl, Tk - 1);
-      vh[u] = __builtin_nontemporal_load((const raw16*)(Vb + (size_t)t * 128 + sub * 16));
-      vl[u] = __builtin_nontemporal_load((const raw8*)(Vl + (size_t)t * 64 + sub * 8));
-    }
+    if (!WSEG_CA_PREFETCH || t0 > 0) load_v(t0);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int t = t0 + u * 32 + wave * 8 + rowl;
