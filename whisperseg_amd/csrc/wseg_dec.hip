@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256, 4) void dec_cross_attn_pk_kernel(DecodeState s
 #define WSEG_CA_PREFETCH 1      // first V rows requested in front of the softmax pass, row scales parked in LDS (A/B: build --variant nopf -DWSEG_CA_PREFETCH=0)
 #endif
 #ifndef WSEG_CA_PREFETCH_K
-#define WSEG_CA_PREFETCH_K 0    // first K rows in front of the query reduction: 8 rows x 6 registers live across it spill at 128 registers (r06: 8-24 VGPRs)
+#define WSEG_CA_PREFETCH_K 0    // first K rows in front of the query reduction: rows live across reduce1 spill at 128 registers (r06: 8 rows 8-24 VGPRs, 4 rows 4-31)
 #endif
 template <typename TO, int NB, bool BFP>
 __global__ __launch_bounds__(256, 4) void dec_cross_attn_k24_kernel(DecodeState st, const float* __restrict__ q,
