@@ -676,6 +676,18 @@ def roofline_leg(args, lib, step, W, world, windows_per_s, flops_window):
            "traffic": traffic, "traffic_note": traffic_note, "launches_per_step": int(n.value),
            "avg_launch_us": ms.value * 1e3 / n.value, "flops_per_step": fl.value,
            "end_to_end_frac": windows_per_s / world * flops_window / MFMA_PEAK_BF16}
+    # matrix-pipe busy share of the SHADER cycles from the committed SQ-counter pass of this mode's GEMM (separate rocprofv3 --pmc passes, like
+    # the traffic; profiles/r06_x3_gemm_sq_counters.json): mfma_pipe_frac below is the same quantity against the NOMINAL 2.4 GHz peak
+    if args.model == "large" and args.dtype in ("f16x3", "bf16x3"):
+        try:
+            with open(os.path.join(ROOT, "profiles", "r06_x3_gemm_sq_counters.json")) as f:
+                sq = json.load(f)["per_launch"]
+            out["mfma_busy_pmc"] = {"per_shape": {k.split(" ")[0]: round(v["mfma_busy_fraction"], 3) for k, v in sq.items()},
+                                    "note": "SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs per launch, committed pass "
+                                            "profiles/r06_x3_gemm_sq_counters.json (f16x3, 256-window encoder shapes): busy share of the "
+                                            "cycles of the clock the kernel actually gets"}
+        except (OSError, KeyError, ValueError):
+            pass
     if x3:
         out.update({"mfma_issue_multiplier": mult, "mfma_pipe_frac": mult * achieved / (MFMA_PEAK_BF16 / 1e12),
                     "note": "achieved / frac = ALGORITHMIC 2*M*N*K per second (what the fp32 reference computes) against the dense 16-bit "
