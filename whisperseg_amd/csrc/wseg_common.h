@@ -403,6 +403,24 @@ __device__ __forceinline__ gelu_f2 gelu_erf_fast2(gelu_f2 x) {
 }
 template <typename T> __device__ __forceinline__ float gelu_for(float x) { return gelu_erf_fast(x); }      // 16-bit modes
 template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }
+// eight elements of an 8-column epilogue: pairs through the packed form in the 16-bit / split modes (bit-identical to gelu_for, 4.5 issue
+// slots per element fewer), the exact erff in f32 mode
+#ifndef WSEG_GELU_PACKED
+#define WSEG_GELU_PACKED 1      // A/B: build --variant sgelu -DWSEG_GELU_PACKED=0
+#endif
+template <typename T> __device__ __forceinline__ void gelu8_for(float* v) {
+  if constexpr (WSEG_GELU_PACKED) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) { const gelu_f2 y = gelu_erf_fast2((gelu_f2){v[e], v[e + 1]}); v[e] = y[0]; v[e + 1] = y[1]; }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gelu_erf_fast(v[e]);
+  }
+}
+template <> __device__ __forceinline__ void gelu8_for<float>(float* v) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+}
 
 // Value of lane (l ^ M) of a wave64 WITHOUT the LDS crossbar: __shfl_xor compiles to ds_bpermute_b32 + s_waitcnt, ~60-100 cycles
 // of exposed latency each — the 96 of them that close a cross-attention workgroup were 5.7 of its 14 us at 8 slots (in-kernel

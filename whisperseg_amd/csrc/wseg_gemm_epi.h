@@ -239,8 +239,7 @@ __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, f
   if constexpr (EPI == EPI_STORE) {
     op_st8<T>(ep.out, (size_t)m, ep.ldc, n0, v);
   } else if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = gelu_for<T>(v[i]);
+    gelu8_for<T>(v);
     op_st8<T>(ep.out, (size_t)m, ep.ldc, n0, v);
   } else if constexpr (EPI == EPI_RESID) {      // the residual stream is fp32 in every mode
     const float* rp = (const float*)ep.resid + (size_t)m * ep.ldc + n0;
@@ -251,8 +250,9 @@ __device__ __forceinline__ void epi_apply8(const EpiParams& ep, int m, int n0, f
   } else if constexpr (EPI == EPI_GELU_POS) {   // conv2 -> residual stream (fp32)
     float p[8];
     ld8_h<PT>((const PT*)ep.pos + (size_t)(m % ep.pos_rows) * ep.ldc + n0, p);
+    gelu8_for<T>(v);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = gelu_for<T>(v[i]) + p[i];
+    for (int i = 0; i < 8; ++i) v[i] += p[i];
     float* o = (float*)ep.out + (size_t)m * ep.ldc + n0;
     *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
     *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
